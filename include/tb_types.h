@@ -1,0 +1,70 @@
+/* Plain-data types that cross the C ABI of the tracking hot path.
+ *
+ * Layouts mirror the OpenCV 3.x types the reference's operator API passes
+ * (reference: include/extractors/ORBextractor.h:38-52, include/matchers/matcher.h:39-62,
+ * include/mapping/LocalBA.h:16-22) so a binding can reinterpret_cast vectors of
+ * cv::KeyPoint / cv::DMatch without a copy.
+ */
+#ifndef TB_TYPES_H
+#define TB_TYPES_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* == cv::KeyPoint (28 bytes): pt.x, pt.y, size, angle, response, octave, class_id */
+typedef struct tb_keypoint {
+    float x, y;
+    float size;
+    float angle;
+    float response;
+    int32_t octave;
+    int32_t class_id;
+} tb_keypoint;
+
+/* == cv::DMatch (16 bytes) */
+typedef struct tb_match {
+    int32_t queryIdx;
+    int32_t trainIdx;
+    int32_t imgIdx;
+    float distance;
+} tb_match;
+
+/* One FAST corner: integer pixel position inside the scanned image + score. */
+typedef struct tb_corner {
+    int32_t x, y, score;
+} tb_corner;
+
+/* One motion-only BA observation (reference: src/mapping/LocalBA.cpp:333-363):
+ * pixel (Feature::px), world point (MapPoint::GetWorldPos), information scale
+ * (Frame::GetInverseScaleSigmaSquares()[octave]). */
+typedef struct tb_obs {
+    float u, v;
+    float X, Y, Z;
+    float inv_sigma2;
+} tb_obs;
+
+/* One local-BA observation: keyframe index, point index, pixel, information scale. */
+typedef struct tb_ba_obs {
+    int32_t kf, pt;
+    float u, v;
+    float inv_sigma2;
+} tb_ba_obs;
+
+/* Error codes (0 = ok). */
+enum {
+    TB_OK = 0,
+    TB_EINVAL = -1,       /* bad argument (null pointer, non-positive size, ...) */
+    TB_ENOMEM = -2,       /* host or device allocation failed */
+    TB_ECAPACITY = -3,    /* caller-provided output capacity too small */
+    TB_EUNSUPPORTED = -4, /* reference behaviour undefined/broken for this input */
+    TB_EDEVICE = -5,      /* HIP runtime error; see tb_last_error() */
+    TB_ESTATE = -6        /* call sequence error (e.g. AddPoints before operator()) */
+};
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TB_TYPES_H */

@@ -1,0 +1,270 @@
+"""TEST INFRASTRUCTURE ONLY -- ctypes binding of the CPU oracle (oracle/liboracle.so).
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import this
+package.  The product package (trackingbench_slam_amd) never does.
+
+Parity status: "parity unpinned" against genuine OpenCV 3.3 / g2o / fast_lib -- the
+reference holds no golden vectors and those libraries are absent; the
+oracle restates their published algorithms next to the reference's own code.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+KEYPOINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+MATCH = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])
+CORNER = np.dtype([("x", "<i4"), ("y", "<i4"), ("score", "<i4")])
+OBS = np.dtype([("u", "<f4"), ("v", "<f4"), ("X", "<f4"), ("Y", "<f4"), ("Z", "<f4"), ("inv_sigma2", "<f4")])
+BA_OBS = np.dtype([("kf", "<i4"), ("pt", "<i4"), ("u", "<f4"), ("v", "<f4"), ("inv_sigma2", "<f4")])
+
+
+def build(force=False):
+    so = os.path.join(_HERE, "liboracle.so")
+    if force or not os.path.exists(so):
+        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+    return so
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        _LIB = C.CDLL(build())
+        _LIB.orc_ic_angle.restype = C.c_float
+        _LIB.orc_shi_tomasi.restype = C.c_float
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _u8(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    assert img.ndim == 2
+    return img
+
+
+class OracleError(RuntimeError):
+    pass
+
+
+def _chk(rc):
+    if rc < 0:
+        raise OracleError("oracle error %d" % rc)
+    return rc
+
+
+def scale_factors(n, scale):
+    sf = np.zeros(n, np.float32); isf = np.zeros(n, np.float32)
+    s2 = np.zeros(n, np.float32); is2 = np.zeros(n, np.float32)
+    _chk(lib().orc_scale_factors(n, C.c_float(scale), _p(sf), _p(isf), _p(s2), _p(is2)))
+    return sf, isf, s2, is2
+
+
+def pyramid_sizes(w, h, sf):
+    n = len(sf)
+    ws = np.zeros(n, np.int32); hs = np.zeros(n, np.int32)
+    sf = np.ascontiguousarray(sf, np.float32)
+    _chk(lib().orc_pyramid_sizes(w, h, n, _p(sf), _p(ws), _p(hs)))
+    return ws, hs
+
+
+def resize_linear(src, dw, dh):
+    src = _u8(src)
+    dst = np.zeros((dh, dw), np.uint8)
+    _chk(lib().orc_resize_linear_u8(_p(src), src.shape[1], src.shape[0], src.strides[0], _p(dst), dw, dh, dw))
+    return dst
+
+
+def pyramid(img, nlevels, scale):
+    """Frame::ComputePyramid: list of level images (level 0 aliases img)."""
+    img = _u8(img)
+    sf = scale_factors(nlevels, scale)[0]
+    ws, hs = pyramid_sizes(img.shape[1], img.shape[0], sf)
+    levels = [img]
+    for i in range(1, nlevels):
+        levels.append(resize_linear(levels[i - 1], int(ws[i]), int(hs[i])))
+    return levels, sf
+
+
+def fast9(img, th, nms=True):
+    img = _u8(img)
+    cap = img.size // (4 if nms else 1) + 64
+    out = np.zeros(cap, CORNER)
+    n = _chk(lib().orc_fast9(_p(img), img.shape[1], img.shape[0], img.strides[0], int(th), int(nms), _p(out), cap))
+    return out[:n].copy()
+
+
+def fast10_nms(img, th=20):
+    img = _u8(img)
+    cap = img.size // 4 + 64
+    out = np.zeros(cap, CORNER)
+    n = _chk(lib().orc_fast10_nms(_p(img), img.shape[1], img.shape[0], img.strides[0], int(th), _p(out), cap))
+    return out[:n].copy()
+
+
+def fast_score_map(img, arc=9):
+    img = _u8(img)
+    out = np.zeros(img.shape, np.int16)
+    _chk(lib().orc_fast_score_map(_p(img), img.shape[1], img.shape[0], img.strides[0], arc, _p(out)))
+    return out
+
+
+def gaussian7(img):
+    img = _u8(img)
+    out = np.zeros_like(img)
+    _chk(lib().orc_gaussian7(_p(img), img.shape[1], img.shape[0], img.strides[0], _p(out), out.strides[0]))
+    return out
+
+
+def ic_angle(img, x, y):
+    img = _u8(img)
+    return float(lib().orc_ic_angle(_p(img), img.strides[0], C.c_float(x), C.c_float(y)))
+
+
+def orb_descriptor(blurred, x, y, angle):
+    img = _u8(blurred)
+    d = np.zeros(32, np.uint8)
+    lib().orc_orb_descriptor(_p(img), img.strides[0], C.c_float(x), C.c_float(y), C.c_float(angle), _p(d))
+    return d
+
+
+def orb_quotas(sf, target):
+    sf = np.ascontiguousarray(sf, np.float32)
+    q = np.zeros(len(sf), np.int32)
+    _chk(lib().orc_orb_quotas(len(sf), _p(sf), int(target), _p(q)))
+    return q
+
+
+def orb_candidates(img, init_th, min_th):
+    img = _u8(img)
+    cap = img.size // 4 + 64
+    out = np.zeros(cap, CORNER)
+    n = _chk(lib().orc_orb_candidates(_p(img), img.shape[1], img.shape[0], img.strides[0],
+                                      C.c_float(init_th), C.c_float(min_th), _p(out), cap))
+    return out[:n].copy()
+
+
+def distribute_octtree(cand, min_x, max_x, min_y, max_y, quota, exit_keys=None):
+    cand = np.ascontiguousarray(cand, CORNER)
+    out = np.zeros(len(cand) + 1, CORNER)
+    ek = None if exit_keys is None else np.ascontiguousarray(exit_keys, KEYPOINT)
+    n = _chk(lib().orc_distribute_octtree(_p(cand), len(cand), _p(ek), 0 if ek is None else len(ek),
+                                          min_x, max_x, min_y, max_y, int(quota), _p(out), len(out)))
+    return out[:n].copy()
+
+
+def _level_args(levels):
+    levels = [_u8(l) for l in levels]
+    n = len(levels)
+    ptrs = (C.c_void_p * n)(*[l.ctypes.data for l in levels])
+    ws = np.array([l.shape[1] for l in levels], np.int32)
+    hs = np.array([l.shape[0] for l in levels], np.int32)
+    st = np.array([l.strides[0] for l in levels], np.int32)
+    return levels, ptrs, ws, hs, st
+
+
+def orb_extract(levels, sf, target, init_th, min_th, exit_keys=None, quotas=None):
+    """ORBExtractor::operator() (quotas None) or AddPoints (quotas given). Returns (kps, desc, quotas)."""
+    levels, ptrs, ws, hs, st = _level_args(levels)
+    sf = np.ascontiguousarray(sf, np.float32)
+    cap = sum(int(l.size) for l in levels) // 4 + 64
+    kps = np.zeros(cap, KEYPOINT)
+    desc = np.zeros((cap, 32), np.uint8)
+    use_q = quotas is not None
+    q = np.zeros(len(levels), np.int32) if quotas is None else np.ascontiguousarray(quotas, np.int32).copy()
+    ek = None if exit_keys is None else np.ascontiguousarray(exit_keys, KEYPOINT)
+    n = _chk(lib().orc_orb_extract(ptrs, _p(ws), _p(hs), _p(st), len(levels), _p(sf), int(target),
+                                   C.c_float(init_th), C.c_float(min_th), _p(ek), 0 if ek is None else len(ek),
+                                   int(use_q), _p(q), _p(kps), _p(desc), cap))
+    return kps[:n].copy(), desc[:n].copy(), q
+
+
+def fastgrid_extract(levels, inv_sf, target, threshold, occupancy=None):
+    levels, ptrs, ws, hs, st = _level_args(levels)
+    inv_sf = np.ascontiguousarray(inv_sf, np.float32)
+    cap = max(int(target), 1) * 4 + 4096
+    kps = np.zeros(cap, KEYPOINT)
+    occ = None if occupancy is None else np.ascontiguousarray(occupancy, np.uint8)
+    n = _chk(lib().orc_fastgrid_extract(ptrs, _p(ws), _p(hs), _p(st), len(levels), _p(inv_sf), int(target),
+                                        C.c_float(threshold), _p(occ), 0 if occ is None else len(occ), _p(kps), cap))
+    return kps[:n].copy()
+
+
+def shi_tomasi(img, u, v):
+    img = _u8(img)
+    return float(lib().orc_shi_tomasi(_p(img), img.shape[1], img.shape[0], img.strides[0], int(u), int(v)))
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return int(lib().orc_descriptor_distance(_p(a), _p(b)))
+
+
+def three_maxima(sizes):
+    sizes = np.ascontiguousarray(sizes, np.int32)
+    i1, i2, i3 = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+    lib().orc_three_maxima(_p(sizes), len(sizes), C.byref(i1), C.byref(i2), C.byref(i3))
+    return i1.value, i2.value, i3.value
+
+
+def _desc(d):
+    d = np.ascontiguousarray(d, np.uint8)
+    if d.size == 0:
+        d = d.reshape(0, 32)
+    assert d.ndim == 2 and d.shape[1] == 32
+    return d
+
+
+def bf_match(d1, d2, crosscheck=True):
+    d1, d2 = _desc(d1), _desc(d2)
+    out = np.zeros(max(len(d1), 1), MATCH)
+    n = _chk(lib().orc_bf_match(_p(d1), len(d1), _p(d2), len(d2), int(crosscheck), _p(out), len(out)))
+    return out[:n].copy()
+
+
+def search_by_bf(d1, d2, ratio, min_th):
+    d1, d2 = _desc(d1), _desc(d2)
+    out = np.zeros(max(len(d1), 1), MATCH)
+    n = _chk(lib().orc_search_by_bf(_p(d1), len(d1), _p(d2), len(d2), C.c_float(ratio), C.c_float(min_th),
+                                    _p(out), len(out)))
+    return out[:n].copy()
+
+
+def search_by_violence(k1, d1, k2, d2, img2_w, img2_h, min_level=0, max_level=1, radius=10.0,
+                       th_low=50, nratio=0.0, histo_len=30, check_orientation=True):
+    k1 = np.ascontiguousarray(k1, KEYPOINT); k2 = np.ascontiguousarray(k2, KEYPOINT)
+    d1, d2 = _desc(d1), _desc(d2)
+    out = np.zeros(max(len(k1), 1), MATCH)
+    n = _chk(lib().orc_search_by_violence(_p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), int(img2_w), int(img2_h),
+                                          int(min_level), int(max_level), C.c_float(radius), int(th_low),
+                                          C.c_float(nratio), int(histo_len), int(check_orientation), _p(out), len(out)))
+    return out[:n].copy()
+
+
+def pose_opt(K, Tcw, obs, outlier=None):
+    K = np.ascontiguousarray(K, np.float64)
+    Tcw = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+    obs = np.ascontiguousarray(obs, OBS)
+    outl = np.zeros(len(obs), np.uint8) if outlier is None else np.ascontiguousarray(outlier, np.uint8).copy()
+    out = np.zeros(16, np.float32)
+    stats = np.zeros(8, np.float64)
+    n = _chk(lib().orc_pose_opt(_p(K), _p(Tcw), _p(obs), len(obs), _p(outl), _p(out), _p(stats)))
+    return n, out.reshape(4, 4), outl, stats
+
+
+def local_ba(K, poses, nfixed, pts, obs, iters=10):
+    K = np.ascontiguousarray(K, np.float64)
+    poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16).copy()
+    pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 3).copy()
+    obs = np.ascontiguousarray(obs, BA_OBS)
+    stats = np.zeros(8, np.float64)
+    n = _chk(lib().orc_local_ba(_p(K), len(poses), int(nfixed), _p(poses), len(pts), _p(pts), _p(obs), len(obs),
+                                int(iters), _p(stats)))
+    return n, poses.reshape(-1, 4, 4), pts, stats

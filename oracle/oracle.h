@@ -1,0 +1,88 @@
+/* TEST INFRASTRUCTURE ONLY -- C entry points of the CPU oracle (see orc_math.h
+ * for the usage rule and the parity status).  Every function restates one
+ * stage of the reference hot path and cites the reference file:line it
+ * follows in oracle.cpp / oracle_match.cpp / oracle_pose.cpp.
+ */
+#ifndef ORACLE_H
+#define ORACLE_H
+
+#include "../include/tb_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* Frame::Frame scale vectors, Frame.cpp:18-29. Arrays of n floats. */
+int orc_scale_factors(int n, float scale, float* sf, float* inv_sf, float* sigma2, float* inv_sigma2);
+/* Frame::ComputePyramid sizes, Frame.cpp:423-424. */
+int orc_pyramid_sizes(int w, int h, int n, const float* sf, int* ws, int* hs);
+/* cv::resize 8U INTER_LINEAR (OpenCV 3.3 fixed point), SURVEY App. A.1. */
+int orc_resize_linear_u8(const uint8_t* src, int sw, int sh, int sstride,
+                         uint8_t* dst, int dw, int dh, int dstride);
+/* cv::FAST(img, kps, th, nms) TYPE_9_16, SURVEY App. A.2. Returns count (or <0). */
+int orc_fast9(const uint8_t* img, int w, int h, int stride, int th, int nms,
+              tb_corner* out, int cap);
+/* fast::fast_corner_detect_10 + fast_corner_score_10 + fast_nonmax_3x3 (FASTextractor.cpp:36-51). */
+int orc_fast10_nms(const uint8_t* img, int w, int h, int stride, int th,
+                   tb_corner* out, int cap);
+/* FAST score map S(p) = max t such that p is a FAST-{arc} corner at threshold t (or -1). */
+int orc_fast_score_map(const uint8_t* img, int w, int h, int stride, int arc, int16_t* out);
+/* cv::GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) 8U, SURVEY App. A.5. */
+int orc_gaussian7(const uint8_t* src, int w, int h, int sstride, uint8_t* dst, int dstride);
+/* IC_Angle, ORBextractor.cpp:17-44. */
+float orc_ic_angle(const uint8_t* img, int stride, float x, float y);
+/* computeOrbDescriptor, ORBextractor.cpp:48-87 (img = blurred level). */
+void orc_orb_descriptor(const uint8_t* img, int stride, float x, float y, float angle_deg, uint8_t* desc32);
+/* per-level quota, ORBextractor.cpp:919-930. */
+int orc_orb_quotas(int nlevels, const float* sf, int target, int* quotas);
+/* cell-grid FAST candidates of one level, ORBextractor.cpp:747-804 (coords relative to the 16-px border). */
+int orc_orb_candidates(const uint8_t* img, int w, int h, int stride, float init_th, float min_th,
+                       tb_corner* out, int cap);
+/* DistributeOctTree, ORBextractor.cpp:494-733. cand coords relative to the border; returns count. */
+int orc_distribute_octtree(const tb_corner* cand, int ncand, const tb_keypoint* exit_keys, int nexit,
+                           int min_x, int max_x, int min_y, int max_y, int quota,
+                           tb_corner* out, int cap);
+/* ORBExtractor::operator() (quotas_inout computed and written) / AddPoints (use_quotas=1: read). */
+int orc_orb_extract(const uint8_t* const* levels, const int* ws, const int* hs, const int* strides,
+                    int nlevels, const float* sf, int target, float init_th, float min_th,
+                    const tb_keypoint* exit_keys, int nexit, int use_quotas, int* quotas_inout,
+                    tb_keypoint* kps, uint8_t* desc, int cap);
+/* FASTExtractor::operator(), FASTextractor.cpp:8-80. occupancy may be NULL. */
+int orc_fastgrid_extract(const uint8_t* const* levels, const int* ws, const int* hs, const int* strides,
+                         int nlevels, const float* inv_sf, int target, float threshold,
+                         const uint8_t* occupancy, int nocc, tb_keypoint* kps, int cap);
+float orc_shi_tomasi(const uint8_t* img, int w, int h, int stride, int u, int v);
+
+/* Matcher::DescriptorDistance, matcher.cpp:793-808. */
+int orc_descriptor_distance(const uint8_t* a, const uint8_t* b);
+/* Matcher::ComputeThreeMaxima, matcher.cpp:810-851 (histogram given as bin sizes). */
+void orc_three_maxima(const int* sizes, int L, int* i1, int* i2, int* i3);
+/* cv::BFMatcher(NORM_HAMMING, crossCheck).match, OpenCV 3.3 batchDistance semantics [memory]. */
+int orc_bf_match(const uint8_t* d1, int n1, const uint8_t* d2, int n2, int crosscheck,
+                 tb_match* out, int cap);
+/* Matcher::searchByBF whole-set branch, matcher.cpp:168-228. */
+int orc_search_by_bf(const uint8_t* d1, int n1, const uint8_t* d2, int n2, float ratio, float min_th,
+                     tb_match* out, int cap);
+/* Matcher::searchByViolence, matcher.cpp:299-395 with Frame grid Frame.cpp:187-265.
+ * img2_w/img2_h = level-0 size of F2 (grid factors, Frame.cpp:30-31). */
+int orc_search_by_violence(const tb_keypoint* k1, const uint8_t* d1, int n1,
+                           const tb_keypoint* k2, const uint8_t* d2, int n2,
+                           int img2_w, int img2_h, int min_level, int max_level, float radius,
+                           int th_low, float nratio, int histo_len, int check_orientation,
+                           tb_match* out, int cap);
+
+/* LocalBA::PoseOptimization, LocalBA.cpp:291-490 (g2o LM restated).
+ * K = fx,fy,cx,cy. Tcw_in: row-major 4x4 float (vertex reset value). outlier: in/out flags.
+ * Returns nInitialCorrespondences - nBad (>=0) or <0 on error. */
+int orc_pose_opt(const double K[4], const float Tcw_in[16], const tb_obs* obs, int n,
+                 uint8_t* outlier, float Tcw_out[16], double* stats /* nullable, 8 doubles */);
+
+/* North-star extension with NO reference counterpart: multi-keyframe local BA,
+ * LM + Schur complement in double. poses: nkf x 16 row-major Tcw (float in/out), pts: npt x 3. */
+int orc_local_ba(const double K[4], int nkf, int nfixed, float* poses, int npt, float* pts,
+                 const tb_ba_obs* obs, int nobs, int iters, double* stats /* nullable, 8 doubles */);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,208 @@
+/* TEST INFRASTRUCTURE ONLY -- CPU oracle, matcher stages (see orc_math.h for the usage rule).
+ * Restates src/matchers/matcher.cpp:168-228, :299-395, :793-851 and the Frame lookup grid of
+ * src/types/Frame.cpp:30-31,187-265. cv::BFMatcher semantics are OpenCV 3.3's batchDistance
+ * restated from memory (library absent): PARITY UNPINNED against genuine OpenCV.
+ */
+#include "oracle.h"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <vector>
+
+extern "C" {
+
+/* Matcher::DescriptorDistance, matcher.cpp:793-808 (8 x 32-bit SWAR popcount). */
+int orc_descriptor_distance(const uint8_t* a, const uint8_t* b) {
+    int dist = 0;
+    for (int i = 0; i < 8; i++) {
+        int32_t pa, pb;
+        std::memcpy(&pa, a + 4 * i, 4);
+        std::memcpy(&pb, b + 4 * i, 4);
+        unsigned int v = pa ^ pb;
+        v = v - ((v >> 1) & 0x55555555);
+        v = (v & 0x33333333) + ((v >> 2) & 0x33333333);
+        dist += (int)(((((v + (v >> 4)) & 0xF0F0F0F) * 0x1010101u) >> 24) & 0xff);
+    }
+    return dist;
+}
+
+/* Matcher::ComputeThreeMaxima, matcher.cpp:810-851. i1..i3 must be initialised by the caller
+ * (the reference passes -1,-1,-1 at :379). */
+void orc_three_maxima(const int* sizes, int L, int* ind1, int* ind2, int* ind3) {
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = sizes[i];
+        if (s > max1) {
+            max3 = max2; max2 = max1; max1 = s;
+            *ind3 = *ind2; *ind2 = *ind1; *ind1 = i;
+        } else if (s > max2) {
+            max3 = max2; max2 = s;
+            *ind3 = *ind2; *ind2 = i;
+        } else if (s > max3) {
+            max3 = s;
+            *ind3 = i;
+        }
+    }
+    if ((float)max2 < 0.1f * (float)max1) {
+        *ind2 = -1;
+        *ind3 = -1;
+    } else if ((float)max3 < 0.1f * (float)max1) {
+        *ind3 = -1;
+    }
+}
+
+/* cv::BFMatcher(NORM_HAMMING, crossCheck)::match(query=d1, train=d2), OpenCV 3.3 [memory]:
+ *  - without cross-check: for each query the nearest train (first index on ties);
+ *  - with cross-check (batchDistance(..., crosscheck=true)): for each TRAIN row i take its nearest
+ *    query idx (first on ties); query idx then keeps the train with the smallest such distance
+ *    (first i on ties); queries nobody points at produce no match.
+ *  Output ordered by queryIdx; distance is the integer Hamming distance as float. */
+int orc_bf_match(const uint8_t* d1, int n1, const uint8_t* d2, int n2, int crosscheck,
+                 tb_match* out, int cap) {
+    if (n1 < 0 || n2 < 0 || (n1 && !d1) || (n2 && !d2)) return TB_EINVAL;
+    if (n1 == 0 || n2 == 0) return 0;
+    std::vector<int> dist(n1, INT_MAX), nidx(n1, -1);
+    if (!crosscheck) {
+        for (int q = 0; q < n1; q++)
+            for (int t = 0; t < n2; t++) {
+                int d = orc_descriptor_distance(d1 + 32 * (size_t)q, d2 + 32 * (size_t)t);
+                if (d < dist[q]) { dist[q] = d; nidx[q] = t; }
+            }
+    } else {
+        for (int t = 0; t < n2; t++) {
+            int best = INT_MAX, bq = -1;
+            for (int q = 0; q < n1; q++) {
+                int d = orc_descriptor_distance(d2 + 32 * (size_t)t, d1 + 32 * (size_t)q);
+                if (d < best) { best = d; bq = q; }
+            }
+            if (best < dist[bq]) { dist[bq] = best; nidx[bq] = t; }
+        }
+    }
+    int n = 0;
+    for (int q = 0; q < n1; q++) {
+        if (nidx[q] < 0) continue;
+        if (out) {
+            if (n >= cap) return TB_ECAPACITY;
+            out[n].queryIdx = q;
+            out[n].trainIdx = nidx[q];
+            out[n].imgIdx = 0;
+            out[n].distance = (float)dist[q];
+        }
+        n++;
+    }
+    return n;
+}
+
+/* Matcher::searchByBF whole-set branch, matcher.cpp:178-182,205-218: cross-checked BF match, then
+ * keep m.distance < fmin(ratio * d_min, minTh). (An empty match list dereferences end() in the
+ * reference; here it returns 0 matches.) */
+int orc_search_by_bf(const uint8_t* d1, int n1, const uint8_t* d2, int n2, float ratio, float min_th,
+                     tb_match* out, int cap) {
+    std::vector<tb_match> m((size_t)std::max(n1, 1));
+    int n = orc_bf_match(d1, n1, d2, n2, 1, m.data(), (int)m.size());
+    if (n <= 0) return n;
+    float min_distance = m[0].distance;
+    for (int i = 1; i < n; i++)
+        if (m[i].distance < min_distance) min_distance = m[i].distance;
+    const float lim = std::fmin(ratio * min_distance, min_th);
+    int k = 0;
+    for (int i = 0; i < n; i++)
+        if (m[i].distance < lim) {
+            if (out) {
+                if (k >= cap) return TB_ECAPACITY;
+                out[k] = m[i];
+            }
+            k++;
+        }
+    return k;
+}
+
+/* Matcher::searchByViolence, matcher.cpp:299-395, over Frame::AssignFeaturesToGrid /
+ * GetFeaturesInArea / PosInGrid (Frame.cpp:187-265). The grid's inverse factors are swapped in the
+ * reference (Frame.cpp:30-31: "HeightInv" = 120/cols, "WidthInv" = 36/rows); reproduced as is. */
+int orc_search_by_violence(const tb_keypoint* k1, const uint8_t* d1, int n1,
+                           const tb_keypoint* k2, const uint8_t* d2, int n2,
+                           int img2_w, int img2_h, int min_level, int max_level, float r,
+                           int th_low, float nratio, int histo_len, int check_orientation,
+                           tb_match* out, int cap) {
+    const int GRID_ROWS = 36, GRID_COLS = 120;
+    if (n1 < 0 || n2 < 0 || histo_len < 1) return TB_EINVAL;
+    const float heightInv = (float)GRID_COLS / (float)img2_w;
+    const float widthInv = (float)GRID_ROWS / (float)img2_h;
+    std::vector<std::vector<int>> grid((size_t)GRID_COLS * GRID_ROWS);
+    for (int i = 0; i < n2; i++) {
+        int posX = (int)std::round(k2[i].x * widthInv);
+        int posY = (int)std::round(k2[i].y * heightInv);
+        if (posX < 0 || posX >= GRID_COLS || posY < 0 || posY >= GRID_ROWS) continue;
+        grid[(size_t)posX * GRID_ROWS + posY].push_back(i);
+    }
+    std::vector<tb_match> matches;
+    std::vector<std::vector<int>> rotHist(histo_len);
+    const float factor = 1.f / (float)histo_len;
+    std::vector<int> cand;
+    for (int i1 = 0; i1 < n1; i1++) {
+        const float x = k1[i1].x, y = k1[i1].y;
+        cand.clear();
+        do {
+            const int nMinCellX = std::max(0, (int)std::floor((x - r) * widthInv));
+            if (nMinCellX >= GRID_COLS) break;
+            const int nMaxCellX = std::min(GRID_COLS - 1, (int)std::ceil((x + r) * widthInv));
+            if (nMaxCellX < 0) break;
+            const int nMinCellY = std::max(0, (int)std::floor((y - r) * heightInv));
+            if (nMinCellY >= GRID_ROWS) break;
+            const int nMaxCellY = std::min(GRID_ROWS - 1, (int)std::ceil((y + r) * heightInv));
+            if (nMaxCellY < 0) break;
+            const bool bCheckLevels = (min_level > 0) || (max_level >= 0);
+            for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+                for (int iy = nMinCellY; iy <= nMaxCellY; iy++)
+                    for (int j : grid[(size_t)ix * GRID_ROWS + iy]) {
+                        if (bCheckLevels) {
+                            if (k2[j].octave < min_level) continue;
+                            if (max_level >= 0 && k2[j].octave > max_level) continue;
+                        }
+                        const float distx = k2[j].x - x, disty = k2[j].y - y;
+                        if (std::fabs(distx) < r && std::fabs(disty) < r) cand.push_back(j);
+                    }
+        } while (0);
+        if (cand.empty()) continue;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int i2 : cand) {
+            int dist = orc_descriptor_distance(d1 + 32 * (size_t)i1, d2 + 32 * (size_t)i2);
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= th_low && (float)bestDist < (float)bestDist2 * nratio) {
+            tb_match m{i1, bestIdx2, -1, (float)bestDist};
+            matches.push_back(m);
+            if (check_orientation) {
+                float rot = k1[i1].angle - k2[bestIdx2].angle;
+                if (rot < 0) rot += 360.f;
+                int bin = (int)std::roundf(rot * factor);
+                if (bin == histo_len) bin = 0;
+                if (bin < 0 || bin >= histo_len) return TB_EUNSUPPORTED; /* reference asserts */
+                rotHist[bin].push_back((int)matches.size() - 1);
+            }
+        }
+    }
+    std::vector<tb_match> good;
+    if (check_orientation) {
+        std::vector<int> sizes(histo_len);
+        for (int i = 0; i < histo_len; i++) sizes[i] = (int)rotHist[i].size();
+        int ind[3] = {-1, -1, -1};
+        orc_three_maxima(sizes.data(), histo_len, &ind[0], &ind[1], &ind[2]);
+        for (int i = 0; i < histo_len; i++)
+            if (i == ind[0] || i == ind[1] || i == ind[2])
+                for (int item : rotHist[i]) good.push_back(matches[item]);
+    } else {
+        good = matches;
+    }
+    if (out) {
+        if ((int)good.size() > cap) return TB_ECAPACITY;
+        std::copy(good.begin(), good.end(), out);
+    }
+    return (int)good.size();
+}
+
+}  // extern "C"

@@ -1,0 +1,87 @@
+"""CPU tests: the oracle re-run against the committed golden vectors (tests/golden/oracle_golden_v1.npz,
+made by tools/gen_golden.py from the reference's own data/left.png + data/right.png and seeded
+synthetic inputs). Guards the oracle against regressions; "parity unpinned" vs genuine OpenCV/g2o."""
+import hashlib
+
+import numpy as np
+
+import oracle
+from trackingbench_slam_amd import synth
+
+
+def _sha(a):
+    return np.frombuffer(hashlib.sha1(np.ascontiguousarray(a).tobytes()).digest(), np.uint8)
+
+
+def test_fixture_images_are_the_reference_pair(kitti_pair):
+    L, R = kitti_pair
+    assert L.shape == (376, 1241) and R.shape == (376, 1241)
+    # pixel SHA-1 prefixes recorded in SURVEY.md 8(c) for data/left.png, data/right.png
+    assert hashlib.sha1(L.tobytes()).hexdigest().startswith("19a64c795068")
+    assert hashlib.sha1(R.tobytes()).hexdigest().startswith("8fba371640c1")
+
+
+def test_pyramid_and_extract_c5(kitti_pair, golden):
+    L, R = kitti_pair
+    for img, side in ((L, "left"), (R, "right")):
+        lv, sf = oracle.pyramid(img, 5, 0.8)
+        assert np.array_equal(sf, golden["c5_sf"])
+        assert np.array_equal(np.stack([_sha(l) for l in lv]), golden[f"c5_pyr_sha_{side}"])
+        k, d, q = oracle.orb_extract(lv, sf, 1000, 80, 30)
+        assert np.array_equal(q, golden["c5_quotas"])
+        assert np.array_equal(k, golden[f"c5_kps_{side}"]) and np.array_equal(d, golden[f"c5_desc_{side}"])
+        if side == "left":
+            for i, l in enumerate(lv):
+                assert np.array_equal(oracle.orb_candidates(l, 80, 30), golden[f"c5_cand_left_L{i}"])
+            assert np.array_equal(np.stack([_sha(oracle.gaussian7(l)) for l in lv]), golden["c5_blur_sha_left"])
+            assert np.array_equal(oracle.fast9(lv[0], 20, True), golden["c5_fast9_th20_left_L0"])
+            isf = oracle.scale_factors(5, 0.8)[1]
+            assert np.array_equal(oracle.fastgrid_extract(lv, isf, 1000, 20.0), golden["c5_fastgrid_left"])
+            ka, da, _ = oracle.orb_extract(lv, sf, 1000, 80, 30, exit_keys=k, quotas=q)
+            assert np.array_equal(ka, golden["c5_addpoints_kps_left"])
+            assert np.array_equal(da, golden["c5_addpoints_desc_left"])
+            assert len(ka) < len(k)  # exit keys suppress nearby re-detections
+
+
+def test_extract_c8(kitti_pair, golden):
+    L, _ = kitti_pair
+    lv, sf = oracle.pyramid(L, 8, 0.8)
+    k, d, _ = oracle.orb_extract(lv, sf, 2000, 80, 30)
+    assert np.array_equal(k, golden["c8_kps_left"]) and np.array_equal(d, golden["c8_desc_left"])
+
+
+def test_matchers(golden):
+    for tag, nl in (("c5", 5), ("c8", 8)):
+        k1, d1 = golden[f"{tag}_kps_left"], golden[f"{tag}_desc_left"]
+        k2, d2 = golden[f"{tag}_kps_right"], golden[f"{tag}_desc_right"]
+        assert np.array_equal(oracle.bf_match(d1, d2, True), golden[f"{tag}_bf_all"])
+        assert np.array_equal(oracle.search_by_bf(d1, d2, 10, 30), golden[f"{tag}_bf_10_30"])
+        v = oracle.search_by_violence(k1, d1, k2, d2, 1241, 376, 0, nl, 50.0, th_low=30, nratio=5.0,
+                                      histo_len=30, check_orientation=True)
+        assert np.array_equal(v, golden[f"{tag}_violence"])
+        assert len(v) > 20
+
+
+def test_pose_opt_kat(golden):
+    K = (718.856, 718.856, 607.1928, 185.2157)
+    n, T, outl, stats = oracle.pose_opt(K, golden["pose_Tinit"], golden["pose_obs"])
+    assert n == int(golden["pose_n"]) and np.array_equal(outl, golden["pose_outlier"])
+    assert np.allclose(T, golden["pose_T"], rtol=1e-6, atol=1e-7)
+    assert np.allclose(stats[1], golden["pose_stats"][1], rtol=1e-6)
+    assert np.abs(T - golden["pose_Ttrue"]).max() < 5e-3
+
+
+def test_local_ba_kat(golden):
+    K = (718.856, 718.856, 607.1928, 185.2157)
+    it, P, X, st = oracle.local_ba(K, golden["ba_poses_init"], 2, golden["ba_pts_init"], golden["ba_obs"], 10)
+    assert np.allclose(P, golden["ba_poses"], rtol=1e-6, atol=1e-7)
+    assert np.allclose(X, golden["ba_pts"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(st[2], golden["ba_stats"][2], rtol=1e-6)
+
+
+def test_synthetic_generator_is_pinned(golden):
+    S = synth.frame(5, 640, 480)
+    assert np.array_equal(_sha(S), golden["synth5_640x480_sha"])
+    lv, sf = oracle.pyramid(S, 8, 0.8)
+    k, d, _ = oracle.orb_extract(lv, sf, 1000, 80, 30)
+    assert np.array_equal(k, golden["synth5_kps"]) and np.array_equal(d, golden["synth5_desc"])

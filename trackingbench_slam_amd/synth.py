@@ -1,0 +1,186 @@
+"""Deterministic synthetic inputs for the tracking hot path.
+
+Frames: u8 grey images with FAST corners at a controllable density -- low-frequency value
+noise + ~W*H/400 random axis-aligned and rotated rectangles (contrast uniform in [40,160]) +
++-3 uniform pixel noise; stereo right image = same rectangles shifted left by a per-rectangle
+disparity in [4,64] px.  Every random draw comes from a splitmix64 stream seeded with
+0xC0FFEE + frame index, so the generator needs no files and is identical on every box.
+
+Pose-optimisation / local-BA inputs follow the recipe of the reference's only self-contained
+test, test_PoseOptimization (test/test_vo.cpp:305-355): random 3-D points projected through a
+known pose, with our own fixed seed.
+"""
+import numpy as np
+
+_MASK = (1 << 64) - 1
+_GAMMA = 0x9E3779B97F4A7C15
+
+
+def splitmix64(seed, n):
+    """n successive splitmix64 outputs for `seed` as uint64."""
+    idx = np.arange(1, n + 1, dtype=np.uint64)
+    with np.errstate(over="ignore"):
+        z = np.uint64(seed & _MASK) + idx * np.uint64(_GAMMA)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return z
+
+
+class Stream:
+    """Sequential reader over a splitmix64 stream."""
+
+    def __init__(self, seed):
+        self.seed = seed & _MASK
+        self.pos = 0
+
+    def u64(self, n):
+        idx = np.arange(self.pos + 1, self.pos + n + 1, dtype=np.uint64)
+        self.pos += n
+        with np.errstate(over="ignore"):
+            z = np.uint64(self.seed) + idx * np.uint64(_GAMMA)
+            z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+            z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+            z = z ^ (z >> np.uint64(31))
+        return z
+
+    def uniform(self, n, lo=0.0, hi=1.0):
+        u = (self.u64(n) >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+        return lo + (hi - lo) * u
+
+    def randint(self, n, lo, hi):
+        """integers in [lo, hi)"""
+        return (lo + (self.u64(n) % np.uint64(hi - lo)).astype(np.int64)).astype(np.int64)
+
+
+def _value_noise(st, w, h, cell=96):
+    gw, gh = w // cell + 2, h // cell + 2
+    g = st.uniform(gw * gh, 60.0, 190.0).reshape(gh, gw)
+    ys = np.arange(h) / cell
+    xs = np.arange(w) / cell
+    y0 = ys.astype(int); x0 = xs.astype(int)
+    fy = (ys - y0)[:, None]; fx = (xs - x0)[None, :]
+    a = g[y0][:, x0]; b = g[y0][:, x0 + 1]; c = g[y0 + 1][:, x0]; d = g[y0 + 1][:, x0 + 1]
+    return a * (1 - fy) * (1 - fx) + b * (1 - fy) * fx + c * fy * (1 - fx) + d * fy * fx
+
+
+def _draw(img, cx, cy, hw, hh, ang, delta):
+    h, w = img.shape
+    if ang == 0.0:
+        x0, x1 = int(max(cx - hw, 0)), int(min(cx + hw, w))
+        y0, y1 = int(max(cy - hh, 0)), int(min(cy + hh, h))
+        if x1 > x0 and y1 > y0:
+            img[y0:y1, x0:x1] += delta
+        return
+    r = int(np.ceil(np.hypot(hw, hh))) + 1
+    x0, x1 = int(max(cx - r, 0)), int(min(cx + r, w))
+    y0, y1 = int(max(cy - r, 0)), int(min(cy + r, h))
+    if x1 <= x0 or y1 <= y0:
+        return
+    yy, xx = np.mgrid[y0:y1, x0:x1]
+    ca, sa = np.cos(ang), np.sin(ang)
+    u = (xx - cx) * ca + (yy - cy) * sa
+    v = -(xx - cx) * sa + (yy - cy) * ca
+    m = (np.abs(u) <= hw) & (np.abs(v) <= hh)
+    img[y0:y1, x0:x1][m] += delta
+
+
+def frame(index, width, height, stereo=False, density=400):
+    """Synthetic frame `index` -> u8 image (or (left, right) when stereo)."""
+    st = Stream(0xC0FFEE + int(index))
+    base = _value_noise(st, width, height)
+    n = max(width * height // density, 1)
+    cx = st.uniform(n, 0, width); cy = st.uniform(n, 0, height)
+    hw = st.uniform(n, 3, 22); hh = st.uniform(n, 3, 22)
+    rot = st.uniform(n) < 0.5
+    ang = np.where(rot, st.uniform(n, 0.15, np.pi / 2 - 0.15), 0.0)
+    delta = st.uniform(n, 40, 160) * np.where(st.uniform(n) < 0.5, -1.0, 1.0)
+    disp = st.uniform(n, 4, 64)
+    left = base.copy()
+    for i in range(n):
+        _draw(left, cx[i], cy[i], hw[i], hh[i], float(ang[i]), delta[i])
+    noise_l = st.randint(width * height, -3, 4).reshape(height, width)
+    out_l = np.clip(np.rint(left) + noise_l, 0, 255).astype(np.uint8)
+    if not stereo:
+        return out_l
+    right = base.copy()
+    for i in range(n):
+        _draw(right, cx[i] - np.rint(disp[i]), cy[i], hw[i], hh[i], float(ang[i]), delta[i])
+    noise_r = st.randint(width * height, -3, 4).reshape(height, width)
+    out_r = np.clip(np.rint(right) + noise_r, 0, 255).astype(np.uint8)
+    return out_l, out_r
+
+
+def pose_problem(seed, n, K, noise_px=0.5, outlier_frac=0.1, nlevels=8, scale=0.8):
+    """test_PoseOptimization-style inputs (test/test_vo.cpp:305-355) with a fixed seed.
+
+    Returns (Tcw_true, Tcw_init, obs) where obs is a structured array
+    (u, v, X, Y, Z, inv_sigma2) and Tcw_* are 4x4 float32.
+    """
+    st = Stream(0xBADC0DE + int(seed))
+    fx, fy, cx, cy = K
+    X = np.stack([st.uniform(n, -4, 4), st.uniform(n, -2, 2), st.uniform(n, 4, 20)], 1)
+    ang = st.uniform(3, -0.08, 0.08)
+    t = st.uniform(3, -0.3, 0.3)
+    Rx = np.array([[1, 0, 0], [0, np.cos(ang[0]), -np.sin(ang[0])], [0, np.sin(ang[0]), np.cos(ang[0])]])
+    Ry = np.array([[np.cos(ang[1]), 0, np.sin(ang[1])], [0, 1, 0], [-np.sin(ang[1]), 0, np.cos(ang[1])]])
+    Rz = np.array([[np.cos(ang[2]), -np.sin(ang[2]), 0], [np.sin(ang[2]), np.cos(ang[2]), 0], [0, 0, 1]])
+    R = Rz @ Ry @ Rx
+    T = np.eye(4); T[:3, :3] = R; T[:3, 3] = t
+    Xf = X.astype(np.float32)
+    pc = Xf.astype(np.float64) @ R.T + t
+    u = pc[:, 0] / pc[:, 2] * fx + cx + st.uniform(n, -noise_px, noise_px)
+    v = pc[:, 1] / pc[:, 2] * fy + cy + st.uniform(n, -noise_px, noise_px)
+    bad = st.uniform(n) < outlier_frac
+    u = np.where(bad, u + st.uniform(n, -60, 60), u)
+    v = np.where(bad, v + st.uniform(n, -60, 60), v)
+    octave = st.randint(n, 0, nlevels)
+    sf = np.float32(1.0)
+    sfs = [sf]
+    for _ in range(1, nlevels):
+        sf = np.float32(sf * np.float32(scale)); sfs.append(sf)
+    sfs = np.array(sfs, np.float32)
+    inv_sigma2 = (np.float32(1.0) / (sfs * sfs)).astype(np.float32)[octave]
+    obs = np.zeros(n, dtype=[("u", "<f4"), ("v", "<f4"), ("X", "<f4"), ("Y", "<f4"), ("Z", "<f4"),
+                             ("inv_sigma2", "<f4")])
+    obs["u"], obs["v"] = u, v
+    obs["X"], obs["Y"], obs["Z"] = Xf[:, 0], Xf[:, 1], Xf[:, 2]
+    obs["inv_sigma2"] = inv_sigma2
+    return T.astype(np.float32), np.eye(4, dtype=np.float32), obs
+
+
+def ba_problem(seed, nkf, npt, K, obs_per_pt=5, noise_px=0.5, pose_noise=0.02, pt_noise=0.05):
+    """Local-BA window (extension; no reference counterpart): nkf keyframes on a short arc,
+    npt points, each seen by up to obs_per_pt keyframes. Returns (poses_true, poses_init, pts_true,
+    pts_init, obs) with obs a structured array (kf, pt, u, v, inv_sigma2)."""
+    st = Stream(0xBA0000 + int(seed))
+    fx, fy, cx, cy = K
+    X = np.stack([st.uniform(npt, -6, 6), st.uniform(npt, -2.5, 2.5), st.uniform(npt, 5, 25)], 1)
+    poses = np.zeros((nkf, 4, 4)); poses[:] = np.eye(4)
+    for k in range(nkf):
+        a = 0.01 * k
+        poses[k, :3, :3] = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+        poses[k, :3, 3] = [-0.25 * k, 0.0, -0.05 * k]
+    kfs = st.randint(npt * obs_per_pt, 0, nkf).reshape(npt, obs_per_pt)
+    rows = []
+    noise = st.uniform(npt * obs_per_pt * 2, -noise_px, noise_px).reshape(npt, obs_per_pt, 2)
+    for p in range(npt):
+        for k in sorted(set(kfs[p].tolist())):
+            pc = poses[k, :3, :3] @ X[p] + poses[k, :3, 3]
+            if pc[2] < 0.5:
+                continue
+            j = int(np.where(kfs[p] == k)[0][0])
+            rows.append((k, p, pc[0] / pc[2] * fx + cx + noise[p, j, 0], pc[1] / pc[2] * fy + cy + noise[p, j, 1], 1.0))
+    obs = np.array(rows, dtype=[("kf", "<i4"), ("pt", "<i4"), ("u", "<f4"), ("v", "<f4"), ("inv_sigma2", "<f4")])
+    order = np.lexsort((obs["kf"], obs["pt"]))
+    obs = obs[order]
+    poses_init = poses.copy()
+    dn = st.uniform(nkf * 6, -1, 1).reshape(nkf, 6)
+    for k in range(2, nkf):
+        poses_init[k, :3, 3] += pose_noise * dn[k, :3]
+        a = pose_noise * 0.2 * dn[k, 3]
+        Rz = np.array([[np.cos(a), -np.sin(a), 0], [np.sin(a), np.cos(a), 0], [0, 0, 1]])
+        poses_init[k, :3, :3] = Rz @ poses_init[k, :3, :3]
+    pts_init = X + pt_noise * st.uniform(npt * 3, -1, 1).reshape(npt, 3)
+    return (poses.astype(np.float32), poses_init.astype(np.float32), X.astype(np.float32),
+            pts_init.astype(np.float32), obs)
