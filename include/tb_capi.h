@@ -1,0 +1,139 @@
+/* C ABI of the MI355X tracking hot path (libtb_hip.so).
+ *
+ * This is the drop-in boundary: plain pointers and sizes, no C++ or torch types.  The reference has no
+ * FFI of its own (it is one C++ static library, CMakeLists.txt:30-45); the functions below are what a
+ * binding for its hot-path operators would bind, one per operator, each citing the reference interface
+ * it replaces.  include/extractors, include/matchers, include/mapping hold the C++ header shims that
+ * keep the reference's class signatures on top of this ABI.
+ *
+ * Conventions: return 0 (TB_OK) or a negative TB_E* code (tb_types.h); tb_last_error(ctx) gives the text.
+ * Outputs are caller-allocated with stated capacities.  A tb_ctx owns one GPU and one HIP stream and is
+ * not thread-safe; contexts on different GPUs are independent.  "host" pointers are ordinary memory,
+ * "dev" pointers are HIP device memory of the context's GPU.  There is NO CPU fallback: every compute
+ * entry point fails with TB_EDEVICE when no gfx950 device is usable.
+ */
+#ifndef TB_CAPI_H
+#define TB_CAPI_H
+
+#include "tb_types.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct tb_ctx tb_ctx;
+typedef struct tb_extractor tb_extractor;
+
+/* ---------------------------------------------------------------- context */
+int tb_create(int device, tb_ctx** out);
+void tb_destroy(tb_ctx* ctx);
+const char* tb_last_error(const tb_ctx* ctx);
+const char* tb_strerror(int code);
+const char* tb_version(void);
+/* Run everything on an existing HIP stream (e.g. torch's current stream); NULL = the context's own. */
+int tb_set_stream(tb_ctx* ctx, void* hip_stream);
+int tb_synchronize(tb_ctx* ctx);
+
+/* ---------------------------------------------------------------- a1/a2/a3: host-side scalar set-up
+ * Frame::Frame scale vectors (src/types/Frame.cpp:18-29), Frame::ComputePyramid sizes (:423-424),
+ * ORBExtractor::operator() per-level quota (src/extractors/ORBextractor.cpp:919-930). Pure host math. */
+int tb_scale_factors(int nlevels, float scale, float* sf, float* inv_sf, float* sigma2, float* inv_sigma2);
+int tb_pyramid_sizes(int width, int height, int nlevels, const float* sf, int* widths, int* heights);
+int tb_orb_quotas(int nlevels, const float* sf, int target, int* quotas);
+
+/* ---------------------------------------------------------------- batched extractor (device resident)
+ * One plan = one image geometry (width x height, nlevels, scale vector) and up to max_images frames in
+ * flight.  Replaces Frame::ComputePyramid (Frame.cpp:414-427) + ORBExtractor::operator()/AddPoints
+ * (ORBextractor.cpp:906-978, :840-904) + FASTExtractor::operator() (FASTextractor.cpp:8-80) for a
+ * whole batch of frames per call. max_target bounds `target` of later calls. */
+int tb_extractor_create(tb_ctx* ctx, int width, int height, int nlevels, const float* sf,
+                        const int* widths, const int* heights, /* per-level sizes; NULL = Frame.cpp:423-424 */
+                        int max_images, int max_target, tb_extractor** out);
+void tb_extractor_destroy(tb_extractor* ex);
+/* Level-0 images: n frames, row stride `stride` bytes, frame pitch `pitch` bytes. The host form copies
+ * (PCIe); the dev form only records the pointer (frames are read in place, they must stay valid). */
+int tb_extractor_set_images_host(tb_extractor* ex, const uint8_t* images, int n, int stride, size_t pitch);
+int tb_extractor_set_images_dev(tb_extractor* ex, const uint8_t* dev_images, int n, int stride, size_t pitch);
+/* Caller-built pyramid for frame `index` (the reference's extractors take std::vector<cv::Mat>&). */
+int tb_extractor_set_levels_host(tb_extractor* ex, int index, const uint8_t* const* levels, const int* strides);
+/* a2: levels 1..n-1 of every frame by the cv::resize INTER_LINEAR chain. */
+int tb_extractor_build_pyramid(tb_extractor* ex, int n);
+int tb_extractor_get_level_host(tb_extractor* ex, int index, int level, uint8_t* out, int out_stride);
+/* a3-a10: ORB extraction of frames [0,n). quota_mode 0 = operator() (quotas from target), 1 = AddPoints
+ * (reuse the quotas of the last quota_mode-0 call; TB_ESTATE if none). exit keys (host, may be NULL)
+ * apply to every frame of the call. Results stay on the device. */
+int tb_extractor_orb(tb_extractor* ex, int n, int target, float init_th, float min_th, int quota_mode,
+                     const tb_keypoint* exit_keys, int n_exit);
+/* a11: FASTExtractor grid extraction (no descriptors). occupancy: host bytes, may be NULL. */
+int tb_extractor_fastgrid(tb_extractor* ex, int n, const float* inv_sf, int target, float threshold,
+                          const uint8_t* occupancy, int n_occupancy);
+/* Results of the last extraction call. counts: n ints (keypoints per frame). */
+int tb_extractor_counts_host(tb_extractor* ex, int n, int* counts);
+int tb_extractor_results_host(tb_extractor* ex, int index, tb_keypoint* kps, uint8_t* desc, int cap, int* count);
+/* Device views (valid until the next extraction call): keypoints [max_images][kp_capacity],
+ * descriptors [max_images][kp_capacity][32], counts [max_images]. */
+int tb_extractor_results_dev(tb_extractor* ex, const tb_keypoint** kps, const uint8_t** desc,
+                             const int32_t** counts, int* kp_capacity);
+/* Stage probes for parity tests: FAST candidates of one level after the cell loop (a4). */
+int tb_extractor_candidates_host(tb_extractor* ex, int index, int level, tb_corner* out, int cap, int* count);
+
+/* ---------------------------------------------------------------- single-frame operator forms (host buffers)
+ * What the header shims call; each wraps a cached plan. */
+/* Frame::ComputePyramid: levels[i] (i>=1) receive widths[i] x heights[i] bytes at strides[i]. */
+int tb_pyramid(tb_ctx* ctx, const uint8_t* image, int width, int height, int stride, int nlevels,
+               const float* sf, uint8_t* const* levels_out, const int* strides_out);
+/* cv::FAST(img, kps, th, nms) TYPE_9_16 on a whole image (the primitive inside a4; raster order). */
+int tb_fast_detect(tb_ctx* ctx, const uint8_t* image, int width, int height, int stride, int threshold,
+                   int nms, tb_corner* out, int cap, int* count);
+/* ORBExtractor::operator() (use_quotas 0) / AddPoints (use_quotas 1), ORBextractor.cpp:906-978,:840-904 */
+int tb_orb_extract(tb_ctx* ctx, const uint8_t* const* levels, const int* widths, const int* heights,
+                   const int* strides, int nlevels, const float* sf, int target, float init_th, float min_th,
+                   const tb_keypoint* exit_keys, int n_exit, int use_quotas, int* quotas_inout,
+                   tb_keypoint* kps, uint8_t* desc, int cap, int* count);
+/* FASTExtractor::operator(), FASTextractor.cpp:8-80 */
+int tb_fastgrid_extract(tb_ctx* ctx, const uint8_t* const* levels, const int* widths, const int* heights,
+                        const int* strides, int nlevels, const float* inv_sf, int target, float threshold,
+                        const uint8_t* occupancy, int n_occupancy, tb_keypoint* kps, int cap, int* count);
+
+/* ---------------------------------------------------------------- matchers
+ * Matcher::DescriptorDistance / ComputeThreeMaxima (matcher.cpp:793-851): host helpers. */
+int tb_descriptor_distance(const uint8_t* a, const uint8_t* b);
+void tb_three_maxima(const int* bin_sizes, int nbins, int* ind1, int* ind2, int* ind3);
+/* cv::BFMatcher(NORM_HAMMING, crossCheck).match (the call inside searchByBF, matcher.cpp:207) */
+int tb_match_bf(tb_ctx* ctx, const uint8_t* d1, int n1, const uint8_t* d2, int n2, int crosscheck,
+                tb_match* out, int cap, int* count);
+/* Matcher::searchByBF whole-set branch, matcher.cpp:168-228 */
+int tb_search_by_bf(tb_ctx* ctx, const uint8_t* d1, int n1, const uint8_t* d2, int n2, float ratio,
+                    float min_th, tb_match* out, int cap, int* count);
+/* Batched device form: npairs descriptor-set pairs, set p of side s at desc_s + p*set_pitch bytes with
+ * counts_s[p] rows; matches to out + p*cap, counts to out_counts[p]. All pointers are device memory. */
+int tb_search_by_bf_batch_dev(tb_ctx* ctx, int npairs, const uint8_t* desc1, const int32_t* counts1,
+                              const uint8_t* desc2, const int32_t* counts2, size_t set_pitch,
+                              float ratio, float min_th, tb_match* out, int cap, int32_t* out_counts);
+/* Matcher::searchByViolence, matcher.cpp:299-395 (+ Frame grid, Frame.cpp:187-265). */
+int tb_search_by_violence(tb_ctx* ctx, const tb_keypoint* k1, const uint8_t* d1, int n1,
+                          const tb_keypoint* k2, const uint8_t* d2, int n2, int img2_width, int img2_height,
+                          int min_level, int max_level, float radius, int th_low, float nratio,
+                          int histo_len, int check_orientation, tb_match* out, int cap, int* count);
+
+/* ---------------------------------------------------------------- pose optimisation / local BA
+ * LocalBA::PoseOptimization, LocalBA.cpp:291-490. K = fx,fy,cx,cy. Tcw_in/out: row-major 4x4.
+ * outlier: n in/out flags (Frame::GetOutlier/SetOutlier). *n_inliers = nInitialCorrespondences - nBad.
+ * stats (nullable, 8 doubles): LM iterations, final robust chi2, final lambda, nBad, t[3], q.w. */
+int tb_pose_opt(tb_ctx* ctx, const double K[4], const float Tcw_in[16], const tb_obs* obs, int n,
+                uint8_t* outlier, float Tcw_out[16], int* n_inliers, double* stats);
+/* Batched device form: problem p reads obs + p*obs_pitch (counts[p] rows), Tcw_in + 16p, outlier +
+ * p*obs_pitch; writes Tcw_out + 16p, n_inliers[p], stats + 8p (nullable). Device pointers. */
+int tb_pose_opt_batch_dev(tb_ctx* ctx, int nproblems, const double K[4], const float* Tcw_in,
+                          const tb_obs* obs, const int32_t* counts, int obs_pitch, uint8_t* outlier,
+                          float* Tcw_out, int32_t* n_inliers, double* stats);
+/* Multi-keyframe local BA -- north-star extension, NO reference counterpart.
+ * poses: nkf x 16 (in/out, first nfixed held), pts: npt x 3 (in/out). stats (nullable, 8 doubles):
+ * iterations, initial chi2, final chi2, final lambda. */
+int tb_local_ba(tb_ctx* ctx, const double K[4], int nkf, int nfixed, float* poses, int npt, float* pts,
+                const tb_ba_obs* obs, int nobs, int iters, double* stats);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TB_CAPI_H */

@@ -1,0 +1,152 @@
+"""GPU parity tests (pytest -m gpu): pyramid / FAST / quadtree / ORB / FAST-grid extraction through the
+C ABI against the CPU oracle and the committed golden vectors.  Bit-exact bar (integer / byte / index
+work; keypoint floats are exact products of small integers and float32 scale factors)."""
+import numpy as np
+import pytest
+
+import oracle
+from trackingbench_slam_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _eq_struct(a, b):
+    assert a.dtype == b.dtype and a.shape == b.shape, (a.shape, b.shape)
+    for f in a.dtype.names:
+        assert np.array_equal(a[f], b[f]), f
+
+
+@pytest.mark.parametrize("shape,nl,scale", [((376, 1241), 5, 0.8), ((480, 640), 8, 0.8), ((300, 400), 4, 0.5),
+                                             ((241, 333), 5, 0.6)])
+def test_pyramid_bit_exact(ctx, kitti_pair, shape, nl, scale):
+    img = kitti_pair[0] if shape == (376, 1241) else synth.frame(21, shape[1], shape[0])
+    got, sf = ctx.pyramid(img, nl, scale)
+    exp, sfo = oracle.pyramid(img, nl, scale)
+    assert np.array_equal(sf, sfo)
+    for l, (g, e) in enumerate(zip(got, exp)):
+        assert g.shape == e.shape
+        assert np.array_equal(g, e), "level %d" % l
+
+
+@pytest.mark.parametrize("th,nms", [(20, True), (7, True), (80, True), (30, False), (0, True)])
+def test_fast_detect_bit_exact(ctx, kitti_pair, th, nms):
+    for img in (kitti_pair[0][:200, :300].copy(), synth.frame(22, 320, 240), synth.frame(23, 61, 64)):
+        _eq_struct(ctx.fast_detect(img, th, nms), oracle.fast9(img, th, nms))
+
+
+def test_fast_detect_degenerate(ctx):
+    for shape in ((6, 50), (50, 6), (7, 7), (8, 9)):
+        img = np.zeros(shape, np.uint8)
+        img[shape[0] // 2, shape[1] // 2] = 255
+        _eq_struct(ctx.fast_detect(img, 10), oracle.fast9(img, 10))
+    flat = np.full((100, 100), 77, np.uint8)
+    assert len(ctx.fast_detect(flat, 1)) == 0
+
+
+def test_cell_candidates_bit_exact(ctx, kitti_pair, golden):
+    L = kitti_pair[0]
+    ex = capi.Extractor(ctx, 1241, 376, 5, 0.8, 1, 1000)
+    ex.set_images_host(L)
+    ex.build_pyramid(1)
+    ex.orb(1, 1000, 80, 30)
+    for l in range(5):
+        _eq_struct(ex.candidates(0, l), golden["c5_cand_left_L%d" % l])
+    ex.close()
+
+
+def test_orb_extract_kitti_golden(ctx, kitti_pair, golden):
+    for img, side in zip(kitti_pair, ("left", "right")):
+        for tag, nl, N in (("c5", 5, 1000), ("c8", 8, 2000)):
+            lv, sf = ctx.pyramid(img, nl, 0.8)
+            k, d, q = ctx.orb_extract(lv, sf, N, 80, 30)
+            assert np.array_equal(q, golden[f"{tag}_quotas"])
+            _eq_struct(k, golden[f"{tag}_kps_{side}"])
+            assert np.array_equal(d, golden[f"{tag}_desc_{side}"])
+
+
+def test_orb_addpoints_golden(ctx, kitti_pair, golden):
+    lv, sf = ctx.pyramid(kitti_pair[0], 5, 0.8)
+    k, d, q = ctx.orb_extract(lv, sf, 1000, 80, 30)
+    ka, da, _ = ctx.orb_extract(lv, sf, 1000, 80, 30, exit_keys=k, quotas=q)
+    _eq_struct(ka, golden["c5_addpoints_kps_left"])
+    assert np.array_equal(da, golden["c5_addpoints_desc_left"])
+
+
+@pytest.mark.parametrize("seed,w,h,nl,N,ith,mth", [(31, 640, 480, 8, 1000, 80, 30), (32, 640, 480, 8, 1000, 20, 7),
+                                                    (33, 320, 200, 4, 300, 40, 10), (34, 1280, 720, 8, 2000, 80, 30),
+                                                    (35, 200, 320, 3, 150, 30, 10), (36, 97, 131, 2, 40, 20, 5)])
+def test_orb_extract_synthetic_vs_oracle(ctx, seed, w, h, nl, N, ith, mth):
+    img = synth.frame(seed, w, h)
+    lv, sf = oracle.pyramid(img, nl, 0.8)
+    ko, do, qo = oracle.orb_extract(lv, sf, N, ith, mth)
+    k, d, q = ctx.orb_extract(lv, sf, N, ith, mth)
+    assert np.array_equal(q, qo)
+    _eq_struct(k, ko)
+    assert np.array_equal(d, do)
+    assert len(k) > 0
+
+
+def test_orb_extract_batched_plan(ctx):
+    imgs = np.stack([synth.frame(40 + i, 640, 480) for i in range(3)])
+    ex = capi.Extractor(ctx, 640, 480, 8, 0.8, 4, 1000)
+    n = ex.set_images_host(imgs)
+    ex.build_pyramid(n)
+    ex.orb(n, 1000, 80, 30)
+    cnt = ex.counts(n)
+    for b in range(n):
+        lv, sf = oracle.pyramid(imgs[b], 8, 0.8)
+        for l in range(8):
+            assert np.array_equal(ex.get_level(b, l), lv[l])
+        ko, do, _ = oracle.orb_extract(lv, sf, 1000, 80, 30)
+        k, d = ex.results(b)
+        assert cnt[b] == len(ko)
+        _eq_struct(k, ko)
+        assert np.array_equal(d, do)
+    ex.close()
+
+
+def test_orb_extract_edge_cases(ctx):
+    sf = oracle.scale_factors(3, 0.8)[0]
+    flat = [np.full((120, 160), 90, np.uint8), np.full((96, 128), 90, np.uint8), np.full((76, 102), 90, np.uint8)]
+    k, d, q = ctx.orb_extract(flat, sf, 500, 80, 30)
+    assert len(k) == 0
+    tiny = [np.zeros((40, 40), np.uint8)] * 3  # no 30-px cell fits
+    k, d, q = ctx.orb_extract(tiny, sf, 500, 80, 30)
+    assert len(k) == 0
+    with pytest.raises(capi.TBError) as e:  # AddPoints before operator(): TB_ESTATE
+        ex = capi.Extractor(ctx, 160, 120, 3, 0.8, 1, 100)
+        ex.set_images_host(flat[0])
+        ex.orb(1, 100, 80, 30, quota_mode=1)
+    assert e.value.code == capi.TB_ESTATE
+    # quota far above the candidate count: every candidate survives alone in a leaf
+    img = synth.frame(37, 160, 120)
+    lv, sf2 = oracle.pyramid(img, 2, 0.8)
+    ko, do, _ = oracle.orb_extract(lv, sf2, 2000, 40, 10)
+    k, d, _ = ctx.orb_extract(lv, sf2, 2000, 40, 10)
+    _eq_struct(k, ko)
+    assert np.array_equal(d, do)
+    # tiny quota: fewer leaves than initial nodes allow
+    ko, do, _ = oracle.orb_extract(lv, sf2, 3, 40, 10)
+    k, d, _ = ctx.orb_extract(lv, sf2, 3, 40, 10)
+    _eq_struct(k, ko)
+    assert np.array_equal(d, do)
+
+
+def test_fastgrid_extract(ctx, kitti_pair, golden):
+    lv, sf = oracle.pyramid(kitti_pair[0], 5, 0.8)
+    isf = oracle.scale_factors(5, 0.8)[1]
+    got = ctx.fastgrid_extract(lv, isf, 1000, 20.0)
+    _eq_struct(got, golden["c5_fastgrid_left"])
+    img = synth.frame(38, 640, 480)
+    lv, _ = oracle.pyramid(img, 3, 0.8)
+    isf = oracle.scale_factors(3, 0.8)[1]
+    occ = np.zeros(2000, np.uint8); occ[::3] = 1
+    for target, th, o in ((1000, 20.0, None), (200, 5.0, None), (500, 10.0, occ)):
+        _eq_struct(ctx.fastgrid_extract(lv, isf, target, th, o), oracle.fastgrid_extract(lv, isf, target, th, o))

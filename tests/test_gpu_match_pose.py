@@ -1,0 +1,99 @@
+"""GPU parity tests (pytest -m gpu): Hamming matchers (bit-exact) and pose optimisation (1e-6 relative,
+the tolerance BASELINE.json's north_star states for BA pose / reprojection error)."""
+import numpy as np
+import pytest
+
+import oracle
+from trackingbench_slam_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+
+K = (718.856, 718.856, 607.1928, 185.2157)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _eq_struct(a, b):
+    assert a.dtype == b.dtype and a.shape == b.shape, (a.shape, b.shape)
+    for f in a.dtype.names:
+        assert np.array_equal(a[f], b[f]), f
+
+
+def test_bf_golden(ctx, golden):
+    for tag in ("c5", "c8"):
+        d1, d2 = golden[f"{tag}_desc_left"], golden[f"{tag}_desc_right"]
+        _eq_struct(ctx.bf_match(d1, d2, True), golden[f"{tag}_bf_all"])
+        _eq_struct(ctx.search_by_bf(d1, d2, 10, 30), golden[f"{tag}_bf_10_30"])
+        _eq_struct(ctx.bf_match(d1, d2, False), oracle.bf_match(d1, d2, False))
+
+
+def test_bf_ties_empty_ragged(ctx):
+    rng = np.random.default_rng(5)
+    d1 = rng.integers(0, 256, (700, 32), dtype=np.uint8)
+    d2 = rng.integers(0, 256, (1300, 32), dtype=np.uint8)
+    d2[:300] = d1[100:400]      # exact duplicates: zero distances and index ties
+    d2[600:650] = d1[5]         # many trains pointing at one query
+    d2[5] ^= 1
+    for a, b in ((d1, d2), (d2, d1), (d1[:1], d2), (d1, d2[:1]), (d1[:257], d2[:513])):
+        _eq_struct(ctx.bf_match(a, b, True), oracle.bf_match(a, b, True))
+        _eq_struct(ctx.bf_match(a, b, False), oracle.bf_match(a, b, False))
+        _eq_struct(ctx.search_by_bf(a, b, 10, 30), oracle.search_by_bf(a, b, 10, 30))
+        _eq_struct(ctx.search_by_bf(a, b, 1.5, 300), oracle.search_by_bf(a, b, 1.5, 300))
+    assert len(ctx.bf_match(d1[:0], d2)) == 0 and len(ctx.bf_match(d1, d2[:0])) == 0
+
+
+def test_violence_golden_and_params(ctx, golden):
+    for tag, nl in (("c5", 5), ("c8", 8)):
+        k1, d1 = golden[f"{tag}_kps_left"], golden[f"{tag}_desc_left"]
+        k2, d2 = golden[f"{tag}_kps_right"], golden[f"{tag}_desc_right"]
+        _eq_struct(ctx.search_by_violence(k1, d1, k2, d2, 1241, 376, 0, nl, 50.0, th_low=30, nratio=5.0, histo_len=30,
+                                          check_orientation=True), golden[f"{tag}_violence"])
+        for kw in (dict(min_level=0, max_level=1, radius=10.0, th_low=50, nratio=0.9, histo_len=30, check_orientation=False),
+                   dict(min_level=1, max_level=3, radius=80.0, th_low=60, nratio=0.8, histo_len=30, check_orientation=True),
+                   dict(min_level=0, max_level=-1, radius=25.0, th_low=100, nratio=1.0, histo_len=12, check_orientation=True)):
+            _eq_struct(ctx.search_by_violence(k1, d1, k2, d2, 1241, 376, **kw),
+                       oracle.search_by_violence(k1, d1, k2, d2, 1241, 376, **kw))
+    assert len(ctx.search_by_violence(k1[:0], d1[:0], k2, d2, 1241, 376)) == 0
+    assert len(ctx.search_by_violence(k1, d1, k2[:0], d2[:0], 1241, 376)) == 0
+
+
+def _pose_close(a, b):
+    assert np.allclose(a, b, rtol=1e-6, atol=1e-6 * max(1.0, float(np.abs(b).max())))
+
+
+def test_pose_opt_kat(ctx, golden):
+    n, T, outl, st = ctx.pose_opt(K, golden["pose_Tinit"], golden["pose_obs"])
+    assert n == int(golden["pose_n"])
+    assert np.array_equal(outl, golden["pose_outlier"])
+    _pose_close(T, golden["pose_T"])
+    assert np.isclose(st[1], golden["pose_stats"][1], rtol=1e-6)  # final robust chi2 (reprojection error)
+    assert st[0] == golden["pose_stats"][0]
+
+
+@pytest.mark.parametrize("seed,n,frac", [(1, 300, 0.15), (2, 2000, 0.05), (3, 50, 0.3), (4, 9, 0.0), (5, 3, 0.0), (6, 700, 0.5)])
+def test_pose_opt_vs_oracle(ctx, seed, n, frac):
+    Tt, Ti, obs = synth.pose_problem(seed, n, K, noise_px=0.4, outlier_frac=frac)
+    no, To, oo, so = oracle.pose_opt(K, Ti, obs)
+    ng, Tg, og, sg = ctx.pose_opt(K, Ti, obs)
+    assert ng == no and np.array_equal(og, oo)
+    _pose_close(Tg, To)
+    assert np.isclose(sg[1], so[1], rtol=1e-6, atol=1e-9)
+    # pre-set outlier flags are an input (Frame::GetOutlier)
+    pre = (np.arange(n) % 7 == 0).astype(np.uint8)
+    no, To, oo, _ = oracle.pose_opt(K, Ti, obs, pre)
+    ng, Tg, og, _ = ctx.pose_opt(K, Ti, obs, pre)
+    assert ng == no and np.array_equal(og, oo)
+    _pose_close(Tg, To)
+
+
+def test_pose_opt_too_few(ctx):
+    Tt, Ti, obs = synth.pose_problem(9, 2, K)
+    n, T, outl, st = ctx.pose_opt(K, Ti, obs)
+    assert n == 0 and np.array_equal(T, Ti)
+    n, T, outl, st = ctx.pose_opt(K, Ti, obs[:0])
+    assert n == 0 and np.array_equal(T, Ti)

@@ -1,0 +1,347 @@
+"""ctypes binding of the C ABI (include/tb_capi.h) exported by libtb_hip.so.
+
+This is plumbing, not the product: every call goes straight into the HIP library.  There is no
+CPU fallback -- if the library is missing or no GPU is usable the calls raise.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libtb_hip.so")
+_LIB = None
+
+KEYPOINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),
+                     ("response", "<f4"), ("octave", "<i4"), ("class_id", "<i4")])
+MATCH = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), ("distance", "<f4")])
+CORNER = np.dtype([("x", "<i4"), ("y", "<i4"), ("score", "<i4")])
+OBS = np.dtype([("u", "<f4"), ("v", "<f4"), ("X", "<f4"), ("Y", "<f4"), ("Z", "<f4"), ("inv_sigma2", "<f4")])
+BA_OBS = np.dtype([("kf", "<i4"), ("pt", "<i4"), ("u", "<f4"), ("v", "<f4"), ("inv_sigma2", "<f4")])
+
+TB_OK, TB_EINVAL, TB_ENOMEM, TB_ECAPACITY, TB_EUNSUPPORTED, TB_EDEVICE, TB_ESTATE = 0, -1, -2, -3, -4, -5, -6
+
+# every symbol include/tb_capi.h declares (checked by tests/test_capi_exports.py)
+EXPORTS = [
+    "tb_create", "tb_destroy", "tb_last_error", "tb_strerror", "tb_version", "tb_set_stream", "tb_synchronize",
+    "tb_scale_factors", "tb_pyramid_sizes", "tb_orb_quotas",
+    "tb_extractor_create", "tb_extractor_destroy", "tb_extractor_set_images_host", "tb_extractor_set_images_dev",
+    "tb_extractor_set_levels_host", "tb_extractor_build_pyramid", "tb_extractor_get_level_host", "tb_extractor_orb",
+    "tb_extractor_fastgrid", "tb_extractor_counts_host", "tb_extractor_results_host", "tb_extractor_results_dev",
+    "tb_extractor_candidates_host",
+    "tb_pyramid", "tb_fast_detect", "tb_orb_extract", "tb_fastgrid_extract",
+    "tb_descriptor_distance", "tb_three_maxima", "tb_match_bf", "tb_search_by_bf", "tb_search_by_bf_batch_dev",
+    "tb_search_by_violence", "tb_pose_opt", "tb_pose_opt_batch_dev", "tb_local_ba",
+]
+
+
+class TBError(RuntimeError):
+    def __init__(self, code, msg):
+        super().__init__("tb error %d: %s" % (code, msg))
+        self.code = code
+
+
+def build(force=False):
+    """Compile libtb_hip.so for gfx950 (hipcc cross-compiles without a GPU)."""
+    if force or not os.path.exists(LIB_PATH):
+        subprocess.check_call(["make", "-C", os.path.join(_HERE, "csrc"), "-j8"], stdout=subprocess.DEVNULL,
+                              stderr=subprocess.DEVNULL)
+    return LIB_PATH
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise TBError(TB_EDEVICE, "libtb_hip.so is not built (run __graft_entry__.build())")
+        L = C.CDLL(LIB_PATH)
+        L.tb_last_error.restype = C.c_char_p
+        L.tb_strerror.restype = C.c_char_p
+        L.tb_version.restype = C.c_char_p
+        L.tb_destroy.restype = None
+        L.tb_extractor_destroy.restype = None
+        L.tb_three_maxima.restype = None
+        L.tb_last_error.argtypes = [C.c_void_p]
+        L.tb_destroy.argtypes = [C.c_void_p]
+        L.tb_extractor_destroy.argtypes = [C.c_void_p]
+        _LIB = L
+    return _LIB
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _u8img(img):
+    img = np.ascontiguousarray(img, dtype=np.uint8)
+    assert img.ndim == 2
+    return img
+
+
+def scale_factors(n, scale):
+    sf = np.zeros(n, np.float32); isf = np.zeros(n, np.float32)
+    s2 = np.zeros(n, np.float32); is2 = np.zeros(n, np.float32)
+    rc = lib().tb_scale_factors(n, C.c_float(scale), _p(sf), _p(isf), _p(s2), _p(is2))
+    if rc:
+        raise TBError(rc, "tb_scale_factors")
+    return sf, isf, s2, is2
+
+
+def pyramid_sizes(w, h, sf):
+    sf = np.ascontiguousarray(sf, np.float32)
+    ws = np.zeros(len(sf), np.int32); hs = np.zeros(len(sf), np.int32)
+    rc = lib().tb_pyramid_sizes(int(w), int(h), len(sf), _p(sf), _p(ws), _p(hs))
+    if rc:
+        raise TBError(rc, "tb_pyramid_sizes")
+    return ws, hs
+
+
+def orb_quotas(sf, target):
+    sf = np.ascontiguousarray(sf, np.float32)
+    q = np.zeros(len(sf), np.int32)
+    rc = lib().tb_orb_quotas(len(sf), _p(sf), int(target), _p(q))
+    if rc:
+        raise TBError(rc, "tb_orb_quotas")
+    return q
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return int(lib().tb_descriptor_distance(_p(a), _p(b)))
+
+
+def three_maxima(sizes):
+    sizes = np.ascontiguousarray(sizes, np.int32)
+    i1, i2, i3 = C.c_int(-1), C.c_int(-1), C.c_int(-1)
+    lib().tb_three_maxima(_p(sizes), len(sizes), C.byref(i1), C.byref(i2), C.byref(i3))
+    return i1.value, i2.value, i3.value
+
+
+class Context:
+    """tb_ctx: one GPU + one HIP stream."""
+
+    def __init__(self, device=0, stream=None):
+        self._h = C.c_void_p()
+        rc = lib().tb_create(int(device), C.byref(self._h))
+        if rc:
+            raise TBError(rc, "tb_create(device=%d): %s" % (device, lib().tb_strerror(rc).decode()))
+        if stream is not None:
+            self.set_stream(stream)
+
+    def close(self):
+        if self._h:
+            lib().tb_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def check(self, rc):
+        if rc:
+            raise TBError(rc, lib().tb_last_error(self._h).decode() or lib().tb_strerror(rc).decode())
+
+    def set_stream(self, stream_ptr):
+        self.check(lib().tb_set_stream(self._h, C.c_void_p(stream_ptr)))
+
+    def synchronize(self):
+        self.check(lib().tb_synchronize(self._h))
+
+    # ---- single-frame operator forms
+    def pyramid(self, img, nlevels, scale):
+        img = _u8img(img)
+        sf = scale_factors(nlevels, scale)[0]
+        ws, hs = pyramid_sizes(img.shape[1], img.shape[0], sf)
+        levels = [img] + [np.zeros((int(hs[i]), int(ws[i])), np.uint8) for i in range(1, nlevels)]
+        ptrs = (C.c_void_p * nlevels)(*[l.ctypes.data for l in levels])
+        st = np.array([l.strides[0] for l in levels], np.int32)
+        self.check(lib().tb_pyramid(self._h, _p(img), img.shape[1], img.shape[0], img.strides[0], nlevels, _p(sf), ptrs, _p(st)))
+        return levels, sf
+
+    def fast_detect(self, img, th, nms=True):
+        img = _u8img(img)
+        cap = img.size // (4 if nms else 1) + 4096
+        out = np.zeros(cap, CORNER)
+        n = C.c_int(0)
+        self.check(lib().tb_fast_detect(self._h, _p(img), img.shape[1], img.shape[0], img.strides[0], int(th), int(nms),
+                                        _p(out), cap, C.byref(n)))
+        return out[:n.value].copy()
+
+    @staticmethod
+    def _level_args(levels):
+        levels = [_u8img(l) for l in levels]
+        n = len(levels)
+        ptrs = (C.c_void_p * n)(*[l.ctypes.data for l in levels])
+        ws = np.array([l.shape[1] for l in levels], np.int32)
+        hs = np.array([l.shape[0] for l in levels], np.int32)
+        st = np.array([l.strides[0] for l in levels], np.int32)
+        return levels, ptrs, ws, hs, st
+
+    def orb_extract(self, levels, sf, target, init_th, min_th, exit_keys=None, quotas=None):
+        levels, ptrs, ws, hs, st = self._level_args(levels)
+        sf = np.ascontiguousarray(sf, np.float32)
+        cap = int(target) + 64 * len(levels) + 64
+        if quotas is not None:
+            cap = max(cap, int(np.sum(quotas)) + 64 * len(levels) + 64)
+        kps = np.zeros(cap, KEYPOINT)
+        desc = np.zeros((cap, 32), np.uint8)
+        q = np.zeros(len(levels), np.int32) if quotas is None else np.ascontiguousarray(quotas, np.int32).copy()
+        ek = None if exit_keys is None else np.ascontiguousarray(exit_keys, KEYPOINT)
+        n = C.c_int(0)
+        self.check(lib().tb_orb_extract(self._h, ptrs, _p(ws), _p(hs), _p(st), len(levels), _p(sf), int(target),
+                                        C.c_float(init_th), C.c_float(min_th), _p(ek), 0 if ek is None else len(ek),
+                                        int(quotas is not None), _p(q), _p(kps), _p(desc), cap, C.byref(n)))
+        return kps[:n.value].copy(), desc[:n.value].copy(), q
+
+    def fastgrid_extract(self, levels, inv_sf, target, threshold, occupancy=None):
+        levels, ptrs, ws, hs, st = self._level_args(levels)
+        inv_sf = np.ascontiguousarray(inv_sf, np.float32)
+        cap = int(target) * 2 + 4096
+        kps = np.zeros(cap, KEYPOINT)
+        occ = None if occupancy is None else np.ascontiguousarray(occupancy, np.uint8)
+        n = C.c_int(0)
+        self.check(lib().tb_fastgrid_extract(self._h, ptrs, _p(ws), _p(hs), _p(st), len(levels), _p(inv_sf), int(target),
+                                             C.c_float(threshold), _p(occ), 0 if occ is None else len(occ), _p(kps), cap,
+                                             C.byref(n)))
+        return kps[:n.value].copy()
+
+    @staticmethod
+    def _desc(d):
+        d = np.ascontiguousarray(d, np.uint8)
+        if d.size == 0:
+            d = d.reshape(0, 32)
+        assert d.ndim == 2 and d.shape[1] == 32
+        return d
+
+    def bf_match(self, d1, d2, crosscheck=True):
+        d1, d2 = self._desc(d1), self._desc(d2)
+        out = np.zeros(max(len(d1), 1), MATCH)
+        n = C.c_int(0)
+        self.check(lib().tb_match_bf(self._h, _p(d1), len(d1), _p(d2), len(d2), int(crosscheck), _p(out), len(out), C.byref(n)))
+        return out[:n.value].copy()
+
+    def search_by_bf(self, d1, d2, ratio, min_th):
+        d1, d2 = self._desc(d1), self._desc(d2)
+        out = np.zeros(max(len(d1), 1), MATCH)
+        n = C.c_int(0)
+        self.check(lib().tb_search_by_bf(self._h, _p(d1), len(d1), _p(d2), len(d2), C.c_float(ratio), C.c_float(min_th),
+                                         _p(out), len(out), C.byref(n)))
+        return out[:n.value].copy()
+
+    def search_by_violence(self, k1, d1, k2, d2, img2_w, img2_h, min_level=0, max_level=1, radius=10.0, th_low=50,
+                           nratio=0.0, histo_len=30, check_orientation=True):
+        k1 = np.ascontiguousarray(k1, KEYPOINT); k2 = np.ascontiguousarray(k2, KEYPOINT)
+        d1, d2 = self._desc(d1), self._desc(d2)
+        out = np.zeros(max(len(k1), 1), MATCH)
+        n = C.c_int(0)
+        self.check(lib().tb_search_by_violence(self._h, _p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), int(img2_w),
+                                               int(img2_h), int(min_level), int(max_level), C.c_float(radius), int(th_low),
+                                               C.c_float(nratio), int(histo_len), int(check_orientation), _p(out), len(out),
+                                               C.byref(n)))
+        return out[:n.value].copy()
+
+    def pose_opt(self, K, Tcw, obs, outlier=None):
+        K = np.ascontiguousarray(K, np.float64)
+        Tcw = np.ascontiguousarray(Tcw, np.float32).reshape(16)
+        obs = np.ascontiguousarray(obs, OBS)
+        outl = np.zeros(len(obs), np.uint8) if outlier is None else np.ascontiguousarray(outlier, np.uint8).copy()
+        out = np.zeros(16, np.float32)
+        stats = np.zeros(8, np.float64)
+        n = C.c_int(0)
+        self.check(lib().tb_pose_opt(self._h, _p(K), _p(Tcw), _p(obs), len(obs), _p(outl), _p(out), C.byref(n), _p(stats)))
+        return n.value, out.reshape(4, 4), outl, stats
+
+    def local_ba(self, K, poses, nfixed, pts, obs, iters=10):
+        K = np.ascontiguousarray(K, np.float64)
+        poses = np.ascontiguousarray(poses, np.float32).reshape(-1, 16).copy()
+        pts = np.ascontiguousarray(pts, np.float32).reshape(-1, 3).copy()
+        obs = np.ascontiguousarray(obs, BA_OBS)
+        stats = np.zeros(8, np.float64)
+        self.check(lib().tb_local_ba(self._h, _p(K), len(poses), int(nfixed), _p(poses), len(pts), _p(pts), _p(obs), len(obs),
+                                     int(iters), _p(stats)))
+        return int(stats[0]), poses.reshape(-1, 4, 4), pts, stats
+
+
+class Extractor:
+    """tb_extractor: batched, device-resident pyramid + ORB / FAST-grid extraction plan."""
+
+    def __init__(self, ctx, width, height, nlevels, scale, max_images, max_target):
+        self.ctx = ctx
+        self.sf, self.inv_sf, self.sigma2, self.inv_sigma2 = scale_factors(nlevels, scale)
+        self.width, self.height, self.nlevels = int(width), int(height), int(nlevels)
+        self.max_images = int(max_images)
+        self.ws, self.hs = pyramid_sizes(width, height, self.sf)
+        self._h = C.c_void_p()
+        ctx.check(lib().tb_extractor_create(ctx._h, self.width, self.height, self.nlevels, _p(self.sf), None, None,
+                                            self.max_images, int(max_target), C.byref(self._h)))
+        self._keep = None
+
+    def close(self):
+        if self._h:
+            lib().tb_extractor_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_images_host(self, images):
+        images = np.ascontiguousarray(images, np.uint8)
+        if images.ndim == 2:
+            images = images[None]
+        assert images.shape[1:] == (self.height, self.width)
+        self._keep = images
+        self.ctx.check(lib().tb_extractor_set_images_host(self._h, _p(images), images.shape[0], images.strides[1],
+                                                          C.c_size_t(images.strides[0])))
+        return images.shape[0]
+
+    def set_images_dev(self, dev_ptr, n, stride, pitch):
+        self.ctx.check(lib().tb_extractor_set_images_dev(self._h, C.c_void_p(dev_ptr), int(n), int(stride), C.c_size_t(pitch)))
+
+    def build_pyramid(self, n):
+        self.ctx.check(lib().tb_extractor_build_pyramid(self._h, int(n)))
+
+    def get_level(self, index, level):
+        out = np.zeros((int(self.hs[level]), int(self.ws[level])), np.uint8)
+        self.ctx.check(lib().tb_extractor_get_level_host(self._h, int(index), int(level), _p(out), out.strides[0]))
+        return out
+
+    def orb(self, n, target, init_th, min_th, quota_mode=0, exit_keys=None):
+        ek = None if exit_keys is None else np.ascontiguousarray(exit_keys, KEYPOINT)
+        self.ctx.check(lib().tb_extractor_orb(self._h, int(n), int(target), C.c_float(init_th), C.c_float(min_th),
+                                              int(quota_mode), _p(ek), 0 if ek is None else len(ek)))
+
+    def fastgrid(self, n, target, threshold, occupancy=None):
+        occ = None if occupancy is None else np.ascontiguousarray(occupancy, np.uint8)
+        self.ctx.check(lib().tb_extractor_fastgrid(self._h, int(n), _p(self.inv_sf), int(target), C.c_float(threshold),
+                                                   _p(occ), 0 if occ is None else len(occ)))
+
+    def counts(self, n):
+        c = np.zeros(int(n), np.int32)
+        self.ctx.check(lib().tb_extractor_counts_host(self._h, int(n), _p(c)))
+        return c
+
+    def results(self, index, cap=None, with_desc=True):
+        cap = int(cap or 65536)
+        kps = np.zeros(cap, KEYPOINT)
+        desc = np.zeros((cap, 32), np.uint8) if with_desc else None
+        n = C.c_int(0)
+        self.ctx.check(lib().tb_extractor_results_host(self._h, int(index), _p(kps), _p(desc), cap, C.byref(n)))
+        return kps[:n.value].copy(), (desc[:n.value].copy() if with_desc else None)
+
+    def results_dev(self):
+        kps, desc, counts, cap = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(0)
+        self.ctx.check(lib().tb_extractor_results_dev(self._h, C.byref(kps), C.byref(desc), C.byref(counts), C.byref(cap)))
+        return kps.value, desc.value, counts.value, cap.value
+
+    def candidates(self, index, level):
+        cap = int(self.ws[level]) * int(self.hs[level]) // 4 + 4096
+        out = np.zeros(cap, CORNER)
+        n = C.c_int(0)
+        self.ctx.check(lib().tb_extractor_candidates_host(self._h, int(index), int(level), _p(out), cap, C.byref(n)))
+        return out[:n.value].copy()

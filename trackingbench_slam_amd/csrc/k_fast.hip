@@ -1,0 +1,374 @@
+/* a4 / a11 -- FAST corner detection + score + 3x3 non-max suppression.
+ *
+ * Reference: ComputeKeyPointsOctTree cell loop calling cv::FAST(ROI, initTh, nms) with the minTH retry
+ * (src/extractors/ORBextractor.cpp:747-804) and FASTExtractor's fast_corner_detect_10 /
+ * fast_corner_score_10 / fast_nonmax_3x3 (src/extractors/FASTextractor.cpp:36-51).
+ *
+ * Formulation (hard part 3): the FAST score S(p) = largest t for which p is still a
+ * corner is threshold independent, a pixel is a corner at t iff S(p) >= t, and 3x3 NMS on S restricted
+ * to the scanned region equals OpenCV's / fast_lib's NMS.  So one pass scores a region once and the
+ * per-cell adaptive threshold becomes a block-wide reduction:
+ *   emit {p : local strict maximum, S(p) >= th},  th = initTh if that set is non-empty else minTh.
+ *
+ * One workgroup per work item (a 30-px cell ROI, or a 58x58 tile in whole-image mode). The ROI
+ * (<= 66x66 u8) is staged in LDS with row-contiguous loads; phase A runs the 16-compare arc test on
+ * every scanned pixel and ballot-compacts the few survivors into an LDS list; phases B-D (exact score,
+ * NMS, emit) touch only that list.  Roofline: HBM (1 read per pixel) but in practice the
+ * 16-tap ring test makes phase A LDS/VALU-issue bound; see DESIGN.md.
+ */
+#include "tb_internal.h"
+#include "tb_device.h"
+
+#define FT_TS 68   /* LDS tile row stride (bytes) */
+#define FT_TH 66   /* max ROI rows / cols */
+#define FT_LIST 3600
+
+struct FastRegion {
+    int lx0, ly0, lx1, ly1; /* loaded pixels */
+    int sx0, sy0, sx1, sy1; /* scored pixels (scan region) */
+    int ox0, oy0, ox1, oy1; /* output pixels */
+};
+
+__device__ __forceinline__ void ft_ring(const uint8_t* c, int r[16]) {
+    r[0] = c[3 * FT_TS];       r[1] = c[3 * FT_TS + 1];  r[2] = c[2 * FT_TS + 2];  r[3] = c[FT_TS + 3];
+    r[4] = c[3];               r[5] = c[-FT_TS + 3];     r[6] = c[-2 * FT_TS + 2]; r[7] = c[-3 * FT_TS + 1];
+    r[8] = c[-3 * FT_TS];      r[9] = c[-3 * FT_TS - 1]; r[10] = c[-2 * FT_TS - 2]; r[11] = c[-FT_TS - 3];
+    r[12] = c[-3];             r[13] = c[FT_TS - 3];     r[14] = c[2 * FT_TS - 2]; r[15] = c[3 * FT_TS - 1];
+}
+
+template <int ARC>
+__device__ __forceinline__ bool ft_is_corner(const uint8_t* c, int th) {
+    int r[16];
+    ft_ring(c, r);
+    const int v = c[0];
+    const int hi = v + th, lo = v - th;
+    uint32_t B = 0, D = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        B |= (uint32_t)(r[k] > hi) << k;
+        D |= (uint32_t)(r[k] < lo) << k;
+    }
+    B |= B << 16;
+    D |= D << 16;
+    uint32_t xb = B & (B >> 1), xd = D & (D >> 1);
+    xb &= xb >> 2; xd &= xd >> 2;
+    xb &= xb >> 4; xd &= xd >> 4;
+    xb &= B >> 8;  xd &= D >> 8;
+    if (ARC == 10) { xb &= B >> 9; xd &= D >> 9; }
+    return ((xb | xd) & 0xffffu) != 0;
+}
+
+/* exact score: max over the 16 arcs of min |d| with a common sign, minus 1 */
+template <int ARC>
+__device__ __forceinline__ int ft_score(const uint8_t* c) {
+    int r[16];
+    ft_ring(c, r);
+    const int v = c[0];
+    int d[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) d[k] = v - r[k];
+    int best = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int mn = d[k], mx = d[k];
+#pragma unroll
+        for (int i = 1; i < ARC; i++) {
+            mn = min(mn, d[(k + i) & 15]);
+            mx = max(mx, d[(k + i) & 15]);
+        }
+        best = max(best, max(mn, -mx));
+    }
+    return best - 1;
+}
+
+/* Shared body. Emits packed records score<<24 | (y-oy_bias)<<12 | (x-ox_bias) into out[] through a
+ * wave-aggregated atomic on *count. two_th: cell mode (initTh with minTh retry). */
+template <int ARC>
+__device__ __forceinline__ void ft_process(const uint8_t* __restrict__ img, int stride, const FastRegion R,
+                                           int th_hi, int th_lo, bool two_th, bool nms, int ox_bias, int oy_bias,
+                                           uint32_t* __restrict__ out, int cap, int* __restrict__ count) {
+    __shared__ __attribute__((aligned(16))) uint8_t tile[FT_TH * FT_TS];
+    __shared__ __attribute__((aligned(16))) uint8_t sc[FT_TH * FT_TS];
+    __shared__ uint16_t clist[FT_LIST];
+    __shared__ int nlist, any_hi;
+    const int tid = threadIdx.x, T = blockDim.x;
+    const int lw = R.lx1 - R.lx0, lh = R.ly1 - R.ly0;
+    if (tid == 0) { nlist = 0; any_hi = 0; }
+    /* stage pixels (row-contiguous) and clear the score map */
+    for (int i = tid; i < lh * FT_TS; i += T) {
+        const int y = i / FT_TS, x = i - y * FT_TS;
+        tile[i] = (x < lw) ? img[(size_t)(R.ly0 + y) * stride + R.lx0 + x] : 0;
+        sc[i] = 0;
+    }
+    __syncthreads();
+    const int sw = R.sx1 - R.sx0, sh = R.sy1 - R.sy0;
+    const int npx = sw > 0 && sh > 0 ? sw * sh : 0;
+    const int thA = two_th ? min(th_hi, th_lo) : th_hi;
+    /* phase A: arc test on every scanned pixel, compact survivors */
+    for (int base = 0; base < npx; base += T) {
+        const int i = base + tid;
+        bool c = false;
+        int idx = 0;
+        if (i < npx) {
+            const int y = i / sw, x = i - y * sw;
+            idx = (R.sy0 - R.ly0 + y) * FT_TS + (R.sx0 - R.lx0 + x);
+            c = ft_is_corner<ARC>(tile + idx, thA);
+        }
+        const unsigned long long m = __ballot(c);
+        int wbase = 0;
+        if (tb_lane() == 0 && m) wbase = atomicAdd(&nlist, __popcll(m));
+        wbase = __shfl(wbase, 0, TB_WAVE);
+        if (c) {
+            const int slot = wbase + __popcll(m & ((1ull << tb_lane()) - 1));
+            if (slot < FT_LIST) clist[slot] = (uint16_t)idx;
+        }
+    }
+    __syncthreads();
+    const int n = min(nlist, FT_LIST);
+    /* phase B: exact scores of the survivors */
+    for (int i = tid; i < n; i += T) {
+        const int idx = clist[i];
+        int s = ft_score<ARC>(tile + idx);
+        sc[idx] = (uint8_t)min(max(s, 0), 255);
+    }
+    __syncthreads();
+    /* phase C: 3x3 strict maximum; neighbours outside the scored region hold 0 */
+    const int oxa = R.ox0 - R.lx0, oxb = R.ox1 - R.lx0, oya = R.oy0 - R.ly0, oyb = R.oy1 - R.ly0;
+    int hit_hi = 0;
+    for (int i = tid; i < n; i += T) {
+        const int idx = clist[i];
+        const int y = idx / FT_TS, x = idx - y * FT_TS;
+        const int s = sc[idx];
+        bool keep = (x >= oxa && x < oxb && y >= oya && y < oyb) && s > 0;
+        if (keep && nms) {
+            keep = s > sc[idx - 1] && s > sc[idx + 1] && s > sc[idx - FT_TS - 1] && s > sc[idx - FT_TS] &&
+                   s > sc[idx - FT_TS + 1] && s > sc[idx + FT_TS - 1] && s > sc[idx + FT_TS] && s > sc[idx + FT_TS + 1];
+        }
+        if (!keep) clist[i] = 0xffff;
+        else if (s >= th_hi) hit_hi = 1;
+    }
+    if (two_th) {
+        if (hit_hi) any_hi = 1; /* benign race: all writers store 1 */
+    }
+    __syncthreads();
+    const int th = two_th ? (any_hi ? th_hi : th_lo) : th_hi;
+    /* phase D: emit */
+    for (int base = 0; base < n; base += T) {
+        const int i = base + tid;
+        bool e = false;
+        uint32_t rec = 0;
+        if (i < n) {
+            const int idx = clist[i];
+            if (idx != 0xffff) {
+                const int s = sc[idx];
+                if (s >= th) {
+                    const int y = idx / FT_TS, x = idx - y * FT_TS;
+                    e = true;
+                    rec = ((uint32_t)s << 24) | ((uint32_t)(R.ly0 + y - oy_bias) << 12) | (uint32_t)(R.lx0 + x - ox_bias);
+                }
+            }
+        }
+        const unsigned long long m = __ballot(e);
+        int wbase = 0;
+        if (tb_lane() == 0 && m) wbase = atomicAdd(count, __popcll(m));
+        wbase = __shfl(wbase, 0, TB_WAVE);
+        if (e) {
+            const int slot = wbase + __popcll(m & ((1ull << tb_lane()) - 1));
+            if (slot < cap) out[slot] = rec;
+        }
+    }
+}
+
+/* ---- cell mode: grid (cells, images) */
+__global__ void __launch_bounds__(256)
+k_fast_cells(PlanGeom g, const uint8_t* __restrict__ slab, const CellDesc* __restrict__ cells,
+             uint32_t* __restrict__ cand, int32_t* __restrict__ candCount, int init_th, int min_th) {
+    const CellDesc c = cells[blockIdx.x];
+    const int b = blockIdx.y;
+    const LevelGeom& L = g.lv[c.level];
+    int stride;
+    const uint8_t* img = tb_level_ptr(g, slab, b, c.level, &stride);
+    FastRegion R;
+    R.lx0 = c.x0; R.ly0 = c.y0; R.lx1 = c.x1; R.ly1 = c.y1;
+    R.sx0 = c.x0 + 3; R.sy0 = c.y0 + 3; R.sx1 = c.x1 - 3; R.sy1 = c.y1 - 3;
+    R.ox0 = R.sx0; R.oy0 = R.sy0; R.ox1 = R.sx1; R.oy1 = R.sy1;
+    ft_process<9>(img, stride, R, init_th, min_th, true, true, TB_BORDER, TB_BORDER,
+                  cand + (size_t)b * g.candPerImage + L.candOff, L.candCap, candCount + b * TB_MAX_LEVELS + c.level);
+}
+
+int tbk_fast_cells(tb_extractor* ex, int n, int init_th, int min_th) {
+    tb_ctx* ctx = ex->ctx;
+    TB_HIP(ctx, hipMemsetAsync(ex->d_candCount, 0, sizeof(int32_t) * TB_MAX_LEVELS * n, ctx->stream));
+    if (ex->nCellsTotal == 0) return TB_OK;
+    dim3 grid(ex->nCellsTotal, n);
+    hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, ctx->stream, ex->g, ex->d_slab, ex->d_cells, ex->d_cand,
+                       ex->d_candCount, init_th, min_th);
+    TB_HIP(ctx, hipGetLastError());
+    return TB_OK;
+}
+
+/* ---- whole-image mode: 58x58 output tiles, scan region [3,w-3) x [3,h-3) */
+#define FT_OUT 58
+
+template <int ARC>
+__global__ void __launch_bounds__(256)
+k_fast_image(const uint8_t* __restrict__ img, int w, int h, int stride, size_t pitch, int th, int nms,
+             uint32_t* __restrict__ out, int cap, size_t out_pitch, int32_t* __restrict__ count, int count_stride) {
+    const int b = blockIdx.z;
+    FastRegion R;
+    R.ox0 = 3 + blockIdx.x * FT_OUT; R.oy0 = 3 + blockIdx.y * FT_OUT;
+    R.ox1 = min(R.ox0 + FT_OUT, w - 3); R.oy1 = min(R.oy0 + FT_OUT, h - 3);
+    R.sx0 = max(R.ox0 - 1, 3); R.sy0 = max(R.oy0 - 1, 3);
+    R.sx1 = min(R.ox1 + 1, w - 3); R.sy1 = min(R.oy1 + 1, h - 3);
+    R.lx0 = R.sx0 - 3; R.ly0 = R.sy0 - 3; R.lx1 = R.sx1 + 3; R.ly1 = R.sy1 + 3;
+    ft_process<ARC>(img + (size_t)b * pitch, stride, R, th, th, false, nms != 0, 0, 0, out + (size_t)b * out_pitch, cap,
+                    count + (size_t)b * count_stride);
+}
+
+int tbk_fast_image(tb_ctx* ctx, const uint8_t* d_img, int w, int h, int stride, int th, int nms, int arc,
+                   uint32_t* d_out, int cap, int32_t* d_count) {
+    TB_HIP(ctx, hipMemsetAsync(d_count, 0, sizeof(int32_t), ctx->stream));
+    if (w < 7 || h < 7) return TB_OK;
+    dim3 grid((w - 6 + FT_OUT - 1) / FT_OUT, (h - 6 + FT_OUT - 1) / FT_OUT, 1);
+    if (arc == 9)
+        hipLaunchKernelGGL(k_fast_image<9>, grid, dim3(256), 0, ctx->stream, d_img, w, h, stride, (size_t)0, th, nms,
+                           d_out, cap, (size_t)0, d_count, 0);
+    else
+        hipLaunchKernelGGL(k_fast_image<10>, grid, dim3(256), 0, ctx->stream, d_img, w, h, stride, (size_t)0, th, nms,
+                           d_out, cap, (size_t)0, d_count, 0);
+    TB_HIP(ctx, hipGetLastError());
+    return TB_OK;
+}
+
+/* ---- a11: FASTExtractor grid selection.
+ * Per level: FAST-10 (th 20) + NMS over the whole level (above), then every surviving corner bids for
+ * its grid cell with (Shi-Tomasi score, first-seen order) -- FASTextractor.cpp:53-69.  "First seen" in
+ * the reference is (level, raster order); the bid key reproduces it so the atomicMax is order free:
+ *   key = score_bits<<32 | ~(level<<26 | y<<13 | x)     (score > 0 so its float bits sort as uints). */
+__device__ __forceinline__ float ft_shi_tomasi(const uint8_t* img, int w, int h, int stride, int u, int v) {
+    /* FASTExtractor::shiTomasiScore, FASTextractor.cpp:87-127 (float accumulation in scan order) */
+    float dXX = 0.f, dYY = 0.f, dXY = 0.f;
+    const int x_min = u - 4, x_max = u + 4, y_min = v - 4, y_max = v + 4;
+    if (x_min < 1 || x_max >= w - 1 || y_min < 1 || y_max >= h - 1) return 0.f;
+    for (int y = y_min; y < y_max; ++y) {
+        const uint8_t* row = img + (size_t)y * stride;
+        for (int x = x_min; x < x_min + 8; ++x) {
+            const float dx = (float)row[x + 1] - (float)row[x - 1];
+            const float dy = (float)row[x + stride] - (float)row[x - stride];
+            dXX = TB_FADD(dXX, TB_FMUL(dx, dx));
+            dYY = TB_FADD(dYY, TB_FMUL(dy, dy));
+            dXY = TB_FADD(dXY, TB_FMUL(dx, dy));
+        }
+    }
+    dXX = TB_FDIV(dXX, 128.f);
+    dYY = TB_FDIV(dYY, 128.f);
+    dXY = TB_FDIV(dXY, 128.f);
+    const float tr = TB_FADD(dXX, dYY);
+    const float disc = TB_FSUB(TB_FMUL(tr, tr), TB_FMUL(4.f, TB_FSUB(TB_FMUL(dXX, dYY), TB_FMUL(dXY, dXY))));
+    return TB_FMUL(0.5f, TB_FSUB(tr, __fsqrt_rn(disc)));
+}
+
+__global__ void __launch_bounds__(256)
+k_fastgrid_bid(PlanGeom g, const uint8_t* __restrict__ slab, const uint32_t* __restrict__ cand,
+               const int32_t* __restrict__ candCount, int level, int cell_size, int grid_cols, int ncell,
+               const uint8_t* __restrict__ occ, int n_occ, unsigned long long* __restrict__ best) {
+    const int b = blockIdx.y;
+    const LevelGeom& L = g.lv[level];
+    const int n = min(candCount[b * TB_MAX_LEVELS + level], L.candCap);
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t rec = cand[(size_t)b * g.candPerImage + L.candOff + i];
+    const int x = rec & 0xfff, y = (rec >> 12) & 0xfff;
+    const float fx = TB_FMUL((float)x, L.inv_sf), fy = TB_FMUL((float)y, L.inv_sf);
+    const int k = (int)TB_FDIV(fy, (float)cell_size) * grid_cols + (int)TB_FDIV(fx, (float)cell_size);
+    if (k < 0 || k >= ncell) return;
+    if (occ && k < n_occ && occ[k]) return;
+    int stride;
+    const uint8_t* img = tb_level_ptr(g, slab, b, level, &stride);
+    const float score = ft_shi_tomasi(img, L.w, L.h, stride, x, y);
+    if (!(score > 0.f)) return;
+    const uint32_t order = ((uint32_t)level << 26) | ((uint32_t)y << 13) | (uint32_t)x;
+    const unsigned long long key = ((unsigned long long)__float_as_uint(score) << 32) | (uint32_t)(~order);
+    atomicMax(&best[(size_t)b * ncell + k], key);
+}
+
+__global__ void __launch_bounds__(256)
+k_fastgrid_emit(PlanGeom g, const unsigned long long* __restrict__ best, int ncell, float threshold,
+                tb_keypoint* __restrict__ kps, int32_t* __restrict__ counts) {
+    /* one block per image: cells in index order -> keyPoints order of FASTextractor.cpp:72-78 */
+    __shared__ int flags[256];
+    __shared__ int tmp[8];
+    __shared__ int running;
+    const int b = blockIdx.x, tid = threadIdx.x;
+    if (tid == 0) running = 0;
+    __syncthreads();
+    for (int base = 0; base < ncell; base += 256) {
+        const int k = base + tid;
+        unsigned long long key = 0;
+        float score = 0.f;
+        if (k < ncell) {
+            key = best[(size_t)b * ncell + k];
+            score = __uint_as_float((uint32_t)(key >> 32));
+        }
+        const int f = (k < ncell && key != 0 && score > threshold) ? 1 : 0;
+        flags[tid] = f;
+        __syncthreads();
+        const int total = tb_block_excl_scan(flags, 256, tmp);
+        if (f) {
+            const uint32_t order = ~(uint32_t)key;
+            const int level = order >> 26, y = (order >> 13) & 0x1fff, x = order & 0x1fff;
+            tb_keypoint kp;
+            kp.x = TB_FMUL((float)x, g.lv[level].inv_sf);
+            kp.y = TB_FMUL((float)y, g.lv[level].inv_sf);
+            kp.size = 1.f; kp.angle = 0.f; kp.response = score; kp.octave = level; kp.class_id = -1;
+            kps[(size_t)b * g.selCap + running + flags[tid]] = kp;
+        }
+        __syncthreads();
+        if (tid == 0) running += total;
+        __syncthreads();
+    }
+    if (tid == 0) counts[b] = running;
+}
+
+int tbk_fastgrid(tb_extractor* ex, int n, int target, float threshold, int n_occ) {
+    tb_ctx* ctx = ex->ctx;
+    const PlanGeom& g = ex->g;
+    const int cell_size = (int)sqrtf((float)g.width * (float)g.height / (float)target);
+    if (cell_size < 1) return tb_fail(ctx, TB_EINVAL, "fastgrid: cell size < 1");
+    const int grid_cols = (int)((float)g.width / (float)cell_size);
+    const int grid_rows = (int)((float)g.height / (float)cell_size);
+    int ncell = (grid_rows + 2) * (grid_cols + 1);
+    if (ncell < target) ncell = target;
+    if (ncell > g.selCap) return tb_fail(ctx, TB_ECAPACITY, "fastgrid: %d grid cells exceed plan capacity %d", ncell, g.selCap);
+    const size_t need = (size_t)n * ncell;
+    if (need > ex->gridBestCap) {
+        if (ex->d_gridBest) hipFree(ex->d_gridBest);
+        ex->d_gridBest = nullptr;
+        TB_HIP(ctx, hipMalloc(&ex->d_gridBest, need * sizeof(unsigned long long)));
+        ex->gridBestCap = need;
+    }
+    TB_HIP(ctx, hipMemsetAsync(ex->d_gridBest, 0, need * sizeof(unsigned long long), ctx->stream));
+    TB_HIP(ctx, hipMemsetAsync(ex->d_candCount, 0, sizeof(int32_t) * TB_MAX_LEVELS * n, ctx->stream));
+    for (int l = 0; l < g.nlevels; l++) {
+        const LevelGeom& L = g.lv[l];
+        if (L.w < 7 || L.h < 7) continue;
+        /* detect (image mode, all frames of the batch in grid.z) */
+        dim3 grid((L.w - 6 + FT_OUT - 1) / FT_OUT, (L.h - 6 + FT_OUT - 1) / FT_OUT, n);
+        const uint8_t* base;
+        size_t pitch;
+        int stride;
+        if (l == 0 && g.img0) { base = g.img0; pitch = g.img0_pitch; stride = g.img0_stride; }
+        else { base = ex->d_slab + L.off; pitch = g.slabBytes; stride = L.stride; }
+        hipLaunchKernelGGL(k_fast_image<10>, grid, dim3(256), 0, ctx->stream, base, L.w, L.h, stride, pitch, 20, 1,
+                           ex->d_cand + L.candOff, L.candCap, (size_t)g.candPerImage, ex->d_candCount + l, TB_MAX_LEVELS);
+        TB_HIP(ctx, hipGetLastError());
+        dim3 bgrid((L.candCap + 255) / 256, n);
+        hipLaunchKernelGGL(k_fastgrid_bid, bgrid, dim3(256), 0, ctx->stream, g, ex->d_slab, ex->d_cand, ex->d_candCount, l,
+                           cell_size, grid_cols, ncell, n_occ > 0 ? ex->d_occ : nullptr, n_occ, ex->d_gridBest);
+        TB_HIP(ctx, hipGetLastError());
+    }
+    hipLaunchKernelGGL(k_fastgrid_emit, dim3(n), dim3(256), 0, ctx->stream, g, ex->d_gridBest, ncell, threshold, ex->d_kps,
+                       ex->d_counts);
+    TB_HIP(ctx, hipGetLastError());
+    return TB_OK;
+}

@@ -1,0 +1,902 @@
+/* Host side of libtb_hip.so: the C ABI of include/tb_capi.h on top of the HIP kernels (k_*.hip).
+ * No CPU compute fallback lives here: every operator either runs its kernels or returns an error.
+ * Host work is limited to set-up arithmetic the reference also does on the host (scale vectors, level
+ * sizes, quotas, resize coefficient tables, cell tables), data movement, and the final ordering /
+ * histogram bookkeeping of the window matcher.
+ */
+#include "tb_internal.h"
+#include "tb_math.h"
+
+#include <stdarg.h>
+#include <string.h>
+#include <algorithm>
+#include <cmath>
+#include <memory>
+
+/* ------------------------------------------------------------------ errors / context */
+int tb_fail(tb_ctx* ctx, int code, const char* fmt, ...) {
+    char buf[512];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    return code;
+}
+
+int tb_scratch(tb_ctx* ctx, int slot, size_t bytes, void** out) {
+    if (bytes < 256) bytes = 256;
+    if (ctx->scratch_cap[slot] < bytes) {
+        if (ctx->scratch[slot]) {
+            TB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            TB_HIP(ctx, hipFree(ctx->scratch[slot]));
+            ctx->scratch[slot] = nullptr;
+            ctx->scratch_cap[slot] = 0;
+        }
+        const size_t cap = bytes + bytes / 4;
+        TB_HIP(ctx, hipMalloc(&ctx->scratch[slot], cap));
+        ctx->scratch_cap[slot] = cap;
+    }
+    *out = ctx->scratch[slot];
+    return TB_OK;
+}
+
+extern "C" {
+
+const char* tb_version(void) { return "trackingbench-slam_amd 0.1 (gfx950)"; }
+
+const char* tb_strerror(int code) {
+    switch (code) {
+        case TB_OK: return "ok";
+        case TB_EINVAL: return "invalid argument";
+        case TB_ENOMEM: return "out of memory";
+        case TB_ECAPACITY: return "output capacity too small";
+        case TB_EUNSUPPORTED: return "unsupported input (reference behaviour undefined)";
+        case TB_EDEVICE: return "HIP device error";
+        case TB_ESTATE: return "call sequence error";
+        default: return "unknown error";
+    }
+}
+
+int tb_create(int device, tb_ctx** out) {
+    if (!out) return TB_EINVAL;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return TB_EDEVICE; /* no GPU: fail loudly */
+    if (device < 0 || device >= ndev) return TB_EINVAL;
+    if (hipSetDevice(device) != hipSuccess) return TB_EDEVICE;
+    tb_ctx* ctx = new (std::nothrow) tb_ctx();
+    if (!ctx) return TB_ENOMEM;
+    ctx->device = device;
+    if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
+        delete ctx;
+        return TB_EDEVICE;
+    }
+    ctx->stream = ctx->own_stream;
+    *out = ctx;
+    return TB_OK;
+}
+
+void tb_destroy(tb_ctx* ctx) {
+    if (!ctx) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->plans) tb_extractor_destroy(kv.second);
+    ctx->plans.clear();
+    for (int i = 0; i < 8; i++)
+        if (ctx->scratch[i]) hipFree(ctx->scratch[i]);
+    if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+}
+
+const char* tb_last_error(const tb_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
+
+int tb_set_stream(tb_ctx* ctx, void* hip_stream) {
+    if (!ctx) return TB_EINVAL;
+    TB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
+    return TB_OK;
+}
+
+int tb_synchronize(tb_ctx* ctx) {
+    if (!ctx) return TB_EINVAL;
+    TB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TB_OK;
+}
+
+/* ------------------------------------------------------------------ a1 / a2 / a3 host arithmetic */
+int tb_scale_factors(int n, float scale, float* sf, float* inv_sf, float* sigma2, float* inv_sigma2) {
+    /* Frame::Frame, Frame.cpp:18-29 (float32 throughout) */
+    if (n < 1 || !sf) return TB_EINVAL;
+    float cur = 1.f, icur = 1.f;
+    for (int i = 0; i < n; i++) {
+        if (i > 0) { cur = cur * scale; icur = icur / scale; }
+        sf[i] = cur;
+        if (inv_sf) inv_sf[i] = icur;
+        const float s2 = (i == 0) ? 1.f : cur * cur;
+        if (sigma2) sigma2[i] = s2;
+        if (inv_sigma2) inv_sigma2[i] = (i == 0) ? 1.f : 1.f / s2;
+    }
+    return TB_OK;
+}
+
+int tb_pyramid_sizes(int width, int height, int nlevels, const float* sf, int* widths, int* heights) {
+    /* Frame::ComputePyramid, Frame.cpp:423-424: cv::Size(cols * scale, rows * scale) truncates */
+    if (nlevels < 1 || !sf || !widths || !heights) return TB_EINVAL;
+    widths[0] = width;
+    heights[0] = height;
+    for (int i = 1; i < nlevels; i++) {
+        widths[i] = (int)((float)width * sf[i]);
+        heights[i] = (int)((float)height * sf[i]);
+    }
+    return TB_OK;
+}
+
+int tb_orb_quotas(int nlevels, const float* sf, int target, int* quotas) {
+    /* ORBExtractor::operator(), ORBextractor.cpp:919-930; reads sf[1], so one level is undefined there */
+    if (nlevels < 2 || !sf || !quotas) return TB_EINVAL;
+    float nDesired = target * (1 - sf[1]) / (1 - (float)pow((double)sf[1], (double)nlevels));
+    int sum = 0;
+    for (int level = 0; level < nlevels - 1; level++) {
+        quotas[level] = tbm::cv_round(nDesired);
+        sum += quotas[level];
+        nDesired *= sf[1];
+    }
+    quotas[nlevels - 1] = std::max(target - sum, 0);
+    return TB_OK;
+}
+
+/* ------------------------------------------------------------------ extractor plan */
+static void build_resize_tables(int sw, int sh, int dw, int dh, std::vector<ResizeX>& rx, std::vector<ResizeY>& ry) {
+    /* cv::resize INTER_LINEAR 8U coefficient set-up (OpenCV 3.3) */
+    const double inv_scale_x = (double)dw / sw, inv_scale_y = (double)dh / sh;
+    const double scale_x = 1. / inv_scale_x, scale_y = 1. / inv_scale_y;
+    rx.resize(dw);
+    ry.resize(dh);
+    for (int dx = 0; dx < dw; dx++) {
+        float fx = (float)((dx + 0.5) * scale_x - 0.5);
+        int sx = tbm::cv_floor(fx);
+        fx -= sx;
+        if (sx < 0) { fx = 0; sx = 0; }
+        if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+        rx[dx].sx = (int16_t)sx;
+        rx[dx].sx1 = (int16_t)std::min(sx + 1, sw - 1);
+        rx[dx].a0 = (int16_t)tbm::cv_round((1.f - fx) * 2048.f);
+        rx[dx].a1 = (int16_t)tbm::cv_round(fx * 2048.f);
+    }
+    for (int dy = 0; dy < dh; dy++) {
+        float fy = (float)((dy + 0.5) * scale_y - 0.5);
+        int sy = tbm::cv_floor(fy);
+        fy -= sy;
+        ry[dy].sy0 = std::min(std::max(sy, 0), sh - 1);
+        ry[dy].sy1 = std::min(std::max(sy + 1, 0), sh - 1);
+        ry[dy].b0 = (int16_t)tbm::cv_round((1.f - fy) * 2048.f);
+        ry[dy].b1 = (int16_t)tbm::cv_round(fy * 2048.f);
+    }
+}
+
+static int fastgrid_ncell(int width, int height, int target) {
+    const int cell = (int)sqrtf((float)width * (float)height / (float)target);
+    if (cell < 1) return 0;
+    const int cols = (int)((float)width / (float)cell), rows = (int)((float)height / (float)cell);
+    return std::max((rows + 2) * (cols + 1), target);
+}
+
+void tb_extractor_destroy(tb_extractor* ex) {
+    if (!ex) return;
+    hipSetDevice(ex->ctx->device);
+    hipStreamSynchronize(ex->ctx->stream);
+    hipFree(ex->d_slab); hipFree(ex->d_img0_copy); hipFree(ex->d_cells);
+    for (int l = 0; l < TB_MAX_LEVELS; l++) { hipFree(ex->d_rx[l]); hipFree(ex->d_ry[l]); }
+    hipFree(ex->d_cand); hipFree(ex->d_candCount); hipFree(ex->d_knode); hipFree(ex->d_sel); hipFree(ex->d_selCount);
+    hipFree(ex->d_kps); hipFree(ex->d_desc); hipFree(ex->d_counts); hipFree(ex->d_exit); hipFree(ex->d_enode);
+    hipFree(ex->d_gridBest); hipFree(ex->d_occ);
+    delete ex;
+}
+
+int tb_extractor_create(tb_ctx* ctx, int width, int height, int nlevels, const float* sf, const int* widths,
+                        const int* heights, int max_images, int max_target, tb_extractor** out) {
+    if (!ctx || !out) return TB_EINVAL;
+    *out = nullptr;
+    if (width < 1 || height < 1 || nlevels < 1 || nlevels > TB_MAX_LEVELS || !sf || max_images < 1 || max_target < 1)
+        return tb_fail(ctx, TB_EINVAL, "extractor_create: bad geometry %dx%d levels=%d images=%d target=%d", width, height,
+                       nlevels, max_images, max_target);
+    if (width > 4095 || height > 4095) return tb_fail(ctx, TB_EUNSUPPORTED, "images larger than 4095 px are not supported");
+    TB_HIP(ctx, hipSetDevice(ctx->device));
+    std::unique_ptr<tb_extractor> exu(new tb_extractor());
+    tb_extractor* ex = exu.get();
+    ex->ctx = ctx;
+    ex->max_images = max_images;
+    ex->max_target = max_target;
+    ex->sf.assign(sf, sf + nlevels);
+    for (int l = 0; l < TB_MAX_LEVELS; l++) { ex->d_rx[l] = nullptr; ex->d_ry[l] = nullptr; ex->quotas[l] = 0; }
+    PlanGeom& g = ex->g;
+    memset(&g, 0, sizeof g);
+    g.nlevels = nlevels;
+    g.width = width;
+    g.height = height;
+    std::vector<int> ws(nlevels), hs(nlevels);
+    if (widths && heights) {
+        for (int l = 0; l < nlevels; l++) { ws[l] = widths[l]; hs[l] = heights[l]; }
+        if (ws[0] != width || hs[0] != height) return tb_fail(ctx, TB_EINVAL, "level 0 size mismatch");
+    } else {
+        tb_pyramid_sizes(width, height, nlevels, sf, ws.data(), hs.data());
+    }
+    int maxq[TB_MAX_LEVELS] = {0};
+    if (nlevels >= 2) tb_orb_quotas(nlevels, sf, max_target, maxq);
+    std::vector<CellDesc> cells;
+    size_t off = 0, candOff = 0;
+    int selBase = 0;
+    for (int l = 0; l < nlevels; l++) {
+        LevelGeom& L = g.lv[l];
+        if (ws[l] < 1 || hs[l] < 1 || ws[l] > 4095 || hs[l] > 4095)
+            return tb_fail(ctx, TB_EINVAL, "level %d has size %dx%d", l, ws[l], hs[l]);
+        L.w = ws[l];
+        L.h = hs[l];
+        L.stride = (L.w + 63) & ~63;
+        L.off = off;
+        off += ((size_t)L.stride * L.h + 255) & ~(size_t)255;
+        L.sf = sf[l];
+        L.inv_sf = 1.f;
+        L.patchSize = (float)(int)(31 * sf[l]);
+        /* ComputeKeyPointsOctTree grid, ORBextractor.cpp:749-763 */
+        const int minB = TB_BORDER, maxBX = L.w - TB_BORDER, maxBY = L.h - TB_BORDER;
+        const float fw = (float)(maxBX - minB), fh = (float)(maxBY - minB);
+        L.nCols = (int)(fw / 30.f);
+        L.nRows = (int)(fh / 30.f);
+        L.cellBase = (int)cells.size();
+        L.nCells = 0;
+        L.nIni = 0;
+        L.hX = 1.f;
+        L.wCell = L.hCell = 1;
+        if (L.nCols >= 1 && L.nRows >= 1) {
+            L.wCell = (int)ceilf(fw / (float)L.nCols);
+            L.hCell = (int)ceilf(fh / (float)L.nRows);
+            for (int i = 0; i < L.nRows; i++) {
+                const float iniY = (float)minB + (float)i * (float)L.hCell;
+                float maxY = iniY + (float)L.hCell + 6.f;
+                if (iniY >= (float)maxBY - 3.f) continue;
+                if (maxY > (float)maxBY) maxY = (float)maxBY;
+                for (int j = 0; j < L.nCols; j++) {
+                    const float iniX = minB + (float)(j * L.wCell);
+                    float maxX = iniX + (float)L.wCell + 6.f;
+                    if (iniX >= (float)maxBX - 6.f) continue;
+                    if (maxX > (float)maxBX) maxX = (float)maxBX;
+                    CellDesc c;
+                    c.level = (int16_t)l; c.pad = 0;
+                    c.x0 = (int16_t)(int)iniX; c.y0 = (int16_t)(int)iniY;
+                    c.x1 = (int16_t)(int)maxX; c.y1 = (int16_t)(int)maxY;
+                    c.cellIdx = i * L.nCols + j;
+                    cells.push_back(c);
+                    L.nCells++;
+                }
+            }
+            /* DistributeOctTree, ORBextractor.cpp:498-500 (nIni < 1 clamped, see k_octree.hip) */
+            int nIni = (int)roundf((float)(maxBX - minB) / (maxBY - minB));
+            if (nIni < 1) nIni = 1;
+            L.nIni = nIni;
+            L.hX = (float)(maxBX - minB) / nIni;
+        }
+        L.candCap = ((L.w + 1) / 2) * ((L.h + 1) / 2) + 64;
+        L.candOff = candOff;
+        candOff += (size_t)L.candCap;
+        L.quota = maxq[l];
+        L.nodeCapAlloc = (L.nCells > 0) ? maxq[l] + 3 + 4 * L.nIni + 8 : 0;
+        L.nodeCap = L.nodeCapAlloc;
+        L.selBase = selBase;
+        selBase += L.nodeCapAlloc;
+    }
+    g.slabBytes = off;
+    g.candPerImage = candOff;
+    g.selCap = std::max(std::max(selBase, fastgrid_ncell(width, height, max_target)), 64);
+    ex->nCellsTotal = (int)cells.size();
+
+    const size_t B = (size_t)max_images;
+    TB_HIP(ctx, hipMalloc(&ex->d_slab, B * g.slabBytes));
+    TB_HIP(ctx, hipMemsetAsync(ex->d_slab, 0, B * g.slabBytes, ctx->stream));
+    if (!cells.empty()) {
+        TB_HIP(ctx, hipMalloc(&ex->d_cells, cells.size() * sizeof(CellDesc)));
+        TB_HIP(ctx, hipMemcpy(ex->d_cells, cells.data(), cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
+    }
+    for (int l = 1; l < nlevels; l++) {
+        std::vector<ResizeX> rx;
+        std::vector<ResizeY> ry;
+        build_resize_tables(ws[l - 1], hs[l - 1], ws[l], hs[l], rx, ry);
+        TB_HIP(ctx, hipMalloc(&ex->d_rx[l], rx.size() * sizeof(ResizeX)));
+        TB_HIP(ctx, hipMalloc(&ex->d_ry[l], ry.size() * sizeof(ResizeY)));
+        TB_HIP(ctx, hipMemcpy(ex->d_rx[l], rx.data(), rx.size() * sizeof(ResizeX), hipMemcpyHostToDevice));
+        TB_HIP(ctx, hipMemcpy(ex->d_ry[l], ry.data(), ry.size() * sizeof(ResizeY), hipMemcpyHostToDevice));
+    }
+    TB_HIP(ctx, hipMalloc(&ex->d_cand, B * g.candPerImage * sizeof(uint32_t)));
+    TB_HIP(ctx, hipMalloc(&ex->d_knode, B * g.candPerImage * sizeof(uint32_t)));
+    TB_HIP(ctx, hipMalloc(&ex->d_candCount, B * TB_MAX_LEVELS * sizeof(int32_t)));
+    TB_HIP(ctx, hipMalloc(&ex->d_selCount, B * TB_MAX_LEVELS * sizeof(int32_t)));
+    TB_HIP(ctx, hipMalloc(&ex->d_sel, B * g.selCap * sizeof(uint32_t)));
+    TB_HIP(ctx, hipMalloc(&ex->d_kps, B * g.selCap * sizeof(tb_keypoint)));
+    TB_HIP(ctx, hipMalloc(&ex->d_desc, B * g.selCap * 32));
+    TB_HIP(ctx, hipMalloc(&ex->d_counts, B * sizeof(int32_t)));
+    TB_HIP(ctx, hipMalloc(&ex->d_enode, 256));
+    TB_HIP(ctx, hipMalloc(&ex->d_exit, 256));
+    ex->enodeCap = 64;
+    ex->exitCap = 32;
+    TB_HIP(ctx, hipMemsetAsync(ex->d_counts, 0, B * sizeof(int32_t), ctx->stream));
+    TB_HIP(ctx, hipMemsetAsync(ex->d_selCount, 0, B * TB_MAX_LEVELS * sizeof(int32_t), ctx->stream));
+    TB_HIP(ctx, hipMemsetAsync(ex->d_candCount, 0, B * TB_MAX_LEVELS * sizeof(int32_t), ctx->stream));
+    /* level 0 defaults to the slab until frames are attached */
+    g.img0 = nullptr;
+    g.img0_pitch = 0;
+    g.img0_stride = 0;
+    *out = exu.release();
+    return TB_OK;
+}
+
+int tb_extractor_set_images_host(tb_extractor* ex, const uint8_t* images, int n, int stride, size_t pitch) {
+    if (!ex || !images || n < 1 || n > ex->max_images || stride < ex->g.width) return TB_EINVAL;
+    tb_ctx* ctx = ex->ctx;
+    const LevelGeom& L0 = ex->g.lv[0];
+    for (int b = 0; b < n; b++)
+        TB_HIP(ctx, hipMemcpy2DAsync(ex->d_slab + (size_t)b * ex->g.slabBytes + L0.off, L0.stride, images + (size_t)b * pitch,
+                                     stride, L0.w, L0.h, hipMemcpyHostToDevice, ctx->stream));
+    ex->g.img0 = nullptr; /* level 0 lives in the slab */
+    return TB_OK;
+}
+
+int tb_extractor_set_images_dev(tb_extractor* ex, const uint8_t* dev_images, int n, int stride, size_t pitch) {
+    if (!ex || !dev_images || n < 1 || n > ex->max_images || stride < ex->g.width) return TB_EINVAL;
+    ex->g.img0 = dev_images;
+    ex->g.img0_stride = stride;
+    ex->g.img0_pitch = pitch;
+    return TB_OK;
+}
+
+int tb_extractor_set_levels_host(tb_extractor* ex, int index, const uint8_t* const* levels, const int* strides) {
+    if (!ex || !levels || !strides || index < 0 || index >= ex->max_images) return TB_EINVAL;
+    tb_ctx* ctx = ex->ctx;
+    for (int l = 0; l < ex->g.nlevels; l++) {
+        const LevelGeom& L = ex->g.lv[l];
+        if (!levels[l] || strides[l] < L.w) return tb_fail(ctx, TB_EINVAL, "set_levels_host: level %d missing", l);
+        TB_HIP(ctx, hipMemcpy2DAsync(ex->d_slab + (size_t)index * ex->g.slabBytes + L.off, L.stride, levels[l], strides[l], L.w,
+                                     L.h, hipMemcpyHostToDevice, ctx->stream));
+    }
+    ex->g.img0 = nullptr;
+    return TB_OK;
+}
+
+int tb_extractor_build_pyramid(tb_extractor* ex, int n) {
+    if (!ex || n < 1 || n > ex->max_images) return TB_EINVAL;
+    for (int l = 1; l < ex->g.nlevels; l++) {
+        int rc = tbk_resize_level(ex, l, n);
+        if (rc) return rc;
+    }
+    return TB_OK;
+}
+
+int tb_extractor_get_level_host(tb_extractor* ex, int index, int level, uint8_t* out, int out_stride) {
+    if (!ex || !out || index < 0 || index >= ex->max_images || level < 0 || level >= ex->g.nlevels) return TB_EINVAL;
+    tb_ctx* ctx = ex->ctx;
+    const LevelGeom& L = ex->g.lv[level];
+    if (out_stride < L.w) return TB_EINVAL;
+    const uint8_t* src;
+    size_t sp;
+    if (level == 0 && ex->g.img0) { src = ex->g.img0 + (size_t)index * ex->g.img0_pitch; sp = ex->g.img0_stride; }
+    else { src = ex->d_slab + (size_t)index * ex->g.slabBytes + L.off; sp = L.stride; }
+    TB_HIP(ctx, hipMemcpy2DAsync(out, out_stride, src, sp, L.w, L.h, hipMemcpyDeviceToHost, ctx->stream));
+    TB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TB_OK;
+}
+
+int tb_extractor_orb(tb_extractor* ex, int n, int target, float init_th, float min_th, int quota_mode,
+                     const tb_keypoint* exit_keys, int n_exit) {
+    if (!ex || n < 1 || n > ex->max_images || target < 0 || n_exit < 0 || (n_exit > 0 && !exit_keys)) return TB_EINVAL;
+    tb_ctx* ctx = ex->ctx;
+    PlanGeom& g = ex->g;
+    if (quota_mode == 0) {
+        if (g.nlevels < 2) return tb_fail(ctx, TB_EUNSUPPORTED, "ORB extraction reads sf[1]: needs >= 2 levels");
+        if (target > ex->max_target) return tb_fail(ctx, TB_ECAPACITY, "target %d exceeds plan max_target %d", target, ex->max_target);
+        tb_orb_quotas(g.nlevels, ex->sf.data(), target, ex->quotas);
+        ex->have_quotas = true;
+    } else if (!ex->have_quotas) {
+        /* AddPoints before operator(): the reference indexes an empty mnFeaturesPerLevel (ORBextractor.cpp:810) */
+        return tb_fail(ctx, TB_ESTATE, "AddPoints-mode extraction before any operator()-mode call");
+    }
+    for (int l = 0; l < g.nlevels; l++) {
+        LevelGeom& L = g.lv[l];
+        L.quota = ex->quotas[l];
+        L.nodeCap = (L.nCells > 0) ? L.quota + 3 + 4 * L.nIni : 0;
+        if (L.nodeCap > L.nodeCapAlloc) return tb_fail(ctx, TB_ECAPACITY, "level %d quota %d exceeds the plan", l, L.quota);
+    }
+    /* cv::FAST clamps its threshold to [0,255]; (int) truncation as at ORBextractor.cpp:786,791 */
+    const int ith = std::min(std::max((int)init_th, 0), 255), mth = std::min(std::max((int)min_th, 0), 255);
+    if (n_exit > 0) {
+        if (n_exit > ex->exitCap) {
+            TB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            hipFree(ex->d_exit);
+            ex->d_exit = nullptr;
+            TB_HIP(ctx, hipMalloc(&ex->d_exit, (size_t)n_exit * 2 * sizeof(float)));
+            ex->exitCap = n_exit;
+        }
+        const size_t need = (size_t)n * g.nlevels * n_exit;
+        if (need > ex->enodeCap) {
+            TB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            hipFree(ex->d_enode);
+            ex->d_enode = nullptr;
+            TB_HIP(ctx, hipMalloc(&ex->d_enode, need * sizeof(int32_t)));
+            ex->enodeCap = need;
+        }
+        std::vector<float> xy((size_t)n_exit * 2);
+        for (int i = 0; i < n_exit; i++) { xy[2 * i] = exit_keys[i].x; xy[2 * i + 1] = exit_keys[i].y; }
+        TB_HIP(ctx, hipMemcpyAsync(ex->d_exit, xy.data(), xy.size() * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+        TB_HIP(ctx, hipStreamSynchronize(ctx->stream)); /* xy is a stack-lifetime staging buffer */
+    }
+    int rc = tbk_fast_cells(ex, n, ith, mth);
+    if (rc) return rc;
+    rc = tbk_octree(ex, n, n_exit);
+    if (rc) return rc;
+    rc = tbk_describe(ex, n);
+    if (rc) return rc;
+    ex->last_n = n;
+    ex->last_was_orb = true;
+    return TB_OK;
+}
+
+int tb_extractor_fastgrid(tb_extractor* ex, int n, const float* inv_sf, int target, float threshold,
+                          const uint8_t* occupancy, int n_occupancy) {
+    if (!ex || n < 1 || n > ex->max_images || !inv_sf || target < 1) return TB_EINVAL;
+    tb_ctx* ctx = ex->ctx;
+    for (int l = 0; l < ex->g.nlevels; l++) ex->g.lv[l].inv_sf = inv_sf[l];
+    int n_occ = 0;
+    if (occupancy && n_occupancy > 0) {
+        if ((size_t)n_occupancy > ex->occCap) {
+            TB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            hipFree(ex->d_occ);
+            ex->d_occ = nullptr;
+            TB_HIP(ctx, hipMalloc(&ex->d_occ, (size_t)n_occupancy));
+            ex->occCap = (size_t)n_occupancy;
+        }
+        TB_HIP(ctx, hipMemcpyAsync(ex->d_occ, occupancy, (size_t)n_occupancy, hipMemcpyHostToDevice, ctx->stream));
+        TB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        n_occ = n_occupancy;
+    }
+    int rc = tbk_fastgrid(ex, n, target, threshold, n_occ);
+    if (rc) return rc;
+    ex->last_n = n;
+    ex->last_was_orb = false;
+    return TB_OK;
+}
+
+int tb_extractor_counts_host(tb_extractor* ex, int n, int* counts) {
+    if (!ex || !counts || n < 1 || n > ex->max_images) return TB_EINVAL;
+    tb_ctx* ctx = ex->ctx;
+    TB_HIP(ctx, hipMemcpyAsync(counts, ex->d_counts, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    TB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TB_OK;
+}
+
+int tb_extractor_results_host(tb_extractor* ex, int index, tb_keypoint* kps, uint8_t* desc, int cap, int* count) {
+    if (!ex || !count || index < 0 || index >= ex->max_images) return TB_EINVAL;
+    tb_ctx* ctx = ex->ctx;
+    int32_t c = 0;
+    TB_HIP(ctx, hipMemcpyAsync(&c, ex->d_counts + index, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
+    TB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *count = c;
+    if (c > cap) return tb_fail(ctx, TB_ECAPACITY, "results: %d keypoints, capacity %d", c, cap);
+    if (c > 0 && kps)
+        TB_HIP(ctx, hipMemcpyAsync(kps, ex->d_kps + (size_t)index * ex->g.selCap, (size_t)c * sizeof(tb_keypoint),
+                                   hipMemcpyDeviceToHost, ctx->stream));
+    if (c > 0 && desc && ex->last_was_orb)
+        TB_HIP(ctx, hipMemcpyAsync(desc, ex->d_desc + (size_t)index * ex->g.selCap * 32, (size_t)c * 32, hipMemcpyDeviceToHost,
+                                   ctx->stream));
+    TB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TB_OK;
+}
+
+int tb_extractor_results_dev(tb_extractor* ex, const tb_keypoint** kps, const uint8_t** desc, const int32_t** counts,
+                             int* kp_capacity) {
+    if (!ex) return TB_EINVAL;
+    if (kps) *kps = ex->d_kps;
+    if (desc) *desc = ex->d_desc;
+    if (counts) *counts = ex->d_counts;
+    if (kp_capacity) *kp_capacity = ex->g.selCap;
+    return TB_OK;
+}
+
+int tb_extractor_candidates_host(tb_extractor* ex, int index, int level, tb_corner* out, int cap, int* count) {
+    if (!ex || !count || index < 0 || index >= ex->max_images || level < 0 || level >= ex->g.nlevels) return TB_EINVAL;
+    tb_ctx* ctx = ex->ctx;
+    const LevelGeom& L = ex->g.lv[level];
+    int32_t c = 0;
+    TB_HIP(ctx, hipMemcpyAsync(&c, ex->d_candCount + index * TB_MAX_LEVELS + level, sizeof c, hipMemcpyDeviceToHost, ctx->stream));
+    TB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (c > L.candCap) return tb_fail(ctx, TB_ECAPACITY, "candidate overflow on level %d", level);
+    *count = c;
+    if (c > cap) return tb_fail(ctx, TB_ECAPACITY, "candidates: %d, capacity %d", c, cap);
+    std::vector<uint32_t> rec((size_t)c);
+    if (c > 0) {
+        TB_HIP(ctx, hipMemcpyAsync(rec.data(), ex->d_cand + (size_t)index * ex->g.candPerImage + L.candOff, (size_t)c * 4,
+                                   hipMemcpyDeviceToHost, ctx->stream));
+        TB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    /* the kernel emits in arrival order; present them in the reference's order (cell-major raster) */
+    std::vector<std::pair<uint64_t, uint32_t>> keyed((size_t)c);
+    for (int i = 0; i < c; i++) {
+        const int x = rec[i] & 0xfff, y = (rec[i] >> 12) & 0xfff;
+        const int ci = (y - 3) / L.hCell, cj = (x - 3) / L.wCell;
+        keyed[i] = std::make_pair(((uint64_t)(ci * L.nCols + cj) << 24) | ((uint64_t)y << 12) | (uint64_t)x, rec[i]);
+    }
+    std::sort(keyed.begin(), keyed.end());
+    for (int i = 0; i < c; i++) {
+        out[i].x = keyed[i].second & 0xfff;
+        out[i].y = (keyed[i].second >> 12) & 0xfff;
+        out[i].score = keyed[i].second >> 24;
+    }
+    return TB_OK;
+}
+
+/* ------------------------------------------------------------------ single-frame operator forms */
+static int get_plan(tb_ctx* ctx, const char* tag, int nlevels, const float* sf, const int* ws, const int* hs, int max_target,
+                    tb_extractor** out) {
+    std::string key = tag;
+    char buf[64];
+    for (int l = 0; l < nlevels; l++) {
+        snprintf(buf, sizeof buf, ":%dx%d:%08x", ws[l], hs[l], *reinterpret_cast<const uint32_t*>(&sf[l]));
+        key += buf;
+    }
+    auto it = ctx->plans.find(key);
+    if (it != ctx->plans.end() && it->second->max_target >= max_target) { *out = it->second; return TB_OK; }
+    if (it != ctx->plans.end()) { tb_extractor_destroy(it->second); ctx->plans.erase(it); }
+    tb_extractor* ex = nullptr;
+    int rc = tb_extractor_create(ctx, ws[0], hs[0], nlevels, sf, ws, hs, 1, std::max(max_target, 2048), &ex);
+    if (rc) return rc;
+    ctx->plans[key] = ex;
+    *out = ex;
+    return TB_OK;
+}
+
+int tb_pyramid(tb_ctx* ctx, const uint8_t* image, int width, int height, int stride, int nlevels, const float* sf,
+               uint8_t* const* levels_out, const int* strides_out) {
+    if (!ctx || !image || !sf || !levels_out || !strides_out || nlevels < 1 || nlevels > TB_MAX_LEVELS) return TB_EINVAL;
+    std::vector<int> ws(nlevels), hs(nlevels);
+    tb_pyramid_sizes(width, height, nlevels, sf, ws.data(), hs.data());
+    tb_extractor* ex = nullptr;
+    int rc = get_plan(ctx, "pyr", nlevels, sf, ws.data(), hs.data(), 1, &ex);
+    if (rc) return rc;
+    rc = tb_extractor_set_images_host(ex, image, 1, stride, 0);
+    if (rc) return rc;
+    rc = tb_extractor_build_pyramid(ex, 1);
+    if (rc) return rc;
+    for (int l = 1; l < nlevels; l++) {
+        if (!levels_out[l]) continue;
+        rc = tb_extractor_get_level_host(ex, 0, l, levels_out[l], strides_out[l]);
+        if (rc) return rc;
+    }
+    return tb_synchronize(ctx);
+}
+
+int tb_fast_detect(tb_ctx* ctx, const uint8_t* image, int width, int height, int stride, int threshold, int nms,
+                   tb_corner* out, int cap, int* count) {
+    if (!ctx || !image || !count || width < 0 || height < 0 || width > 4095 || height > 4095) return TB_EINVAL;
+    *count = 0;
+    if (width < 7 || height < 7) return TB_OK;
+    threshold = std::min(std::max(threshold, 0), 255);
+    void *d_img, *d_out, *d_cnt;
+    const int rcap = (nms ? ((width + 1) / 2) * ((height + 1) / 2) : width * height) + 64;
+    int rc;
+    if ((rc = tb_scratch(ctx, 0, (size_t)width * height, &d_img))) return rc;
+    if ((rc = tb_scratch(ctx, 1, (size_t)rcap * 4, &d_out))) return rc;
+    if ((rc = tb_scratch(ctx, 2, 256, &d_cnt))) return rc;
+    TB_HIP(ctx, hipMemcpy2DAsync(d_img, width, image, stride, width, height, hipMemcpyHostToDevice, ctx->stream));
+    rc = tbk_fast_image(ctx, (const uint8_t*)d_img, width, height, width, threshold, nms, 9, (uint32_t*)d_out, rcap, (int32_t*)d_cnt);
+    if (rc) return rc;
+    int32_t c = 0;
+    TB_HIP(ctx, hipMemcpyAsync(&c, d_cnt, 4, hipMemcpyDeviceToHost, ctx->stream));
+    TB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *count = c;
+    if (c > cap || c > rcap) return tb_fail(ctx, TB_ECAPACITY, "fast_detect: %d corners, capacity %d", c, cap);
+    std::vector<uint32_t> rec((size_t)c);
+    if (c > 0) {
+        TB_HIP(ctx, hipMemcpy(rec.data(), d_out, (size_t)c * 4, hipMemcpyDeviceToHost));
+        /* raster order of cv::FAST: sort by (y, x) */
+        std::sort(rec.begin(), rec.end(), [](uint32_t a, uint32_t b) { return (a & 0xffffff) < (b & 0xffffff); });
+    }
+    for (int i = 0; i < c && out; i++) {
+        out[i].x = rec[i] & 0xfff;
+        out[i].y = (rec[i] >> 12) & 0xfff;
+        out[i].score = rec[i] >> 24;
+    }
+    return TB_OK;
+}
+
+int tb_orb_extract(tb_ctx* ctx, const uint8_t* const* levels, const int* widths, const int* heights, const int* strides,
+                   int nlevels, const float* sf, int target, float init_th, float min_th, const tb_keypoint* exit_keys,
+                   int n_exit, int use_quotas, int* quotas_inout, tb_keypoint* kps, uint8_t* desc, int cap, int* count) {
+    if (!ctx || !levels || !widths || !heights || !strides || !sf || !quotas_inout || !count || nlevels < 1 ||
+        nlevels > TB_MAX_LEVELS)
+        return TB_EINVAL;
+    *count = 0;
+    if (!levels[0] || widths[0] < 1 || heights[0] < 1) return TB_OK; /* images.at(0).empty(): silent return */
+    if (nlevels < 2) return tb_fail(ctx, TB_EUNSUPPORTED, "ORB extraction reads sf[1]: needs >= 2 levels");
+    int qsum = 0;
+    if (use_quotas) for (int l = 0; l < nlevels; l++) qsum += quotas_inout[l];
+    tb_extractor* ex = nullptr;
+    int rc = get_plan(ctx, "orb", nlevels, sf, widths, heights, std::max(target, qsum), &ex);
+    if (rc) return rc;
+    rc = tb_extractor_set_levels_host(ex, 0, levels, strides);
+    if (rc) return rc;
+    if (use_quotas) {
+        for (int l = 0; l < nlevels; l++) ex->quotas[l] = quotas_inout[l];
+        ex->have_quotas = true;
+    }
+    rc = tb_extractor_orb(ex, 1, target, init_th, min_th, use_quotas ? 1 : 0, exit_keys, n_exit);
+    if (rc) return rc;
+    if (!use_quotas) for (int l = 0; l < nlevels; l++) quotas_inout[l] = ex->quotas[l];
+    return tb_extractor_results_host(ex, 0, kps, desc, cap, count);
+}
+
+int tb_fastgrid_extract(tb_ctx* ctx, const uint8_t* const* levels, const int* widths, const int* heights, const int* strides,
+                        int nlevels, const float* inv_sf, int target, float threshold, const uint8_t* occupancy,
+                        int n_occupancy, tb_keypoint* kps, int cap, int* count) {
+    if (!ctx || !levels || !widths || !heights || !strides || !inv_sf || !count || nlevels < 1 || nlevels > TB_MAX_LEVELS ||
+        target < 1)
+        return TB_EINVAL;
+    *count = 0;
+    if (!levels[0] || widths[0] < 1 || heights[0] < 1) return TB_OK;
+    std::vector<float> sf(nlevels);
+    for (int l = 0; l < nlevels; l++) sf[l] = 1.f / inv_sf[l]; /* plan key + ORB fields only; unused by fastgrid */
+    tb_extractor* ex = nullptr;
+    int rc = get_plan(ctx, "fg", nlevels, sf.data(), widths, heights, target, &ex);
+    if (rc) return rc;
+    rc = tb_extractor_set_levels_host(ex, 0, levels, strides);
+    if (rc) return rc;
+    rc = tb_extractor_fastgrid(ex, 1, inv_sf, target, threshold, occupancy, n_occupancy);
+    if (rc) return rc;
+    return tb_extractor_results_host(ex, 0, kps, nullptr, cap, count);
+}
+
+/* ------------------------------------------------------------------ matchers */
+int tb_descriptor_distance(const uint8_t* a, const uint8_t* b) {
+    /* Matcher::DescriptorDistance, matcher.cpp:793-808: 256-bit Hamming distance */
+    int dist = 0;
+    for (int i = 0; i < 4; i++) {
+        uint64_t x, y;
+        memcpy(&x, a + 8 * i, 8);
+        memcpy(&y, b + 8 * i, 8);
+        dist += __builtin_popcountll(x ^ y);
+    }
+    return dist;
+}
+
+void tb_three_maxima(const int* sizes, int L, int* ind1, int* ind2, int* ind3) {
+    /* Matcher::ComputeThreeMaxima, matcher.cpp:810-851 (caller initialises the indices, :379) */
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = sizes[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; *ind3 = *ind2; *ind2 = *ind1; *ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; *ind3 = *ind2; *ind2 = i; }
+        else if (s > max3) { max3 = s; *ind3 = i; }
+    }
+    if ((float)max2 < 0.1f * (float)max1) { *ind2 = -1; *ind3 = -1; }
+    else if ((float)max3 < 0.1f * (float)max1) { *ind3 = -1; }
+}
+
+static int bf_host(tb_ctx* ctx, const uint8_t* d1, int n1, const uint8_t* d2, int n2, int crosscheck, int filter, float ratio,
+                   float min_th, tb_match* out, int cap, int* count) {
+    if (!ctx || !count || n1 < 0 || n2 < 0 || (n1 && !d1) || (n2 && !d2)) return TB_EINVAL;
+    *count = 0;
+    if (n1 == 0 || n2 == 0) return TB_OK;
+    const int max_n = std::max(n1, n2);
+    const size_t pitch = (size_t)max_n * 32;
+    void *dd1, *dd2, *tb, *qb, *dout, *dcnt;
+    int rc;
+    if ((rc = tb_scratch(ctx, 0, pitch, &dd1))) return rc;
+    if ((rc = tb_scratch(ctx, 1, pitch, &dd2))) return rc;
+    if ((rc = tb_scratch(ctx, 2, (size_t)max_n * 8, &tb))) return rc;
+    if ((rc = tb_scratch(ctx, 3, (size_t)max_n * 8, &qb))) return rc;
+    if ((rc = tb_scratch(ctx, 4, (size_t)n1 * sizeof(tb_match), &dout))) return rc;
+    if ((rc = tb_scratch(ctx, 5, 256, &dcnt))) return rc;
+    int32_t cnts[3] = {n1, n2, 0};
+    TB_HIP(ctx, hipMemcpyAsync(dd1, d1, (size_t)n1 * 32, hipMemcpyHostToDevice, ctx->stream));
+    TB_HIP(ctx, hipMemcpyAsync(dd2, d2, (size_t)n2 * 32, hipMemcpyHostToDevice, ctx->stream));
+    TB_HIP(ctx, hipMemcpyAsync(dcnt, cnts, sizeof cnts, hipMemcpyHostToDevice, ctx->stream));
+    TB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    rc = tbk_bf_batch(ctx, 1, (const uint8_t*)dd1, (const int32_t*)dcnt, (const uint8_t*)dd2, (const int32_t*)dcnt + 1, pitch,
+                      max_n, crosscheck, filter, ratio, min_th, (tb_match*)dout, n1, (int32_t*)dcnt + 2,
+                      (unsigned long long*)tb, (unsigned long long*)qb);
+    if (rc) return rc;
+    int32_t c = 0;
+    TB_HIP(ctx, hipMemcpyAsync(&c, (int32_t*)dcnt + 2, 4, hipMemcpyDeviceToHost, ctx->stream));
+    TB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *count = c;
+    if (c > cap) return tb_fail(ctx, TB_ECAPACITY, "matches: %d, capacity %d", c, cap);
+    if (c > 0 && out) TB_HIP(ctx, hipMemcpy(out, dout, (size_t)c * sizeof(tb_match), hipMemcpyDeviceToHost));
+    return TB_OK;
+}
+
+int tb_match_bf(tb_ctx* ctx, const uint8_t* d1, int n1, const uint8_t* d2, int n2, int crosscheck, tb_match* out, int cap,
+                int* count) {
+    return bf_host(ctx, d1, n1, d2, n2, crosscheck, 0, 0.f, 0.f, out, cap, count);
+}
+
+int tb_search_by_bf(tb_ctx* ctx, const uint8_t* d1, int n1, const uint8_t* d2, int n2, float ratio, float min_th,
+                    tb_match* out, int cap, int* count) {
+    return bf_host(ctx, d1, n1, d2, n2, 1, 1, ratio, min_th, out, cap, count);
+}
+
+int tb_search_by_bf_batch_dev(tb_ctx* ctx, int npairs, const uint8_t* desc1, const int32_t* counts1, const uint8_t* desc2,
+                              const int32_t* counts2, size_t set_pitch, float ratio, float min_th, tb_match* out, int cap,
+                              int32_t* out_counts) {
+    if (!ctx || npairs < 0 || !desc1 || !desc2 || !counts1 || !counts2 || !out || !out_counts || set_pitch < 32 || cap < 1)
+        return TB_EINVAL;
+    if (npairs == 0) return TB_OK;
+    const int max_n = (int)(set_pitch / 32);
+    void *tb, *qb;
+    int rc;
+    if ((rc = tb_scratch(ctx, 2, (size_t)npairs * max_n * 8, &tb))) return rc;
+    if ((rc = tb_scratch(ctx, 3, (size_t)npairs * max_n * 8, &qb))) return rc;
+    return tbk_bf_batch(ctx, npairs, desc1, counts1, desc2, counts2, set_pitch, max_n, 1, 1, ratio, min_th, out, cap, out_counts,
+                        (unsigned long long*)tb, (unsigned long long*)qb);
+}
+
+int tb_search_by_violence(tb_ctx* ctx, const tb_keypoint* k1, const uint8_t* d1, int n1, const tb_keypoint* k2,
+                          const uint8_t* d2, int n2, int img2_width, int img2_height, int min_level, int max_level,
+                          float radius, int th_low, float nratio, int histo_len, int check_orientation, tb_match* out,
+                          int cap, int* count) {
+    if (!ctx || !count || n1 < 0 || n2 < 0 || histo_len < 1 || img2_width < 1 || img2_height < 1) return TB_EINVAL;
+    *count = 0;
+    if (n1 == 0) return TB_OK;
+    if ((n1 && (!k1 || !d1)) || (n2 && (!k2 || !d2))) return TB_EINVAL;
+    const int GRID_ROWS = 36, GRID_COLS = 120;
+    /* Frame.cpp:30-31: the two inverse factors are swapped in the reference; kept */
+    const float heightInv = (float)GRID_COLS / (float)img2_width;
+    const float widthInv = (float)GRID_ROWS / (float)img2_height;
+    /* Frame::AssignFeaturesToGrid as CSR (insertion order inside a cell = key index order) */
+    std::vector<int32_t> cellOf((size_t)n2), start((size_t)GRID_COLS * GRID_ROWS + 1, 0), items((size_t)std::max(n2, 1));
+    for (int i = 0; i < n2; i++) {
+        const int posX = (int)roundf(k2[i].x * widthInv), posY = (int)roundf(k2[i].y * heightInv);
+        cellOf[i] = (posX < 0 || posX >= GRID_COLS || posY < 0 || posY >= GRID_ROWS) ? -1 : posX * GRID_ROWS + posY;
+        if (cellOf[i] >= 0) start[cellOf[i] + 1]++;
+    }
+    for (size_t c = 0; c < (size_t)GRID_COLS * GRID_ROWS; c++) start[c + 1] += start[c];
+    {
+        std::vector<int32_t> fill(start.begin(), start.end() - 1);
+        for (int i = 0; i < n2; i++)
+            if (cellOf[i] >= 0) items[fill[cellOf[i]]++] = i;
+    }
+    void *dk1, *dd1, *dk2, *dd2, *dst, *dit, *dbest;
+    int rc;
+    if ((rc = tb_scratch(ctx, 0, (size_t)n1 * 32, &dd1))) return rc;
+    if ((rc = tb_scratch(ctx, 1, (size_t)std::max(n2, 1) * 32, &dd2))) return rc;
+    if ((rc = tb_scratch(ctx, 2, (size_t)n1 * sizeof(tb_keypoint), &dk1))) return rc;
+    if ((rc = tb_scratch(ctx, 3, (size_t)std::max(n2, 1) * sizeof(tb_keypoint), &dk2))) return rc;
+    if ((rc = tb_scratch(ctx, 4, start.size() * 4, &dst))) return rc;
+    if ((rc = tb_scratch(ctx, 5, items.size() * 4, &dit))) return rc;
+    if ((rc = tb_scratch(ctx, 6, (size_t)n1 * 16, &dbest))) return rc;
+    TB_HIP(ctx, hipMemcpyAsync(dd1, d1, (size_t)n1 * 32, hipMemcpyHostToDevice, ctx->stream));
+    TB_HIP(ctx, hipMemcpyAsync(dk1, k1, (size_t)n1 * sizeof(tb_keypoint), hipMemcpyHostToDevice, ctx->stream));
+    if (n2 > 0) {
+        TB_HIP(ctx, hipMemcpyAsync(dd2, d2, (size_t)n2 * 32, hipMemcpyHostToDevice, ctx->stream));
+        TB_HIP(ctx, hipMemcpyAsync(dk2, k2, (size_t)n2 * sizeof(tb_keypoint), hipMemcpyHostToDevice, ctx->stream));
+    }
+    TB_HIP(ctx, hipMemcpyAsync(dst, start.data(), start.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    TB_HIP(ctx, hipMemcpyAsync(dit, items.data(), items.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+    TB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    rc = tbk_window_match(ctx, (const tb_keypoint*)dk1, (const uint8_t*)dd1, n1, (const tb_keypoint*)dk2, (const uint8_t*)dd2, n2,
+                          (const int32_t*)dst, (const int32_t*)dit, widthInv, heightInv, min_level, max_level, radius,
+                          (int32_t*)dbest);
+    if (rc) return rc;
+    std::vector<int32_t> best((size_t)n1 * 4);
+    TB_HIP(ctx, hipMemcpyAsync(best.data(), dbest, best.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    TB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    /* acceptance + rotation histogram, matcher.cpp:352-392 (bookkeeping over <= n1 survivors) */
+    std::vector<tb_match> matches;
+    std::vector<std::vector<int>> rotHist((size_t)histo_len);
+    const float factor = 1.f / (float)histo_len;
+    for (int i1 = 0; i1 < n1; i1++) {
+        const int bestDist = best[4 * i1], bestDist2 = best[4 * i1 + 1], bestIdx = best[4 * i1 + 2];
+        if (best[4 * i1 + 3] == 0) continue;
+        if (bestDist <= th_low && (float)bestDist < (float)bestDist2 * nratio) {
+            tb_match m = {i1, bestIdx, -1, (float)bestDist};
+            matches.push_back(m);
+            if (check_orientation) {
+                float rot = k1[i1].angle - k2[bestIdx].angle;
+                if (rot < 0) rot += 360.f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == histo_len) bin = 0;
+                if (bin < 0 || bin >= histo_len) return tb_fail(ctx, TB_EUNSUPPORTED, "rotation bin %d outside histogram (reference asserts)", bin);
+                rotHist[bin].push_back((int)matches.size() - 1);
+            }
+        }
+    }
+    std::vector<tb_match> good;
+    if (check_orientation) {
+        std::vector<int> sizes((size_t)histo_len);
+        for (int i = 0; i < histo_len; i++) sizes[i] = (int)rotHist[i].size();
+        int ind[3] = {-1, -1, -1};
+        tb_three_maxima(sizes.data(), histo_len, &ind[0], &ind[1], &ind[2]);
+        for (int i = 0; i < histo_len; i++)
+            if (i == ind[0] || i == ind[1] || i == ind[2])
+                for (int item : rotHist[i]) good.push_back(matches[item]);
+    } else {
+        good.swap(matches);
+    }
+    *count = (int)good.size();
+    if ((int)good.size() > cap) return tb_fail(ctx, TB_ECAPACITY, "matches: %d, capacity %d", (int)good.size(), cap);
+    if (out) std::copy(good.begin(), good.end(), out);
+    return TB_OK;
+}
+
+/* ------------------------------------------------------------------ pose optimisation / local BA */
+int tb_pose_opt_batch_dev(tb_ctx* ctx, int nproblems, const double K[4], const float* Tcw_in, const tb_obs* obs,
+                          const int32_t* counts, int obs_pitch, uint8_t* outlier, float* Tcw_out, int32_t* n_inliers,
+                          double* stats) {
+    if (!ctx || nproblems < 0 || !K || !Tcw_in || !obs || !counts || !outlier || !Tcw_out || !n_inliers || obs_pitch < 1)
+        return TB_EINVAL;
+    void* derr;
+    int rc = tb_scratch(ctx, 7, (size_t)nproblems * obs_pitch * 3 * sizeof(double), &derr);
+    if (rc) return rc;
+    return tbk_pose_batch(ctx, nproblems, K, Tcw_in, obs, counts, obs_pitch, outlier, Tcw_out, n_inliers, stats, (double*)derr);
+}
+
+int tb_pose_opt(tb_ctx* ctx, const double K[4], const float Tcw_in[16], const tb_obs* obs, int n, uint8_t* outlier,
+                float Tcw_out[16], int* n_inliers, double* stats) {
+    if (!ctx || !K || !Tcw_in || !Tcw_out || !n_inliers || n < 0 || (n && (!obs || !outlier))) return TB_EINVAL;
+    const int pitch = std::max(n, 1);
+    void *dobs, *dmisc, *dout;
+    int rc;
+    if ((rc = tb_scratch(ctx, 0, (size_t)pitch * sizeof(tb_obs), &dobs))) return rc;
+    if ((rc = tb_scratch(ctx, 1, (size_t)pitch, &dout))) return rc;
+    if ((rc = tb_scratch(ctx, 2, 512, &dmisc))) return rc;
+    /* dmisc: Tin[16] f32 | Tout[16] f32 | count i32 | ninl i32 | stats[8] f64 (at byte 192) */
+    float* dTin = (float*)dmisc;
+    float* dTout = dTin + 16;
+    int32_t* dcnt = (int32_t*)(dTout + 16);
+    int32_t* dninl = dcnt + 1;
+    double* dstats = (double*)((char*)dmisc + 192);
+    int32_t cnt = n;
+    if (n > 0) {
+        TB_HIP(ctx, hipMemcpyAsync(dobs, obs, (size_t)n * sizeof(tb_obs), hipMemcpyHostToDevice, ctx->stream));
+        TB_HIP(ctx, hipMemcpyAsync(dout, outlier, (size_t)n, hipMemcpyHostToDevice, ctx->stream));
+    }
+    TB_HIP(ctx, hipMemcpyAsync(dTin, Tcw_in, 64, hipMemcpyHostToDevice, ctx->stream));
+    TB_HIP(ctx, hipMemcpyAsync(dcnt, &cnt, 4, hipMemcpyHostToDevice, ctx->stream));
+    TB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    rc = tb_pose_opt_batch_dev(ctx, 1, K, dTin, (const tb_obs*)dobs, dcnt, pitch, (uint8_t*)dout, dTout, dninl, dstats);
+    if (rc) return rc;
+    int32_t ninl = 0;
+    TB_HIP(ctx, hipMemcpyAsync(Tcw_out, dTout, 64, hipMemcpyDeviceToHost, ctx->stream));
+    TB_HIP(ctx, hipMemcpyAsync(&ninl, dninl, 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (n > 0) TB_HIP(ctx, hipMemcpyAsync(outlier, dout, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+    if (stats) TB_HIP(ctx, hipMemcpyAsync(stats, dstats, 64, hipMemcpyDeviceToHost, ctx->stream));
+    TB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *n_inliers = ninl;
+    return TB_OK;
+}
+
+int tb_local_ba(tb_ctx* ctx, const double K[4], int nkf, int nfixed, float* poses, int npt, float* pts, const tb_ba_obs* obs,
+                int nobs, int iters, double* stats) {
+    if (!ctx || !K || !poses || !pts || !obs || nkf < 1 || npt < 1 || nobs < 1 || nfixed < 0 || nfixed > nkf || iters < 0)
+        return TB_EINVAL;
+    for (int e = 0; e < nobs; e++)
+        if (obs[e].kf < 0 || obs[e].kf >= nkf || obs[e].pt < 0 || obs[e].pt >= npt) return tb_fail(ctx, TB_EINVAL, "local_ba: observation %d out of range", e);
+    void *dposes, *dpts, *dobs, *dstats, *dwork;
+    int rc;
+    const size_t wb = tbk_local_ba_work_bytes(nkf, nfixed, npt, nobs);
+    if ((rc = tb_scratch(ctx, 0, (size_t)nkf * 64, &dposes))) return rc;
+    if ((rc = tb_scratch(ctx, 1, (size_t)npt * 12, &dpts))) return rc;
+    if ((rc = tb_scratch(ctx, 2, (size_t)nobs * sizeof(tb_ba_obs), &dobs))) return rc;
+    if ((rc = tb_scratch(ctx, 3, 256, &dstats))) return rc;
+    if ((rc = tb_scratch(ctx, 4, wb, &dwork))) return rc;
+    TB_HIP(ctx, hipMemcpyAsync(dposes, poses, (size_t)nkf * 64, hipMemcpyHostToDevice, ctx->stream));
+    TB_HIP(ctx, hipMemcpyAsync(dpts, pts, (size_t)npt * 12, hipMemcpyHostToDevice, ctx->stream));
+    TB_HIP(ctx, hipMemcpyAsync(dobs, obs, (size_t)nobs * sizeof(tb_ba_obs), hipMemcpyHostToDevice, ctx->stream));
+    TB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    rc = tbk_local_ba(ctx, K, nkf, nfixed, (float*)dposes, npt, (float*)dpts, (const tb_ba_obs*)dobs, nobs, iters, (double*)dstats,
+                      dwork, wb);
+    if (rc) return rc;
+    TB_HIP(ctx, hipMemcpyAsync(poses, dposes, (size_t)nkf * 64, hipMemcpyDeviceToHost, ctx->stream));
+    TB_HIP(ctx, hipMemcpyAsync(pts, dpts, (size_t)npt * 12, hipMemcpyDeviceToHost, ctx->stream));
+    if (stats) TB_HIP(ctx, hipMemcpyAsync(stats, dstats, 64, hipMemcpyDeviceToHost, ctx->stream));
+    TB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,139 @@
+/* Internal declarations of libtb_hip.so (not part of the C ABI). */
+#ifndef TB_INTERNAL_H
+#define TB_INTERNAL_H
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/tb_capi.h"
+
+#define TB_MAX_LEVELS 16
+#define TB_BORDER 16          /* EDGE_THRESHOLD - 3, ORBextractor.cpp:749 */
+#define TB_NODE_CAP_MAX 2048  /* quadtree list capacity that fits LDS (k_octree.hip) */
+
+struct tb_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    std::string err;
+    std::map<std::string, tb_extractor*> plans; /* cached single-frame plans */
+    /* grow-only device scratch for the matcher / pose entry points */
+    void* scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+};
+
+int tb_fail(tb_ctx* ctx, int code, const char* fmt, ...);
+int tb_scratch(tb_ctx* ctx, int slot, size_t bytes, void** out);
+
+#define TB_HIP(ctx, call)                                                                     \
+    do {                                                                                      \
+        hipError_t e_ = (call);                                                               \
+        if (e_ != hipSuccess)                                                                 \
+            return tb_fail((ctx), TB_EDEVICE, "%s: %s (%s:%d)", #call, hipGetErrorString(e_), \
+                           __FILE__, __LINE__);                                               \
+    } while (0)
+
+/* Geometry of one pyramid level inside a plan (host and device copies are identical). */
+struct LevelGeom {
+    int w, h, stride;     /* stride of the slab copy of this level */
+    int nCols, nRows;     /* 30-px cell grid, ORBextractor.cpp:757-763 */
+    int wCell, hCell;
+    int cellBase;         /* index of this level's first entry in the cell table */
+    int nCells;           /* valid (not skipped) cells of this level */
+    int candCap;          /* capacity of the per-image candidate array of this level */
+    int nodeCap;          /* quadtree list capacity = quota + 3 + 4*nIni (this call) */
+    int nodeCapAlloc;     /* slots reserved for this level in the selection array */
+    int nIni;             /* DistributeOctTree initial nodes, ORBextractor.cpp:498 */
+    int quota;            /* mnFeaturesPerLevel[level] of the current call */
+    int selBase;          /* first slot of this level in the per-image selection array */
+    float hX;             /* (maxX-minX)/nIni as float, ORBextractor.cpp:500 */
+    float patchSize;      /* (float)(int)(31*sf[level]), ORBextractor.cpp:812 */
+    float sf;             /* mvScaleFactor[level] */
+    float inv_sf;         /* FASTExtractor scale argument (fastgrid only) */
+    unsigned long long off;     /* byte offset of the level inside one image's slab */
+    unsigned long long candOff; /* element offset of the level inside one image's candidate array */
+};
+
+struct PlanGeom {
+    int nlevels;
+    int width, height;
+    int selCap;                      /* slots per image in the selection / result arrays */
+    unsigned long long slabBytes;    /* bytes per image slab */
+    unsigned long long candPerImage; /* candidate records per image */
+    /* level-0 source: external frames (dev pointer) or the slab */
+    const uint8_t* img0;
+    unsigned long long img0_pitch;
+    int img0_stride;
+    int pad_;
+    LevelGeom lv[TB_MAX_LEVELS];
+};
+
+/* One FAST work item: a region of one level whose pixels are scored and non-max suppressed. */
+struct CellDesc {
+    int16_t level;
+    int16_t pad;
+    int16_t x0, y0, x1, y1; /* ROI in absolute level coordinates, [x0,x1) x [y0,y1) */
+    int32_t cellIdx;        /* row-major index in the level's grid (ordering key) */
+};
+
+/* resize tables, built on the host with the oracle-identical double/float arithmetic */
+struct ResizeX { int16_t sx, sx1, a0, a1; };
+struct ResizeY { int32_t sy0, sy1; int16_t b0, b1; };
+
+struct tb_extractor {
+    tb_ctx* ctx = nullptr;
+    PlanGeom g;                /* host copy; img0* fields updated per call */
+    int max_images = 0, max_target = 0;
+    std::vector<float> sf;
+    bool have_quotas = false;
+    int quotas[TB_MAX_LEVELS];
+    int last_n = 0;
+    bool last_was_orb = false;
+    /* device memory */
+    uint8_t* d_slab = nullptr;          /* [max_images][slabBytes] */
+    uint8_t* d_img0_copy = nullptr;     /* [max_images][h][stride0] for host-provided frames */
+    CellDesc* d_cells = nullptr; int nCellsTotal = 0;
+    ResizeX* d_rx[TB_MAX_LEVELS]; ResizeY* d_ry[TB_MAX_LEVELS];
+    uint32_t* d_cand = nullptr;         /* [max_images][candPerImage] packed score<<24|y<<12|x */
+    int32_t* d_candCount = nullptr;     /* [max_images][TB_MAX_LEVELS] */
+    uint32_t* d_knode = nullptr;        /* [max_images][candPerImage] quadtree scratch */
+    uint32_t* d_sel = nullptr;          /* [max_images][selCap] selected keypoints, packed */
+    int32_t* d_selCount = nullptr;      /* [max_images][TB_MAX_LEVELS] */
+    tb_keypoint* d_kps = nullptr;       /* [max_images][selCap] */
+    uint8_t* d_desc = nullptr;          /* [max_images][selCap][32] */
+    int32_t* d_counts = nullptr;        /* [max_images] */
+    float* d_exit = nullptr; int exitCap = 0;   /* exit keys (x,y) */
+    int32_t* d_enode = nullptr; size_t enodeCap = 0;
+    /* fastgrid scratch */
+    unsigned long long* d_gridBest = nullptr; size_t gridBestCap = 0;
+    uint8_t* d_occ = nullptr; size_t occCap = 0;
+};
+
+/* kernel launchers (k_*.hip) */
+int tbk_resize_level(tb_extractor* ex, int level, int n);
+int tbk_fast_cells(tb_extractor* ex, int n, int init_th, int min_th);
+int tbk_octree(tb_extractor* ex, int n, int n_exit);
+int tbk_describe(tb_extractor* ex, int n);
+int tbk_fast_image(tb_ctx* ctx, const uint8_t* d_img, int w, int h, int stride, int th, int nms, int arc,
+                   uint32_t* d_out, int cap, int32_t* d_count);
+int tbk_fastgrid(tb_extractor* ex, int n, int target, float threshold, int n_occ);
+int tbk_bf_batch(tb_ctx* ctx, int npairs, const uint8_t* d1, const int32_t* c1, const uint8_t* d2,
+                 const int32_t* c2, size_t set_pitch, int max_n, int crosscheck, int filter, float ratio,
+                 float min_th, tb_match* out, int cap, int32_t* out_counts, unsigned long long* d_tbest,
+                 unsigned long long* d_qbest);
+int tbk_window_match(tb_ctx* ctx, const tb_keypoint* d_k1, const uint8_t* d_d1, int n1, const tb_keypoint* d_k2,
+                     const uint8_t* d_d2, int n2, const int32_t* d_cellStart, const int32_t* d_cellItems,
+                     float widthInv, float heightInv, int min_level, int max_level, float r,
+                     int32_t* d_best /* n1 x 4: bestDist, bestDist2, bestIdx, #candidates */);
+int tbk_pose_batch(tb_ctx* ctx, int nproblems, const double K[4], const float* Tcw_in, const tb_obs* obs,
+                   const int32_t* counts, int obs_pitch, uint8_t* outlier, float* Tcw_out, int32_t* n_inliers,
+                   double* stats, double* d_err);
+int tbk_local_ba(tb_ctx* ctx, const double K[4], int nkf, int nfixed, float* d_poses, int npt, float* d_pts,
+                 const tb_ba_obs* d_obs, int nobs, int iters, double* d_stats, void* d_work, size_t work_bytes);
+size_t tbk_local_ba_work_bytes(int nkf, int nfixed, int npt, int nobs);
+
+#endif
