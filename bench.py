@@ -1,0 +1,186 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec end-to-end of the tracking hot path on N MI355X (driver contract).
+
+Workload (BASELINE.json configs[2], the one `metric` / north_star is quoted on): 1280x720 stereo frames,
+8-level pyramid x 0.8, 2000 ORB keypoints per image (FAST 80/30), searchByBF left<->right (ratio 10,
+minTh 30), motion-only pose optimisation per frame, and one 10-keyframe / 5000-point local BA window per
+frame.  One "step" = one pass of the path over a resident batch of F stereo frames per GPU; inputs are
+synthetic (trackingbench_slam_amd/synth.py) and already in HBM when the timed region starts.
+
+N > 1: launched by torch.distributed.run, one rank per GPU; frames shard across ranks with no data-path
+collective (weak scaling); the per-batch track records are gathered to rank 0 over RCCL inside the step.
+Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+from trackingbench_slam_amd import dist as tbd  # noqa: E402
+from trackingbench_slam_amd import synth  # noqa: E402
+from trackingbench_slam_amd.pipeline import KITTI_K, TrackingPipeline  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured achievable
+
+
+def level_pixels(w, h, nlevels, scale):
+    sf = np.float32(1.0)
+    px = []
+    for i in range(nlevels):
+        if i:
+            sf = np.float32(sf * np.float32(scale))
+        px.append((w if i == 0 else int(np.float32(w) * sf)) * (h if i == 0 else int(np.float32(h) * sf)))
+    return px
+
+
+def algorithmic_bytes(kernel, w, h, nlevels, scale, target, nimg, npairs):
+    """SURVEY.md 8(d) per-unit algorithmic bytes x units of one step (see DESIGN.md 'Roofline accounting')."""
+    px = level_pixels(w, h, nlevels, scale)
+    spx = sum(px)
+    per_img = {
+        "k_resize": sum(px[l - 1] + px[l] for l in range(1, nlevels)),          # pyramid row
+        "k_fast_cells": spx,                                                    # FAST detect row: 1 read / px
+        "k_describe": 2 * spx + target * 2 * 961 + target * 60,                 # blur + orient/describe rows (fused)
+        "k_octree": 0,                                                          # not HBM-bound (no 8d row)
+    }
+    if kernel in per_img:
+        return per_img[kernel] * nimg
+    if kernel == "k_bf_nn":
+        return 2 * target * 32 * npairs                                         # (N1+N2)*32 B per pair
+    return 0
+
+
+def cpu_baseline(args, seconds=20.0):
+    """CPU restatement of the reference path (oracle/, kind "port", 1 thread) on a bounded sample of the same
+    workload: whole stereo frames end to end until ~`seconds` of CPU time."""
+    import oracle
+    done, t0 = 0, time.perf_counter()
+    K = KITTI_K
+    while True:
+        L, R = synth.frame(done % 8, args.width, args.height, stereo=True)
+        lvL, sf = oracle.pyramid(L, args.levels, args.scale)
+        lvR, _ = oracle.pyramid(R, args.levels, args.scale)
+        k1, d1, _ = oracle.orb_extract(lvL, sf, args.target, args.init_th, args.min_th)
+        k2, d2, _ = oracle.orb_extract(lvR, sf, args.target, args.init_th, args.min_th)
+        m = oracle.search_by_bf(d1, d2, 10.0, 30.0)
+        _, Ti, obs = synth.pose_problem(done, max(len(m), 3), K)
+        oracle.pose_opt(K, Ti, obs)
+        if not args.no_ba:
+            Pt, Pi, Xt, Xi, bo = synth.ba_problem(done, args.ba_kf, args.ba_pts, K)
+            oracle.local_ba(K, Pi, 2, Xi, bo, args.ba_iters)
+        done += 1
+        el = time.perf_counter() - t0
+        if el >= seconds or done >= 64:
+            break
+    return {"value": done / el, "unit": "frames/s", "cores": 1, "kind": "port",
+            "sample": "%d stereo frames end-to-end (synthetic %dx%d, same stages) in %.1f s on 1 host thread; "
+                      "synthetic-frame generation included" % (done, args.width, args.height, el)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--frames", type=int, default=32, help="stereo frames per GPU per step")
+    ap.add_argument("--width", type=int, default=1280)
+    ap.add_argument("--height", type=int, default=720)
+    ap.add_argument("--levels", type=int, default=8)
+    ap.add_argument("--scale", type=float, default=0.8)
+    ap.add_argument("--target", type=int, default=2000)
+    ap.add_argument("--init-th", type=float, default=80.0)
+    ap.add_argument("--min-th", type=float, default=30.0)
+    ap.add_argument("--ba-kf", type=int, default=10)
+    ap.add_argument("--ba-pts", type=int, default=5000)
+    ap.add_argument("--ba-iters", type=int, default=10)
+    ap.add_argument("--no-ba", action="store_true", help="diagnostic only: drop the local-BA stage")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic stereo pairs tiled over the batch")
+    args = ap.parse_args()
+
+    rank, world, local = tbd.init_from_env("nccl")
+    if world != args.gpus:
+        if rank == 0:
+            print("warning: --gpus %d but WORLD_SIZE %d" % (args.gpus, world), file=sys.stderr)
+    dev = local if world > 1 else 0
+    torch.cuda.set_device(dev)
+
+    pipe = TrackingPipeline(args.width, args.height, args.levels, args.scale, args.target, args.init_th, args.min_th,
+                            frames=args.frames, device=dev, with_ba=not args.no_ba, ba_kf=args.ba_kf, ba_pts=args.ba_pts,
+                            ba_iters=args.ba_iters, seed=rank)
+    pipe.set_synthetic(distinct=args.distinct, first=rank * args.frames)
+
+    def one_step():
+        pipe.step()
+        if world > 1:
+            tbd.gather_tracks(tbd.pipeline_records(pipe), dst=0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    fence()
+    pipe.ctx.profile_enable(True)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        one_step()
+    fence()
+    el = time.perf_counter() - t0
+    prof = pipe.ctx.profile_report()
+    pipe.ctx.profile_enable(False)
+    t = torch.tensor([el], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    el = float(t.item())
+
+    if rank == 0:
+        frames_total = args.frames * world * args.steps
+        nimg, npairs = 2 * args.frames, args.frames
+        # dominant kernel of the timed region (HIP events on the kernels' stream, tb_profile_*)
+        dom = max(prof.items(), key=lambda kv: kv[1][1]) if prof else (None, (0, 0.0))
+        name, (calls, tot_ms) = dom
+        abytes = algorithmic_bytes(name, args.width, args.height, args.levels, args.scale, args.target, nimg, npairs)
+        launches_per_step = max(calls // max(args.steps, 1), 1)
+        avg_ms_per_step = tot_ms / max(args.steps, 1)
+        achieved = (abytes / 1e9) / (avg_ms_per_step / 1e3) if avg_ms_per_step > 0 else 0.0
+        roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                    "launches_per_step": launches_per_step, "avg_launch_ms": round(tot_ms / max(calls, 1), 5),
+                    "algorithmic_bytes_per_step": abytes,
+                    "kernels_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items())}}
+        out = {
+            "metric": "frames/sec end-to-end (extract+match+local-BA)", "value": round(frames_total / el, 2),
+            "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(1e3 * el / args.steps, 3), "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "u8 (pyramid/FAST/ORB/Hamming) + f64 (pose-opt/BA)", "data": "synthetic",
+            "config": {"workload": "%dx%d stereo, %d-level pyramid x%.1f, %d kpts/image (FAST %g/%g), searchByBF L<->R, "
+                                   "pose-opt%s" % (args.width, args.height, args.levels, args.scale, args.target,
+                                                   args.init_th, args.min_th,
+                                                   "" if args.no_ba else ", %d-KF/%d-pt local BA x%d iters" %
+                                                   (args.ba_kf, args.ba_pts, args.ba_iters)),
+                       "frames_per_gpu_per_step": args.frames, "distinct_synthetic_pairs": min(args.distinct, args.frames),
+                       "parallelism": "frames sharded x%d, RCCL gather of tracks" % world},
+            "roofline": roofline,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args, args.cpu_seconds)
+        print(json.dumps(out))
+    pipe.close()
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

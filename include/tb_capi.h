@@ -33,6 +33,11 @@ const char* tb_version(void);
 /* Run everything on an existing HIP stream (e.g. torch's current stream); NULL = the context's own. */
 int tb_set_stream(tb_ctx* ctx, void* hip_stream);
 int tb_synchronize(tb_ctx* ctx);
+/* Per-kernel timing with HIP events on the context's stream (measurement aid for bench.py: the roofline
+ * figure needs the dominant kernel's average launch duration over the timed region). enable(1) resets the
+ * accumulators; report() synchronises and writes one line per kernel: "name calls total_ms\n". */
+int tb_profile_enable(tb_ctx* ctx, int on);
+int tb_profile_report(tb_ctx* ctx, char* buf, int cap);
 
 /* ---------------------------------------------------------------- a1/a2/a3: host-side scalar set-up
  * Frame::Frame scale vectors (src/types/Frame.cpp:18-29), Frame::ComputePyramid sizes (:423-424),
@@ -74,6 +79,10 @@ int tb_extractor_results_host(tb_extractor* ex, int index, tb_keypoint* kps, uin
  * descriptors [max_images][kp_capacity][32], counts [max_images]. */
 int tb_extractor_results_dev(tb_extractor* ex, const tb_keypoint** kps, const uint8_t** desc,
                              const int32_t** counts, int* kp_capacity);
+/* Copy the results of frames [0,n) into caller-owned device buffers (e.g. torch tensors that feed the
+ * RCCL gather): kps [n][cap], desc [n][cap][32], counts [n]; cap >= the plan's kp_capacity is not required,
+ * rows beyond cap are dropped (counts are clamped). Asynchronous on the context's stream. */
+int tb_extractor_copy_results_dev(tb_extractor* ex, int n, tb_keypoint* kps, uint8_t* desc, int32_t* counts, int cap);
 /* Stage probes for parity tests: FAST candidates of one level after the cell loop (a4). */
 int tb_extractor_candidates_host(tb_extractor* ex, int index, int level, tb_corner* out, int cap, int* count);
 

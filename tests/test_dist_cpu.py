@@ -1,0 +1,68 @@
+"""CPU tests of the multi-process path: world_size-2 gloo gather of track records and frame sharding."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ.update(RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank), MASTER_ADDR="127.0.0.1",
+                      MASTER_PORT=str(port))
+    from trackingbench_slam_amd import dist as tbd
+    r, w, _ = tbd.init_from_env("gloo")
+    F, cap = 3, 5
+    lo, hi = tbd.shard_range(2 * F, w, r)
+    rec = {
+        "kps": torch.arange(F * cap * 7, dtype=torch.float32).reshape(F, cap, 7) + 1000 * r,
+        "desc": (torch.arange(F * cap * 32) % 251).to(torch.uint8).reshape(F, cap, 32) + r,
+        "kp_counts": torch.tensor([lo, lo + 1, lo + 2], dtype=torch.int32),
+        "pose": torch.full((F, 16), float(r)),
+    }
+    out = tbd.gather_tracks(rec, dst=0)
+    if r == 0:
+        ok = out["kps"].shape == (w * F, cap, 7) and torch.equal(out["kps"][F:], rec["kps"] + 1000) \
+            and torch.equal(out["desc"][F:], rec["desc"] + 1) \
+            and out["kp_counts"].tolist() == [0, 1, 2, 3, 4, 5] and out["pose"][F:].eq(1).all().item()
+        q.put(bool(ok))
+    else:
+        q.put(out is None)
+    torch.distributed.destroy_process_group()
+
+
+def test_gather_tracks_gloo_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    assert res == [True, True]
+
+
+def test_shard_range_partitions():
+    from trackingbench_slam_amd import dist as tbd
+    for total in (0, 1, 7, 64, 65):
+        for world in (1, 2, 3, 8):
+            spans = [tbd.shard_range(total, world, r) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == total
+            assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+            sizes = [hi - lo for lo, hi in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert tbd.gather_tracks({"a": torch.zeros(2)})["a"].shape == (2,)

@@ -25,11 +25,12 @@ TB_OK, TB_EINVAL, TB_ENOMEM, TB_ECAPACITY, TB_EUNSUPPORTED, TB_EDEVICE, TB_ESTAT
 # every symbol include/tb_capi.h declares (checked by tests/test_capi_exports.py)
 EXPORTS = [
     "tb_create", "tb_destroy", "tb_last_error", "tb_strerror", "tb_version", "tb_set_stream", "tb_synchronize",
+    "tb_profile_enable", "tb_profile_report",
     "tb_scale_factors", "tb_pyramid_sizes", "tb_orb_quotas",
     "tb_extractor_create", "tb_extractor_destroy", "tb_extractor_set_images_host", "tb_extractor_set_images_dev",
     "tb_extractor_set_levels_host", "tb_extractor_build_pyramid", "tb_extractor_get_level_host", "tb_extractor_orb",
     "tb_extractor_fastgrid", "tb_extractor_counts_host", "tb_extractor_results_host", "tb_extractor_results_dev",
-    "tb_extractor_candidates_host",
+    "tb_extractor_candidates_host", "tb_extractor_copy_results_dev",
     "tb_pyramid", "tb_fast_detect", "tb_orb_extract", "tb_fastgrid_extract",
     "tb_descriptor_distance", "tb_three_maxima", "tb_match_bf", "tb_search_by_bf", "tb_search_by_bf_batch_dev",
     "tb_search_by_violence", "tb_pose_opt", "tb_pose_opt_batch_dev", "tb_local_ba",
@@ -149,6 +150,19 @@ class Context:
 
     def synchronize(self):
         self.check(lib().tb_synchronize(self._h))
+
+    def profile_enable(self, on=True):
+        self.check(lib().tb_profile_enable(self._h, int(on)))
+
+    def profile_report(self):
+        """{kernel name: (calls, total_ms)} accumulated since profile_enable(True)."""
+        buf = C.create_string_buffer(8192)
+        self.check(lib().tb_profile_report(self._h, buf, len(buf)))
+        out = {}
+        for line in buf.value.decode().splitlines():
+            name, calls, ms = line.split()
+            out[name] = (int(calls), float(ms))
+        return out
 
     # ---- single-frame operator forms
     def pyramid(self, img, nlevels, scale):
@@ -280,9 +294,10 @@ class Extractor:
         self._keep = None
 
     def close(self):
-        if self._h:
+        # tb_destroy() releases every plan of its context; only destroy while the context is alive
+        if self._h and self.ctx._h:
             lib().tb_extractor_destroy(self._h)
-            self._h = C.c_void_p()
+        self._h = C.c_void_p()
 
     def __del__(self):
         try:
@@ -338,6 +353,10 @@ class Extractor:
         kps, desc, counts, cap = C.c_void_p(), C.c_void_p(), C.c_void_p(), C.c_int(0)
         self.ctx.check(lib().tb_extractor_results_dev(self._h, C.byref(kps), C.byref(desc), C.byref(counts), C.byref(cap)))
         return kps.value, desc.value, counts.value, cap.value
+
+    def copy_results_dev(self, n, kps_ptr, desc_ptr, counts_ptr, cap):
+        self.ctx.check(lib().tb_extractor_copy_results_dev(self._h, int(n), C.c_void_p(kps_ptr), C.c_void_p(desc_ptr),
+                                                           C.c_void_p(counts_ptr), int(cap)))
 
     def candidates(self, index, level):
         cap = int(self.ws[level]) * int(self.hs[level]) // 4 + 4096

@@ -149,8 +149,10 @@ k_describe(PlanGeom g, const uint8_t* __restrict__ slab, const uint32_t* __restr
 int tbk_describe(tb_extractor* ex, int n) {
     tb_ctx* ctx = ex->ctx;
     dim3 grid(ex->g.selCap, n);
+    tb_prof_begin(ctx, "k_describe");
     hipLaunchKernelGGL(k_describe, grid, dim3(64), 0, ctx->stream, ex->g, ex->d_slab, ex->d_sel, ex->d_selCount,
                        ex->d_kps, ex->d_desc, ex->d_counts);
+    tb_prof_end(ctx);
     TB_HIP(ctx, hipGetLastError());
     return TB_OK;
 }

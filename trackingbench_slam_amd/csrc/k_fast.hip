@@ -201,8 +201,10 @@ int tbk_fast_cells(tb_extractor* ex, int n, int init_th, int min_th) {
     TB_HIP(ctx, hipMemsetAsync(ex->d_candCount, 0, sizeof(int32_t) * TB_MAX_LEVELS * n, ctx->stream));
     if (ex->nCellsTotal == 0) return TB_OK;
     dim3 grid(ex->nCellsTotal, n);
+    tb_prof_begin(ctx, "k_fast_cells");
     hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, ctx->stream, ex->g, ex->d_slab, ex->d_cells, ex->d_cand,
                        ex->d_candCount, init_th, min_th);
+    tb_prof_end(ctx);
     TB_HIP(ctx, hipGetLastError());
     return TB_OK;
 }
@@ -230,12 +232,14 @@ int tbk_fast_image(tb_ctx* ctx, const uint8_t* d_img, int w, int h, int stride, 
     TB_HIP(ctx, hipMemsetAsync(d_count, 0, sizeof(int32_t), ctx->stream));
     if (w < 7 || h < 7) return TB_OK;
     dim3 grid((w - 6 + FT_OUT - 1) / FT_OUT, (h - 6 + FT_OUT - 1) / FT_OUT, 1);
+    tb_prof_begin(ctx, "k_fast_image");
     if (arc == 9)
         hipLaunchKernelGGL(k_fast_image<9>, grid, dim3(256), 0, ctx->stream, d_img, w, h, stride, (size_t)0, th, nms,
                            d_out, cap, (size_t)0, d_count, 0);
     else
         hipLaunchKernelGGL(k_fast_image<10>, grid, dim3(256), 0, ctx->stream, d_img, w, h, stride, (size_t)0, th, nms,
                            d_out, cap, (size_t)0, d_count, 0);
+    tb_prof_end(ctx);
     TB_HIP(ctx, hipGetLastError());
     return TB_OK;
 }
@@ -265,7 +269,7 @@ __device__ __forceinline__ float ft_shi_tomasi(const uint8_t* img, int w, int h,
     dXY = TB_FDIV(dXY, 128.f);
     const float tr = TB_FADD(dXX, dYY);
     const float disc = TB_FSUB(TB_FMUL(tr, tr), TB_FMUL(4.f, TB_FSUB(TB_FMUL(dXX, dYY), TB_FMUL(dXY, dXY))));
-    return TB_FMUL(0.5f, TB_FSUB(tr, __fsqrt_rn(disc)));
+    return TB_FMUL(0.5f, TB_FSUB(tr, sqrtf(disc)));
 }
 
 __global__ void __launch_bounds__(256)
@@ -359,16 +363,22 @@ int tbk_fastgrid(tb_extractor* ex, int n, int target, float threshold, int n_occ
         int stride;
         if (l == 0 && g.img0) { base = g.img0; pitch = g.img0_pitch; stride = g.img0_stride; }
         else { base = ex->d_slab + L.off; pitch = g.slabBytes; stride = L.stride; }
+        tb_prof_begin(ctx, "k_fast_image");
         hipLaunchKernelGGL(k_fast_image<10>, grid, dim3(256), 0, ctx->stream, base, L.w, L.h, stride, pitch, 20, 1,
                            ex->d_cand + L.candOff, L.candCap, (size_t)g.candPerImage, ex->d_candCount + l, TB_MAX_LEVELS);
+        tb_prof_end(ctx);
         TB_HIP(ctx, hipGetLastError());
         dim3 bgrid((L.candCap + 255) / 256, n);
+        tb_prof_begin(ctx, "k_fastgrid_bid");
         hipLaunchKernelGGL(k_fastgrid_bid, bgrid, dim3(256), 0, ctx->stream, g, ex->d_slab, ex->d_cand, ex->d_candCount, l,
                            cell_size, grid_cols, ncell, n_occ > 0 ? ex->d_occ : nullptr, n_occ, ex->d_gridBest);
+        tb_prof_end(ctx);
         TB_HIP(ctx, hipGetLastError());
     }
+    tb_prof_begin(ctx, "k_fastgrid_emit");
     hipLaunchKernelGGL(k_fastgrid_emit, dim3(n), dim3(256), 0, ctx->stream, g, ex->d_gridBest, ncell, threshold, ex->d_kps,
                        ex->d_counts);
+    tb_prof_end(ctx);
     TB_HIP(ctx, hipGetLastError());
     return TB_OK;
 }

@@ -120,18 +120,26 @@ int tbk_bf_batch(tb_ctx* ctx, int npairs, const uint8_t* d1, const int32_t* c1, 
     if (crosscheck) {
         TB_HIP(ctx, hipMemsetAsync(d_tbest, 0xff, bytes, ctx->stream));
         /* rows = train (d2), cols = query (d1) */
+        tb_prof_begin(ctx, "k_bf_nn");
         hipLaunchKernelGGL(k_bf_nn, grid, dim3(BF_T), 0, ctx->stream, d2, c2, d1, c1, set_pitch, max_n, d_tbest);
+        tb_prof_end(ctx);
         TB_HIP(ctx, hipGetLastError());
+        tb_prof_begin(ctx, "k_bf_cross");
         hipLaunchKernelGGL(k_bf_cross, dim3((max_n + BF_T - 1) / BF_T, npairs), dim3(BF_T), 0, ctx->stream, c2, max_n, d_tbest,
                            d_qbest);
+        tb_prof_end(ctx);
         TB_HIP(ctx, hipGetLastError());
     } else {
         /* rows = query, cols = train: qbest[q] = (dist, nearest train) directly */
+        tb_prof_begin(ctx, "k_bf_nn");
         hipLaunchKernelGGL(k_bf_nn, grid, dim3(BF_T), 0, ctx->stream, d1, c1, d2, c2, set_pitch, max_n, d_qbest);
+        tb_prof_end(ctx);
         TB_HIP(ctx, hipGetLastError());
     }
+    tb_prof_begin(ctx, "k_bf_finalize");
     hipLaunchKernelGGL(k_bf_finalize, dim3(npairs), dim3(BF_T), 0, ctx->stream, c1, max_n, d_qbest, filter, ratio, min_th, out,
                        cap, out_counts);
+    tb_prof_end(ctx);
     TB_HIP(ctx, hipGetLastError());
     return TB_OK;
 }
@@ -184,8 +192,10 @@ int tbk_window_match(tb_ctx* ctx, const tb_keypoint* d_k1, const uint8_t* d_d1, 
                      const uint8_t* d_d2, int n2, const int32_t* d_cellStart, const int32_t* d_cellItems, float widthInv,
                      float heightInv, int min_level, int max_level, float r, int32_t* d_best) {
     if (n1 <= 0) return TB_OK;
+    tb_prof_begin(ctx, "k_window");
     hipLaunchKernelGGL(k_window, dim3((n1 + 255) / 256), dim3(256), 0, ctx->stream, d_k1, d_d1, n1, d_k2, d_d2, d_cellStart,
                        d_cellItems, widthInv, heightInv, min_level, max_level, r, d_best);
+    tb_prof_end(ctx);
     TB_HIP(ctx, hipGetLastError());
     return TB_OK;
 }

@@ -400,8 +400,10 @@ int tbk_octree(tb_extractor* ex, int n, int n_exit) {
         attr_set = true;
     }
     dim3 grid(ex->g.nlevels, n);
+    tb_prof_begin(ctx, "k_octree");
     hipLaunchKernelGGL(k_octree, grid, dim3(OT_T), lds, ctx->stream, ex->g, ex->d_cand, ex->d_candCount, ex->d_knode,
                        ex->d_exit, n_exit, ex->d_enode, ex->d_sel, ex->d_selCount, capMax);
+    tb_prof_end(ctx);
     TB_HIP(ctx, hipGetLastError());
     return TB_OK;
 }

@@ -359,8 +359,10 @@ int tbk_pose_batch(tb_ctx* ctx, int nproblems, const double K[4], const float* T
                    const int32_t* counts, int obs_pitch, uint8_t* outlier, float* Tcw_out, int32_t* n_inliers,
                    double* stats, double* d_err) {
     if (nproblems <= 0) return TB_OK;
+    tb_prof_begin(ctx, "k_pose");
     hipLaunchKernelGGL(k_pose, dim3(nproblems), dim3(PO_T), 0, ctx->stream, nproblems, K[0], K[1], K[2], K[3], Tcw_in, obs,
                        counts, obs_pitch, outlier, Tcw_out, n_inliers, stats, d_err);
+    tb_prof_end(ctx);
     TB_HIP(ctx, hipGetLastError());
     return TB_OK;
 }

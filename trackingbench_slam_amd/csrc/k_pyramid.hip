@@ -48,11 +48,14 @@ k_resize(PlanGeom g, uint8_t* __restrict__ slab, const ResizeX* __restrict__ rx,
 }
 
 int tbk_resize_level(tb_extractor* ex, int level, int n) {
+    tb_ctx* ctx = ex->ctx;
     const LevelGeom& D = ex->g.lv[level];
     const int groups = (D.stride >> 2) * D.h;
     dim3 grid((groups + 255) / 256, n);
+    tb_prof_begin(ctx, "k_resize");
     hipLaunchKernelGGL(k_resize, grid, dim3(256), 0, ex->ctx->stream, ex->g, ex->d_slab, ex->d_rx[level],
                        ex->d_ry[level], level);
+    tb_prof_end(ctx);
     TB_HIP(ex->ctx, hipGetLastError());
     return TB_OK;
 }

@@ -41,7 +41,63 @@ int tb_scratch(tb_ctx* ctx, int slot, size_t bytes, void** out) {
     return TB_OK;
 }
 
+static hipEvent_t prof_event(tb_ctx* ctx) {
+    if (!ctx->prof_pool.empty()) { hipEvent_t e = ctx->prof_pool.back(); ctx->prof_pool.pop_back(); return e; }
+    hipEvent_t e = nullptr;
+    hipEventCreate(&e);
+    return e;
+}
+void tb_prof_begin(tb_ctx* ctx, const char* name) {
+    if (!ctx->prof) return;
+    tb_ctx::ProfRec r;
+    r.name = name;
+    r.a = prof_event(ctx);
+    r.b = prof_event(ctx);
+    hipEventRecord(r.a, ctx->stream);
+    ctx->prof_recs.push_back(r);
+}
+void tb_prof_end(tb_ctx* ctx) {
+    if (!ctx->prof || ctx->prof_recs.empty()) return;
+    hipEventRecord(ctx->prof_recs.back().b, ctx->stream);
+}
+static void prof_drain(tb_ctx* ctx) {
+    hipStreamSynchronize(ctx->stream);
+    for (auto& r : ctx->prof_recs) {
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, r.a, r.b) == hipSuccess) {
+            auto& acc = ctx->prof_acc[r.name];
+            acc.first += 1;
+            acc.second += ms;
+        }
+        ctx->prof_pool.push_back(r.a);
+        ctx->prof_pool.push_back(r.b);
+    }
+    ctx->prof_recs.clear();
+}
+
 extern "C" {
+
+int tb_profile_enable(tb_ctx* ctx, int on) {
+    if (!ctx) return TB_EINVAL;
+    prof_drain(ctx);
+    ctx->prof_acc.clear();
+    ctx->prof = on != 0;
+    return TB_OK;
+}
+
+int tb_profile_report(tb_ctx* ctx, char* buf, int cap) {
+    if (!ctx || !buf || cap < 1) return TB_EINVAL;
+    prof_drain(ctx);
+    std::string out;
+    char line[256];
+    for (auto& kv : ctx->prof_acc) {
+        snprintf(line, sizeof line, "%s %ld %.6f\n", kv.first.c_str(), kv.second.first, kv.second.second);
+        out += line;
+    }
+    if ((int)out.size() + 1 > cap) return tb_fail(ctx, TB_ECAPACITY, "profile report needs %d bytes", (int)out.size() + 1);
+    memcpy(buf, out.c_str(), out.size() + 1);
+    return TB_OK;
+}
 
 const char* tb_version(void) { return "trackingbench-slam_amd 0.1 (gfx950)"; }
 
@@ -81,10 +137,12 @@ void tb_destroy(tb_ctx* ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     hipStreamSynchronize(ctx->stream);
-    for (auto& kv : ctx->plans) tb_extractor_destroy(kv.second);
     ctx->plans.clear();
+    while (!ctx->live.empty()) tb_extractor_destroy(*ctx->live.begin()); /* plans never outlive their context */
     for (int i = 0; i < 8; i++)
         if (ctx->scratch[i]) hipFree(ctx->scratch[i]);
+    prof_drain(ctx);
+    for (hipEvent_t e : ctx->prof_pool) hipEventDestroy(e);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
     delete ctx;
 }
@@ -184,6 +242,9 @@ static int fastgrid_ncell(int width, int height, int target) {
 
 void tb_extractor_destroy(tb_extractor* ex) {
     if (!ex) return;
+    ex->ctx->live.erase(ex);
+    for (auto it = ex->ctx->plans.begin(); it != ex->ctx->plans.end();)
+        it = (it->second == ex) ? ex->ctx->plans.erase(it) : std::next(it);
     hipSetDevice(ex->ctx->device);
     hipStreamSynchronize(ex->ctx->stream);
     hipFree(ex->d_slab); hipFree(ex->d_img0_copy); hipFree(ex->d_cells);
@@ -326,6 +387,7 @@ int tb_extractor_create(tb_ctx* ctx, int width, int height, int nlevels, const f
     g.img0 = nullptr;
     g.img0_pitch = 0;
     g.img0_stride = 0;
+    ctx->live.insert(ex);
     *out = exu.release();
     return TB_OK;
 }
@@ -500,6 +562,33 @@ int tb_extractor_results_dev(tb_extractor* ex, const tb_keypoint** kps, const ui
     return TB_OK;
 }
 
+__global__ void k_copy_results(const tb_keypoint* __restrict__ skp, const uint8_t* __restrict__ sdesc,
+                               const int32_t* __restrict__ scnt, int selCap, tb_keypoint* __restrict__ dkp,
+                               uint8_t* __restrict__ ddesc, int32_t* __restrict__ dcnt, int cap) {
+    const int b = blockIdx.y;
+    const int c = min(scnt[b], cap);
+    if (blockIdx.x == 0 && threadIdx.x == 0) dcnt[b] = c;
+    /* 60 bytes per keypoint row: 7 dwords of tb_keypoint + 8 dwords of descriptor */
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= c * 15) return;
+    const int row = i / 15, w = i - row * 15;
+    if (w < 7) reinterpret_cast<uint32_t*>(dkp + (size_t)b * cap + row)[w] = reinterpret_cast<const uint32_t*>(skp + (size_t)b * selCap + row)[w];
+    else reinterpret_cast<uint32_t*>(ddesc + ((size_t)b * cap + row) * 32)[w - 7] =
+             reinterpret_cast<const uint32_t*>(sdesc + ((size_t)b * selCap + row) * 32)[w - 7];
+}
+
+int tb_extractor_copy_results_dev(tb_extractor* ex, int n, tb_keypoint* kps, uint8_t* desc, int32_t* counts, int cap) {
+    if (!ex || n < 1 || n > ex->max_images || !kps || !desc || !counts || cap < 1) return TB_EINVAL;
+    tb_ctx* ctx = ex->ctx;
+    const int rows = std::min(cap, ex->g.selCap);
+    tb_prof_begin(ctx, "k_copy_results");
+    hipLaunchKernelGGL(k_copy_results, dim3((rows * 15 + 255) / 256, n), dim3(256), 0, ctx->stream, ex->d_kps, ex->d_desc,
+                       ex->d_counts, ex->g.selCap, kps, desc, counts, cap);
+    tb_prof_end(ctx);
+    TB_HIP(ctx, hipGetLastError());
+    return TB_OK;
+}
+
 int tb_extractor_candidates_host(tb_extractor* ex, int index, int level, tb_corner* out, int cap, int* count) {
     if (!ex || !count || index < 0 || index >= ex->max_images || level < 0 || level >= ex->g.nlevels) return TB_EINVAL;
     tb_ctx* ctx = ex->ctx;
@@ -543,7 +632,7 @@ static int get_plan(tb_ctx* ctx, const char* tag, int nlevels, const float* sf, 
     }
     auto it = ctx->plans.find(key);
     if (it != ctx->plans.end() && it->second->max_target >= max_target) { *out = it->second; return TB_OK; }
-    if (it != ctx->plans.end()) { tb_extractor_destroy(it->second); ctx->plans.erase(it); }
+    if (it != ctx->plans.end()) tb_extractor_destroy(it->second); /* also drops the cache entry */
     tb_extractor* ex = nullptr;
     int rc = tb_extractor_create(ctx, ws[0], hs[0], nlevels, sf, ws, hs, 1, std::max(max_target, 2048), &ex);
     if (rc) return rc;

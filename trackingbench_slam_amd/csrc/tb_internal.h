@@ -6,6 +6,7 @@
 #include <stdint.h>
 #include <stdio.h>
 #include <map>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -21,12 +22,21 @@ struct tb_ctx {
     hipStream_t stream = nullptr;
     std::string err;
     std::map<std::string, tb_extractor*> plans; /* cached single-frame plans */
+    std::set<tb_extractor*> live;               /* every plan created on this context */
+    /* per-kernel HIP-event timing (tb_profile_*) */
+    bool prof = false;
+    struct ProfRec { const char* name; hipEvent_t a, b; };
+    std::vector<ProfRec> prof_recs;
+    std::vector<hipEvent_t> prof_pool;
+    std::map<std::string, std::pair<long, double>> prof_acc;
     /* grow-only device scratch for the matcher / pose entry points */
     void* scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t scratch_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 int tb_fail(tb_ctx* ctx, int code, const char* fmt, ...);
+void tb_prof_begin(tb_ctx* ctx, const char* name);
+void tb_prof_end(tb_ctx* ctx);
 int tb_scratch(tb_ctx* ctx, int slot, size_t bytes, void** out);
 
 #define TB_HIP(ctx, call)                                                                     \

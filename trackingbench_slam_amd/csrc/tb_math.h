@@ -22,6 +22,12 @@
 #define TB_HD inline
 #endif
 
+/* The __f*_rn / __d*_rn intrinsics of ROCm 7.2 are plain operators (no rounding-mode variants are
+ * built in), so contraction must be off for the whole translation unit, not only through them. */
+#if defined(__clang__)
+#pragma clang fp contract(off)
+#endif
+
 namespace tbm {
 
 #if defined(__HIP_DEVICE_COMPILE__)

@@ -1,0 +1,67 @@
+"""Multi-GPU sharding of the tracking hot path: one process per GPU, frames shard embarrassingly
+ -- no collective inside the data path -- and ONE exchange step at the end of a batch: the
+per-frame track records (keypoints, descriptors, matches, pose) are gathered to rank 0 over RCCL
+(`torch.distributed` backend "nccl" on ROCm) or gloo (CPU tests).
+
+The reference has no distributed code at all; this module is the MI355X-side design.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def shard_range(total, world_size, rank):
+    """Contiguous block of frame indices [lo, hi) owned by `rank` (B/ngpu frames each, remainder spread)."""
+    base, rem = divmod(int(total), int(world_size))
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def init_from_env(backend=None):
+    """Initialise torch.distributed from RANK / WORLD_SIZE / MASTER_* (torchrun contract). Returns
+    (rank, world_size, local_rank). Single-process runs need no initialisation."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def gather_tracks(records, dst=0, group=None):
+    """Gather fixed-shape per-rank track tensors to `dst`.
+
+    records: dict name -> tensor [F_local, ...] (same shape and dtype on every rank: rows are padded to the
+    plan's keypoint capacity, the true lengths travel in the *_counts tensors).  Returns on `dst` a dict
+    name -> tensor [world * F_local, ...] in rank order (= global frame order for contiguous shards), and
+    None elsewhere.  With one process it returns the records unchanged."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return dict(records)
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    out = {} if rank == dst else None
+    for name in sorted(records):
+        t = records[name].contiguous()
+        if rank == dst:
+            parts = [torch.empty_like(t) for _ in range(world)]
+            dist.gather(t, gather_list=parts, dst=dst, group=group)
+            out[name] = torch.cat(parts, 0)
+        else:
+            dist.gather(t, gather_list=None, dst=dst, group=group)
+    return out
+
+
+def pipeline_records(p):
+    """The track records of a TrackingPipeline batch as a dict of device tensors."""
+    return {
+        "kps": p.trk_kps, "desc": p.trk_desc, "kp_counts": p.trk_counts,
+        "matches": p.matches, "match_counts": p.match_counts,
+        "pose": p.Tout, "n_inliers": p.n_inliers,
+    }

@@ -1,0 +1,113 @@
+"""Host-side driver of the batched tracking hot path on one GPU.
+
+One `TrackingPipeline.step()` = one pass of the path over a resident batch of F stereo frames:
+
+    pyramid (2F images) -> ORB extract (2F) -> searchByBF left<->right (F pairs) ->
+    motion-only pose optimisation (F problems) -> [multi-keyframe local BA, F windows] -> track records
+
+Everything stays in HBM between stages; torch supplies device memory, the stream and (in dist.py) the
+RCCL gather.  All compute goes through the C ABI of libtb_hip.so -- there is no torch or CPU fallback.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi, synth
+
+KITTI_K = (718.856, 718.856, 607.1928, 185.2157)  # hard-coded in the reference, LocalBA.cpp:356-359
+
+
+class TrackingPipeline:
+    def __init__(self, width=1280, height=720, nlevels=8, scale=0.8, target=2000, init_th=80.0, min_th=30.0,
+                 frames=16, bf_ratio=10.0, bf_min_th=30.0, device=0, with_ba=True, ba_kf=10, ba_pts=5000, ba_iters=10,
+                 seed=0):
+        self.dev = torch.device("cuda", device)
+        torch.cuda.set_device(self.dev)
+        self.F = int(frames)
+        self.width, self.height, self.nlevels, self.scale = width, height, nlevels, scale
+        self.target, self.init_th, self.min_th = target, init_th, min_th
+        self.bf_ratio, self.bf_min_th = bf_ratio, bf_min_th
+        self.ctx = capi.Context(device, stream=torch.cuda.current_stream(self.dev).cuda_stream)
+        self.ex = capi.Extractor(self.ctx, width, height, nlevels, scale, 2 * self.F, target)
+        self.kps_ptr, self.desc_ptr, self.counts_ptr, self.kp_cap = self.ex.results_dev()
+        F, cap = self.F, self.kp_cap
+        self.images = None
+        # matcher outputs
+        self.matches = torch.zeros((F, cap, 4), dtype=torch.int32, device=self.dev)  # tb_match records
+        self.match_counts = torch.zeros(F, dtype=torch.int32, device=self.dev)
+        # pose-opt inputs: one seeded synthetic problem per frame, the first #matches rows are used
+        self.K = np.ascontiguousarray(KITTI_K, np.float64)
+        self.obs_pitch = cap
+        obs = np.zeros((F, cap), capi.OBS)
+        Tin = np.zeros((F, 16), np.float32)
+        for f in range(F):
+            _, Ti, o = synth.pose_problem(seed * 1000 + f, cap, KITTI_K)
+            obs[f] = o
+            Tin[f] = Ti.reshape(16)
+        self.obs = torch.from_numpy(obs.view(np.float32).reshape(F, cap, 6)).to(self.dev)
+        self.Tin = torch.from_numpy(Tin).to(self.dev)
+        self.Tout = torch.zeros((F, 16), dtype=torch.float32, device=self.dev)
+        self.outlier = torch.zeros((F, cap), dtype=torch.uint8, device=self.dev)
+        self.n_inliers = torch.zeros(F, dtype=torch.int32, device=self.dev)
+        self.pose_stats = torch.zeros((F, 8), dtype=torch.float64, device=self.dev)
+        # left-image keypoints / descriptors copied out for the track records
+        self.trk_kps = torch.zeros((F, cap, 7), dtype=torch.float32, device=self.dev)
+        self.trk_desc = torch.zeros((F, cap, 32), dtype=torch.uint8, device=self.dev)
+        self.trk_counts = torch.zeros(F, dtype=torch.int32, device=self.dev)
+        self.with_ba = with_ba
+        self.ba = None
+        if with_ba:
+            from .ba import BatchedLocalBA
+            self.ba = BatchedLocalBA(self.ctx, F, ba_kf, ba_pts, ba_iters, seed, self.dev)
+
+    def close(self):
+        self.ex.close()
+        self.ctx.close()
+
+    # ---- inputs
+    def set_stereo_frames(self, left, right):
+        """left/right: uint8 arrays [F, H, W] (host). Kept resident in HBM: images [0,F) = left, [F,2F) = right."""
+        left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
+        assert left.shape == (self.F, self.height, self.width) and right.shape == left.shape
+        self.images = torch.from_numpy(np.concatenate([left, right], 0)).to(self.dev)
+        self.ex.set_images_dev(self.images.data_ptr(), 2 * self.F, self.width, self.width * self.height)
+
+    def set_synthetic(self, distinct=8, first=0):
+        """Seeded synthetic stereo frames (synth.frame); `distinct` different pairs tiled over the batch."""
+        pairs = [synth.frame(first + i, self.width, self.height, stereo=True) for i in range(min(distinct, self.F))]
+        L = np.stack([pairs[i % len(pairs)][0] for i in range(self.F)])
+        R = np.stack([pairs[i % len(pairs)][1] for i in range(self.F)])
+        self.set_stereo_frames(L, R)
+        return L, R
+
+    # ---- one pass of the hot path
+    def step(self):
+        F, ex, ctx, L = self.F, self.ex, self.ctx, capi.lib()
+        ex.build_pyramid(2 * F)
+        ex.orb(2 * F, self.target, self.init_th, self.min_th)
+        pitch = self.kp_cap * 32
+        ctx.check(L.tb_search_by_bf_batch_dev(ctx._h, F, C.c_void_p(self.desc_ptr), C.c_void_p(self.counts_ptr),
+                                              C.c_void_p(self.desc_ptr + F * pitch), C.c_void_p(self.counts_ptr + 4 * F),
+                                              C.c_size_t(pitch), C.c_float(self.bf_ratio), C.c_float(self.bf_min_th),
+                                              C.c_void_p(self.matches.data_ptr()), self.kp_cap,
+                                              C.c_void_p(self.match_counts.data_ptr())))
+        self.outlier.zero_()
+        ctx.check(L.tb_pose_opt_batch_dev(ctx._h, F, self.K.ctypes.data_as(C.c_void_p), C.c_void_p(self.Tin.data_ptr()),
+                                          C.c_void_p(self.obs.data_ptr()), C.c_void_p(self.match_counts.data_ptr()),
+                                          self.obs_pitch, C.c_void_p(self.outlier.data_ptr()), C.c_void_p(self.Tout.data_ptr()),
+                                          C.c_void_p(self.n_inliers.data_ptr()), C.c_void_p(self.pose_stats.data_ptr())))
+        if self.ba is not None:
+            self.ba.run()
+        ex.copy_results_dev(F, self.trk_kps.data_ptr(), self.trk_desc.data_ptr(), self.trk_counts.data_ptr(), self.kp_cap)
+
+    # ---- outputs (host copies, for tests)
+    def frame_results(self, f):
+        """(kps_left, desc_left, kps_right, desc_right, matches, Tcw, n_inliers, outlier) of frame f."""
+        torch.cuda.synchronize(self.dev)
+        kl, dl = self.ex.results(f, self.kp_cap)
+        kr, dr = self.ex.results(self.F + f, self.kp_cap)
+        nm = int(self.match_counts[f].item())
+        m = self.matches[f, :nm].cpu().numpy().view(capi.MATCH).reshape(-1)
+        return (kl, dl, kr, dr, m, self.Tout[f].cpu().numpy().reshape(4, 4), int(self.n_inliers[f].item()),
+                self.outlier[f].cpu().numpy())
