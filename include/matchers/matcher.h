@@ -1,0 +1,56 @@
+/* Header shim: the hot-path slice of TRACKING_BENCH::Matcher with the reference's signatures
+ * (reference include/matchers/matcher.h:18-62,149-150) on the C ABI (tb_search_by_bf,
+ * tb_search_by_violence). Projection / BoW / NN(LSH) / optical-flow / direct-alignment matchers are out
+ * of scope (SURVEY.md sections 2 and 8f). */
+#ifndef TRACKING_BENCH_MATCHER_H
+#define TRACKING_BENCH_MATCHER_H
+#include <memory>
+#include <vector>
+#include "../tb_compat/deps.h"
+
+namespace TRACKING_BENCH
+{
+    class Frame;
+
+    class Matcher
+    {
+    public:
+        Matcher() = default;
+        ~Matcher() = default;
+        //  match parameter (reference :23-27)
+        int TH_LOW = 50;
+        int TH_HIGH = 100;
+        int HISTO_LENGTH = 30;
+        bool checkOrientation = true;
+        float nRatio{};
+
+        // OpenCV BF (reference :39-44); only the whole-set branch is defined
+        std::vector<cv::DMatch> searchByBF(
+                const std::shared_ptr<Frame>& F1,
+                const std::shared_ptr<Frame>& F2,
+                int MinLevel, int MaxLevel,
+                float ratio, float minTh,
+                bool MapPointOnly = false);
+
+        // Violence (reference :48-62)
+        void setViolenceParam(int low, int high, int histo_length, bool check, float ratio)
+        {
+            TH_LOW = low;
+            TH_HIGH = high;
+            HISTO_LENGTH = histo_length;
+            checkOrientation=check;
+            nRatio=ratio;
+        }
+        std::vector<cv::DMatch> searchByViolence(
+                const std::shared_ptr<Frame>& F1,
+                const std::shared_ptr<Frame>& F2,
+                int min_level = 0,
+                int max_level = 1,
+                float search_r = 10,
+                bool MapPointOnly = false);
+
+        static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b);
+        static void ComputeThreeMaxima(std::vector<int>* histo, const int L, int &ind1, int &ind2, int &ind3);
+    };
+}
+#endif //TRACKING_BENCH_MATCHER_H

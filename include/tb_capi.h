@@ -141,6 +141,13 @@ int tb_pose_opt_batch_dev(tb_ctx* ctx, int nproblems, const double K[4], const f
  * iterations, initial chi2, final chi2, final lambda. */
 int tb_local_ba(tb_ctx* ctx, const double K[4], int nkf, int nfixed, float* poses, int npt, float* pts,
                 const tb_ba_obs* obs, int nobs, int iters, double* stats);
+/* Batched device form: nwindows equally sized windows; window w uses poses + w*nkf*16, pts + w*npt*3,
+ * obs + w*obs_pitch (obs_counts[w] rows, GROUPED BY ASCENDING POINT INDEX), stats + 8w (nullable;
+ * stats[7] = -1 flags a window whose observations were out of range / not grouped). Device pointers.
+ * Synchronises the stream once (LM termination is data dependent). */
+int tb_local_ba_batch_dev(tb_ctx* ctx, int nwindows, const double K[4], int nkf, int nfixed, float* poses, int npt,
+                          float* pts, const tb_ba_obs* obs, const int32_t* obs_counts, int obs_pitch, int iters,
+                          double* stats);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,45 @@
+"""Batched multi-keyframe local BA windows for the pipeline (north-star extension, no reference
+counterpart: SURVEY.md D1 / a17).  One seeded synthetic window per stereo frame (synth.ba_problem),
+resident in HBM; run() re-optimises every window from its initial state through tb_local_ba_batch_dev."""
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import capi, synth
+KITTI_K = (718.856, 718.856, 607.1928, 185.2157)
+
+
+class BatchedLocalBA:
+    def __init__(self, ctx, nwindows, nkf=10, npt=5000, iters=10, seed=0, device=None, nfixed=2, distinct=4):
+        self.ctx, self.W, self.nkf, self.npt, self.iters, self.nfixed = ctx, int(nwindows), int(nkf), int(npt), int(iters), nfixed
+        probs = [synth.ba_problem(seed * 100 + i, nkf, npt, KITTI_K) for i in range(min(distinct, self.W))]
+        self.obs_pitch = max(len(p[4]) for p in probs)
+        obs = np.zeros((self.W, self.obs_pitch), capi.BA_OBS)
+        cnt = np.zeros(self.W, np.int32)
+        poses = np.zeros((self.W, nkf, 16), np.float32)
+        pts = np.zeros((self.W, npt, 3), np.float32)
+        for w in range(self.W):
+            Pt, Pi, Xt, Xi, o = probs[w % len(probs)]
+            obs[w, :len(o)] = o
+            cnt[w] = len(o)
+            poses[w] = Pi.reshape(nkf, 16)
+            pts[w] = Xi
+        self.host = dict(obs=obs, counts=cnt, poses=poses, pts=pts)
+        dev = device
+        self.obs = torch.from_numpy(obs.view(np.uint8).reshape(self.W, self.obs_pitch, capi.BA_OBS.itemsize)).to(dev)
+        self.counts = torch.from_numpy(cnt).to(dev)
+        self.poses0 = torch.from_numpy(poses).to(dev)
+        self.pts0 = torch.from_numpy(pts).to(dev)
+        self.poses = torch.empty_like(self.poses0)
+        self.pts = torch.empty_like(self.pts0)
+        self.stats = torch.zeros((self.W, 8), dtype=torch.float64, device=dev)
+        self.K = np.ascontiguousarray(KITTI_K, np.float64)
+
+    def run(self):
+        self.poses.copy_(self.poses0)
+        self.pts.copy_(self.pts0)
+        self.ctx.check(capi.lib().tb_local_ba_batch_dev(
+            self.ctx._h, self.W, self.K.ctypes.data_as(C.c_void_p), self.nkf, self.nfixed, C.c_void_p(self.poses.data_ptr()),
+            self.npt, C.c_void_p(self.pts.data_ptr()), C.c_void_p(self.obs.data_ptr()), C.c_void_p(self.counts.data_ptr()),
+            self.obs_pitch, self.iters, C.c_void_p(self.stats.data_ptr())))

@@ -960,31 +960,52 @@ int tb_pose_opt(tb_ctx* ctx, const double K[4], const float Tcw_in[16], const tb
     return TB_OK;
 }
 
+int tb_local_ba_batch_dev(tb_ctx* ctx, int nwindows, const double K[4], int nkf, int nfixed, float* poses, int npt, float* pts,
+                          const tb_ba_obs* obs, const int32_t* obs_counts, int obs_pitch, int iters, double* stats) {
+    if (!ctx || !K || !poses || !pts || !obs || !obs_counts || nwindows < 0 || nkf < 1 || npt < 1 || obs_pitch < 1 || nfixed < 0 ||
+        nfixed > nkf || iters < 0)
+        return TB_EINVAL;
+    if (nwindows == 0) return TB_OK;
+    const size_t wb = tbk_local_ba_work_bytes(nwindows, nkf, nfixed, npt, obs_pitch);
+    void* dwork;
+    int rc = tb_scratch(ctx, 6, wb, &dwork);
+    if (rc) return rc;
+    return tbk_local_ba_batch(ctx, nwindows, K, nkf, nfixed, poses, npt, pts, obs, obs_counts, obs_pitch, iters, stats, dwork, wb);
+}
+
 int tb_local_ba(tb_ctx* ctx, const double K[4], int nkf, int nfixed, float* poses, int npt, float* pts, const tb_ba_obs* obs,
                 int nobs, int iters, double* stats) {
     if (!ctx || !K || !poses || !pts || !obs || nkf < 1 || npt < 1 || nobs < 1 || nfixed < 0 || nfixed > nkf || iters < 0)
         return TB_EINVAL;
     for (int e = 0; e < nobs; e++)
-        if (obs[e].kf < 0 || obs[e].kf >= nkf || obs[e].pt < 0 || obs[e].pt >= npt) return tb_fail(ctx, TB_EINVAL, "local_ba: observation %d out of range", e);
-    void *dposes, *dpts, *dobs, *dstats, *dwork;
+        if (obs[e].kf < 0 || obs[e].kf >= nkf || obs[e].pt < 0 || obs[e].pt >= npt)
+            return tb_fail(ctx, TB_EINVAL, "local_ba: observation %d out of range", e);
+    /* the kernels want observations grouped by point: stable sort keeps each point's edges in caller order */
+    std::vector<tb_ba_obs> sorted(obs, obs + nobs);
+    std::stable_sort(sorted.begin(), sorted.end(), [](const tb_ba_obs& a, const tb_ba_obs& b) { return a.pt < b.pt; });
+    void *dposes, *dpts, *dobs, *dmisc;
     int rc;
-    const size_t wb = tbk_local_ba_work_bytes(nkf, nfixed, npt, nobs);
     if ((rc = tb_scratch(ctx, 0, (size_t)nkf * 64, &dposes))) return rc;
     if ((rc = tb_scratch(ctx, 1, (size_t)npt * 12, &dpts))) return rc;
     if ((rc = tb_scratch(ctx, 2, (size_t)nobs * sizeof(tb_ba_obs), &dobs))) return rc;
-    if ((rc = tb_scratch(ctx, 3, 256, &dstats))) return rc;
-    if ((rc = tb_scratch(ctx, 4, wb, &dwork))) return rc;
+    if ((rc = tb_scratch(ctx, 3, 256, &dmisc))) return rc;
+    double* dstats = (double*)dmisc;
+    int32_t* dcnt = (int32_t*)((char*)dmisc + 64);
+    int32_t cnt = nobs;
     TB_HIP(ctx, hipMemcpyAsync(dposes, poses, (size_t)nkf * 64, hipMemcpyHostToDevice, ctx->stream));
     TB_HIP(ctx, hipMemcpyAsync(dpts, pts, (size_t)npt * 12, hipMemcpyHostToDevice, ctx->stream));
-    TB_HIP(ctx, hipMemcpyAsync(dobs, obs, (size_t)nobs * sizeof(tb_ba_obs), hipMemcpyHostToDevice, ctx->stream));
+    TB_HIP(ctx, hipMemcpyAsync(dobs, sorted.data(), (size_t)nobs * sizeof(tb_ba_obs), hipMemcpyHostToDevice, ctx->stream));
+    TB_HIP(ctx, hipMemcpyAsync(dcnt, &cnt, 4, hipMemcpyHostToDevice, ctx->stream));
     TB_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    rc = tbk_local_ba(ctx, K, nkf, nfixed, (float*)dposes, npt, (float*)dpts, (const tb_ba_obs*)dobs, nobs, iters, (double*)dstats,
-                      dwork, wb);
+    rc = tb_local_ba_batch_dev(ctx, 1, K, nkf, nfixed, (float*)dposes, npt, (float*)dpts, (const tb_ba_obs*)dobs, dcnt, nobs, iters, dstats);
     if (rc) return rc;
+    double st[8];
     TB_HIP(ctx, hipMemcpyAsync(poses, dposes, (size_t)nkf * 64, hipMemcpyDeviceToHost, ctx->stream));
     TB_HIP(ctx, hipMemcpyAsync(pts, dpts, (size_t)npt * 12, hipMemcpyDeviceToHost, ctx->stream));
-    if (stats) TB_HIP(ctx, hipMemcpyAsync(stats, dstats, 64, hipMemcpyDeviceToHost, ctx->stream));
+    TB_HIP(ctx, hipMemcpyAsync(st, dstats, 64, hipMemcpyDeviceToHost, ctx->stream));
     TB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (stats) memcpy(stats, st, 64);
+    if (st[7] < 0) return tb_fail(ctx, TB_EINVAL, "local_ba: observations rejected by the device-side check");
     return TB_OK;
 }
 

@@ -142,8 +142,9 @@ int tbk_window_match(tb_ctx* ctx, const tb_keypoint* d_k1, const uint8_t* d_d1, 
 int tbk_pose_batch(tb_ctx* ctx, int nproblems, const double K[4], const float* Tcw_in, const tb_obs* obs,
                    const int32_t* counts, int obs_pitch, uint8_t* outlier, float* Tcw_out, int32_t* n_inliers,
                    double* stats, double* d_err);
-int tbk_local_ba(tb_ctx* ctx, const double K[4], int nkf, int nfixed, float* d_poses, int npt, float* d_pts,
-                 const tb_ba_obs* d_obs, int nobs, int iters, double* d_stats, void* d_work, size_t work_bytes);
-size_t tbk_local_ba_work_bytes(int nkf, int nfixed, int npt, int nobs);
+int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixed, float* d_poses, int npt, float* d_pts,
+                       const tb_ba_obs* d_obs, const int32_t* d_counts, int obs_pitch, int iters, double* d_stats, void* d_work,
+                       size_t work_bytes);
+size_t tbk_local_ba_work_bytes(int W, int nkf, int nfixed, int npt, int obs_pitch);
 
 #endif
