@@ -29,6 +29,7 @@ from trackingbench_slam_amd import synth  # noqa: E402
 from trackingbench_slam_amd.pipeline import KITTI_K, TrackingPipeline  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the measured achievable
+F64_MFMA_PEAK_TFLOPS = 78.6  # FP64 matrix peak = half the 157.3 TFLOP/s FP32 matrix peak of the guide's chip table
 
 
 def level_pixels(w, h, nlevels, scale):
@@ -58,31 +59,41 @@ def algorithmic_bytes(kernel, w, h, nlevels, scale, target, nimg, npairs):
     return 0
 
 
+def schur_flops_per_launch(ba_pts, nwindows):
+    """k_ba_schur: dense 64x64 tile x (96 densified columns per 32-point chunk) per window per LM trial."""
+    nchunks = (ba_pts + 31) // 32
+    return 2.0 * 64 * 64 * 96 * nchunks * nwindows
+
+
 def cpu_baseline(args, seconds=20.0):
     """CPU restatement of the reference path (oracle/, kind "port", 1 thread) on a bounded sample of the same
     workload: whole stereo frames end to end until ~`seconds` of CPU time."""
     import oracle
-    done, t0 = 0, time.perf_counter()
     K = KITTI_K
+    inputs = []
+    for i in range(4):  # input generation is not part of the path: prepared before the clock starts
+        L, R = synth.frame(i, args.width, args.height, stereo=True)
+        ba = None if args.no_ba else synth.ba_problem(i, args.ba_kf, args.ba_pts, K)
+        inputs.append((L, R, synth.pose_problem(i, args.target + 100, K), ba))
+    done, t0 = 0, time.perf_counter()
     while True:
-        L, R = synth.frame(done % 8, args.width, args.height, stereo=True)
+        L, R, (_, Ti, obs), ba = inputs[done % len(inputs)]
         lvL, sf = oracle.pyramid(L, args.levels, args.scale)
         lvR, _ = oracle.pyramid(R, args.levels, args.scale)
         k1, d1, _ = oracle.orb_extract(lvL, sf, args.target, args.init_th, args.min_th)
         k2, d2, _ = oracle.orb_extract(lvR, sf, args.target, args.init_th, args.min_th)
         m = oracle.search_by_bf(d1, d2, 10.0, 30.0)
-        _, Ti, obs = synth.pose_problem(done, max(len(m), 3), K)
-        oracle.pose_opt(K, Ti, obs)
-        if not args.no_ba:
-            Pt, Pi, Xt, Xi, bo = synth.ba_problem(done, args.ba_kf, args.ba_pts, K)
+        oracle.pose_opt(K, Ti, obs[:max(len(m), 0)])
+        if ba is not None:
+            Pt, Pi, Xt, Xi, bo = ba
             oracle.local_ba(K, Pi, 2, Xi, bo, args.ba_iters)
         done += 1
         el = time.perf_counter() - t0
         if el >= seconds or done >= 64:
             break
     return {"value": done / el, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d stereo frames end-to-end (synthetic %dx%d, same stages) in %.1f s on 1 host thread; "
-                      "synthetic-frame generation included" % (done, args.width, args.height, el)}
+            "sample": "%d stereo frames end-to-end (synthetic %dx%d, same stages incl. local BA: %s) in %.1f s on 1 host "
+                      "thread" % (done, args.width, args.height, "no" if args.no_ba else "yes", el)}
 
 
 def main():
@@ -154,12 +165,20 @@ def main():
         abytes = algorithmic_bytes(name, args.width, args.height, args.levels, args.scale, args.target, nimg, npairs)
         launches_per_step = max(calls // max(args.steps, 1), 1)
         avg_ms_per_step = tot_ms / max(args.steps, 1)
-        achieved = (abytes / 1e9) / (avg_ms_per_step / 1e3) if avg_ms_per_step > 0 else 0.0
-        roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                    "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
-                    "launches_per_step": launches_per_step, "avg_launch_ms": round(tot_ms / max(calls, 1), 5),
-                    "algorithmic_bytes_per_step": abytes,
-                    "kernels_ms_per_step": {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items())}}
+        kern_ms = {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items())}
+        if name == "k_ba_schur":
+            fl = schur_flops_per_launch(args.ba_pts, args.frames)
+            achieved = fl / 1e12 / (tot_ms / max(calls, 1) / 1e3)
+            roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": F64_MFMA_PEAK_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(achieved / F64_MFMA_PEAK_TFLOPS, 5), "traffic": None,
+                        "launches_per_step": launches_per_step, "avg_launch_ms": round(tot_ms / max(calls, 1), 5),
+                        "algorithmic_flops_per_launch": fl, "kernels_ms_per_step": kern_ms}
+        else:
+            achieved = (abytes / 1e9) / (avg_ms_per_step / 1e3) if avg_ms_per_step > 0 else 0.0
+            roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "launches_per_step": launches_per_step, "avg_launch_ms": round(tot_ms / max(calls, 1), 5),
+                        "algorithmic_bytes_per_step": abytes, "kernels_ms_per_step": kern_ms}
         out = {
             "metric": "frames/sec end-to-end (extract+match+local-BA)", "value": round(frames_total / el, 2),
             "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
