@@ -60,9 +60,8 @@ def algorithmic_bytes(kernel, w, h, nlevels, scale, target, nimg, npairs):
 
 
 def schur_flops_per_launch(ba_pts, nwindows):
-    """k_ba_schur: dense 64x64 tile x (96 densified columns per 32-point chunk) per window per LM trial."""
-    nchunks = (ba_pts + 31) // 32
-    return 2.0 * 64 * 64 * 96 * nchunks * nwindows
+    """k_ba_schur: dense 64x64 tile x (3 densified columns per point) per window per LM trial."""
+    return 2.0 * 64 * 64 * 3 * ba_pts * nwindows
 
 
 def cpu_baseline(args, seconds=20.0):

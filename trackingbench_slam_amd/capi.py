@@ -56,6 +56,12 @@ def lib():
     if _LIB is None:
         if not os.path.exists(LIB_PATH):
             raise TBError(TB_EDEVICE, "libtb_hip.so is not built (run __graft_entry__.build())")
+        try:
+            # One HIP runtime per process: when torch is installed its bundled libamdhip64 must be the one that
+            # gets loaded (loading ROCm's copy first makes torch's later initialisation find no GPU).
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(LIB_PATH)
         L.tb_last_error.restype = C.c_char_p
         L.tb_strerror.restype = C.c_char_p

@@ -27,9 +27,10 @@
 #include "tb_se3.h"
 
 #define BA_T 256
-#define BA_CP 32              /* points per Schur chunk */
+#define BA_CP 4               /* points per Schur chunk (one wavefront each) */
 #define BA_LD (BA_CP * 3 + 1) /* LDS row stride (doubles) of the densified tiles */
 #define BA_KFCH 1024          /* edges per keyframe-pass chunk */
+#define BA_KFBLK 4            /* workgroups per keyframe in the keyframe pass */
 
 struct BaState {
     double lambda, ni, currentChi, chi0, scale_p, rho;
@@ -98,17 +99,48 @@ __device__ __forceinline__ double ba_block_max1(double v, double* red) {
     return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
 }
 
-/* ---- setup: CSR by point (observations must be grouped by ascending point index) and by keyframe */
+/* ---- setup: CSR by point (observations must be grouped by ascending point index) and by keyframe.
+ * grid (nkf + 1, W): block k < nkf lists keyframe k's edges in ascending edge order (its base offset is
+ * the count of edges with a smaller keyframe index, recounted per block so blocks stay independent);
+ * block nkf initialises the LM state, checks the input, builds ptStart and converts poses / points. */
 __global__ void __launch_bounds__(BA_T)
 k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ pts, const tb_ba_obs* __restrict__ obsAll,
            const int32_t* __restrict__ obsCounts, double* __restrict__ dw, int* __restrict__ iw, BaState* __restrict__ states) {
     __shared__ int tmp[8];
-    const int w = blockIdx.x, tid = threadIdx.x;
+    __shared__ int sflags[BA_T];
+    __shared__ int srun;
+    const int w = blockIdx.y, k = blockIdx.x, tid = threadIdx.x;
     const tb_ba_obs* obs = obsAll + (size_t)w * d.obs_pitch;
     const int nobs = min(obsCounts[w], d.obs_pitch);
     double* D = dw + (size_t)w * d.wstride;
     int* I = iw + (size_t)w * d.istride;
     BaState* st = states + w;
+    if (k < d.nkf) {
+        int below = 0;
+        for (int e = tid; e < nobs; e += BA_T) below += (obs[e].kf >= 0 && obs[e].kf < k) ? 1 : 0;
+        below = tb_wave_sum(below);
+        if ((tid & 63) == 0) tmp[tid >> 6] = below;
+        if (tid == 0) srun = 0;
+        __syncthreads();
+        const int base = tmp[0] + tmp[1] + tmp[2] + tmp[3];
+        __syncthreads();
+        for (int e0 = 0; e0 < nobs; e0 += BA_T) {
+            const int e = e0 + tid;
+            const int f = (e < nobs && obs[e].kf == k) ? 1 : 0;
+            sflags[tid] = f;
+            __syncthreads();
+            const int total = tb_block_excl_scan(sflags, BA_T, tmp);
+            if (f) I[d.oKfEdges + base + srun + sflags[tid]] = e;
+            __syncthreads();
+            if (tid == 0) srun += total;
+            __syncthreads();
+        }
+        if (tid == 0) {
+            I[d.oKfStart + k] = base;
+            if (k == d.nkf - 1) I[d.oKfStart + d.nkf] = base + srun;
+        }
+        return;
+    }
     if (tid == 0) {
         st->lambda = 0; st->ni = 2; st->currentChi = 0; st->chi0 = 0; st->scale_p = 0; st->rho = 0;
         st->iter = 0; st->qmax = 0; st->status = (d.iters > 0 && nobs > 0) ? 0 : 1; st->need_lin = 1; st->cur = 0; st->ok2 = 1;
@@ -124,26 +156,13 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
         while (lo < hi) { const int mid = (lo + hi) >> 1; if (obs[mid].pt < p) lo = mid + 1; else hi = mid; }
         I[d.oPtStart + p] = lo;
     }
-    int* scan = I + d.oScan;
-    int base = 0;
-    for (int k = 0; k < d.nkf; k++) {
-        for (int e = tid; e < nobs; e += BA_T) scan[e] = (obs[e].kf == k) ? 1 : 0;
-        __syncthreads();
-        const int cnt = tb_block_excl_scan(scan, nobs, tmp);
-        for (int e = tid; e < nobs; e += BA_T)
-            if (obs[e].kf == k) I[d.oKfEdges + base + scan[e]] = e;
-        if (tid == 0) I[d.oKfStart + k] = base;
-        base += cnt;
-        __syncthreads();
-    }
-    if (tid == 0) I[d.oKfStart + d.nkf] = base;
-    for (int k = tid; k < d.nkf; k += BA_T) {
-        const float* T = poses + ((size_t)w * d.nkf + k) * 16;
+    for (int kk = tid; kk < d.nkf; kk += BA_T) {
+        const float* T = poses + ((size_t)w * d.nkf + kk) * 16;
         double R[9], t[3];
         for (int i = 0; i < 3; i++) { for (int j = 0; j < 3; j++) R[i * 3 + j] = (double)T[i * 4 + j]; t[i] = (double)T[i * 4 + 3]; }
         const PoSE3 s = po_from_Rt(R, t);
-        ba_store_se3(D + d.oT + (size_t)k * 7, s);
-        ba_store_se3(D + d.oT + (size_t)(d.nkf + k) * 7, s);
+        ba_store_se3(D + d.oT + (size_t)kk * 7, s);
+        ba_store_se3(D + d.oT + (size_t)(d.nkf + kk) * 7, s);
     }
     for (int i = tid; i < d.npt * 3; i += BA_T) {
         const double v = (double)pts[(size_t)w * d.npt * 3 + i];
@@ -228,7 +247,7 @@ __global__ void __launch_bounds__(BA_T)
 k_ba_kf(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw, const int* __restrict__ iw,
         const BaState* __restrict__ states) {
     __shared__ double red[4 * 27];
-    const int w = blockIdx.z, kf = d.nfixed + blockIdx.y, chunk = blockIdx.x, tid = threadIdx.x;
+    const int w = blockIdx.z, kf = d.nfixed + blockIdx.y, tid = threadIdx.x;
     const BaState st = states[w];
     if (st.status || !st.need_lin) return;
     const tb_ba_obs* obs = obsAll + (size_t)w * d.obs_pitch;
@@ -237,42 +256,61 @@ k_ba_kf(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw,
     const int beg = I[d.oKfStart + kf], end = I[d.oKfStart + kf + 1];
     const PoSE3 Tk = ba_load_se3(D + d.oT + ((size_t)st.cur * d.nkf + kf) * 7);
     const double* P = D + d.oP + (size_t)st.cur * d.npt * 3;
-    double acc[27];
-    for (int i = 0; i < 27; i++) acc[i] = 0;
-    for (int j = 0; j < BA_KFCH / BA_T; j++) {
-        const int idx = beg + chunk * BA_KFCH + j * BA_T + tid;
-        if (idx < end) {
-            const int e = I[d.oKfEdges + idx];
-            const int p = obs[e].pt;
+    /* BA_KFBLK blocks per keyframe walk its chunks; k_ba_reduce sums the occupied chunks in order */
+    for (int chunk = blockIdx.x; chunk * BA_KFCH < end - beg; chunk += BA_KFBLK) {
+        double acc[27];
+#pragma unroll
+        for (int i = 0; i < 27; i++) acc[i] = 0;
+        int ee[BA_KFCH / BA_T], pp[BA_KFCH / BA_T];
+#pragma unroll
+        for (int j = 0; j < BA_KFCH / BA_T; j++) {
+            const int idx = beg + chunk * BA_KFCH + j * BA_T + tid;
+            ee[j] = (idx < end) ? I[d.oKfEdges + idx] : -1;
+        }
+#pragma unroll
+        for (int j = 0; j < BA_KFCH / BA_T; j++) pp[j] = (ee[j] >= 0) ? obs[ee[j]].pt : 0;
+#pragma unroll
+        for (int j = 0; j < BA_KFCH / BA_T; j++) {
+            if (ee[j] < 0) continue;
+            const int e = ee[j], p = pp[j];
             const double X[3] = {P[3 * p], P[3 * p + 1], P[3 * p + 2]};
             double pc[3], Jp[12];
             po_map(Tk, X, pc);
             ba_jac_pose(pc, d.fx, d.fy, Jp);
             const double ww = D[d.oWgt + e], e0 = D[d.oErr + 2 * (size_t)e], e1 = D[d.oErr + 2 * (size_t)e + 1];
-            int k = 0;
+#pragma unroll
             for (int a = 0; a < 6; a++) {
                 acc[21 + a] -= ww * (Jp[a] * e0 + Jp[6 + a] * e1);
-                for (int c = a; c < 6; c++) acc[k++] += ww * (Jp[a] * Jp[c] + Jp[6 + a] * Jp[6 + c]);
+#pragma unroll
+                for (int c = a; c < 6; c++) acc[a * 6 - (a * (a - 1)) / 2 + (c - a)] += ww * (Jp[a] * Jp[c] + Jp[6 + a] * Jp[6 + c]);
             }
         }
+        po_block_sum<27>(acc, red);
+        if (tid == 0) { /* static indices only: a lane-indexed read of acc[] would push it to scratch */
+            double* o = D + d.oPartKF + ((size_t)blockIdx.y * d.kfChunks + chunk) * 27;
+#pragma unroll
+            for (int i = 0; i < 27; i++) o[i] = acc[i];
+        }
+        __syncthreads();
     }
-    po_block_sum<27>(acc, red);
-    if (tid < 27) D[d.oPartKF + ((size_t)blockIdx.y * d.kfChunks + chunk) * 27 + tid] = acc[tid];
 }
 
 /* ---- C: ordered reduction of the partials, lambda_0 */
 __global__ void __launch_bounds__(BA_T)
-k_ba_reduce(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) {
+k_ba_reduce(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, BaState* __restrict__ states) {
     __shared__ double red[4];
     const int w = blockIdx.x, tid = threadIdx.x;
     BaState* st = states + w;
     if (st->status || !st->need_lin) return;
     double* D = dw + (size_t)w * d.wstride;
+    const int* I = iw + (size_t)w * d.istride;
     double maxd = 0;
     for (int i = tid; i < d.nfree * 27; i += BA_T) {
         const int kf = i / 27, c = i - kf * 27;
+        const int nedges = I[d.oKfStart + d.nfixed + kf + 1] - I[d.oKfStart + d.nfixed + kf];
+        const int nch = (nedges + BA_KFCH - 1) / BA_KFCH;
         double s = 0;
-        for (int ch = 0; ch < d.kfChunks; ch++) s += D[d.oPartKF + ((size_t)kf * d.kfChunks + ch) * 27 + c];
+        for (int ch = 0; ch < nch; ch++) s += D[d.oPartKF + ((size_t)kf * d.kfChunks + ch) * 27 + c];
         if (c >= 21) D[d.oBp + kf * 6 + (c - 21)] = s;
         else {
             /* c -> (a, b) of the upper triangle, row-major */
@@ -294,134 +332,271 @@ k_ba_reduce(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) {
     }
 }
 
-/* ---- D: Schur complement S' (np x np) and reduced rhs as an FP64 MFMA block GEMM */
+/* ---- D: Schur complement S' (np x np, lower triangle) and reduced rhs as an FP64 MFMA block GEMM.
+ * Every WAVEFRONT works on its own 4-point chunks with private LDS tiles (no workgroup barrier in the
+ * loop; three workgroups per CU keep three waves per SIMD so one wave's scatter overlaps another's MFMAs):
+ *   (1) 4 lanes invert the damped 3x3 point blocks, (2) all lanes scatter the chunk's Hpl rows (6 x 3 per
+ *   edge) into the dense tiles W and Y = Hpl * Hinv, bl goes to row np of W so the reduced rhs falls out of
+ *   the same product, (3) 3 k-steps of v_mfma_f64_16x16x4 over the needed 16x16 tiles (row tile >= column
+ *   tile, plus the column tile holding the rhs), (4) the touched entries are cleared again.
+ * The loads of the wave's next chunk are issued before the MFMA phase (software pipeline). The four waves'
+ * accumulators are summed through LDS in wave order; one partial tile per workgroup goes to k_ba_solve. */
+#define BA_MAXT 4 /* 16-row tiles per side (np <= 60) */
+#define BA_WAVE_LDS (2 * 64 * BA_LD + BA_CP * 9) /* doubles per wave */
+
 __global__ void __launch_bounds__(BA_T)
 k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw, const int* __restrict__ iw,
            BaState* __restrict__ states) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    double* Yl = lds;                /* [64][BA_LD]: Hpl * (Hll + lambda I)^-1 */
-    double* Wl = lds + 64 * BA_LD;   /* [64][BA_LD]: Hpl; row np holds bl */
     const int w = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
     const BaState st = states[w];
     if (st.status) return;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    double* Yl = lds + (size_t)wave * BA_WAVE_LDS; /* [64][BA_LD]: Hpl * (Hll + lambda I)^-1 */
+    double* Wl = Yl + 64 * BA_LD;                  /* [64][BA_LD]: Hpl; row np holds bl */
+    double* Hi = Wl + 64 * BA_LD;                  /* [BA_CP][9] */
     const tb_ba_obs* obs = obsAll + (size_t)w * d.obs_pitch;
     double* D = dw + (size_t)w * d.wstride;
     const int* I = iw + (size_t)w * d.istride;
-    const int wave = tid >> 6, lane = tid & 63;
-    ba_d4 acc[4];
-    for (int j = 0; j < 4; j++) acc[j] = (ba_d4){0, 0, 0, 0};
-    for (int ch = g; ch < d.nChunks; ch += d.G) {
-        for (int i = tid; i < 2 * 64 * BA_LD; i += BA_T) lds[i] = 0;
-        __syncthreads();
-        const int pl = tid; /* one thread per point of the chunk */
-        const int p = ch * BA_CP + pl;
-        if (pl < BA_CP && p < d.npt) {
-            double Hi[9];
-            const bool ok = ba_inv3(D + d.oHll + (size_t)p * 6, st.lambda, Hi);
-            if (!ok) states[w].sing = 1; /* benign race: every writer stores 1 */
-            if (ok) {
-                for (int c = 0; c < 3; c++) Wl[d.np * BA_LD + 3 * pl + c] = D[d.oBl + (size_t)p * 3 + c];
-                for (int e = I[d.oPtStart + p]; e < I[d.oPtStart + p + 1]; e++) {
-                    const int kf = obs[e].kf;
-                    if (kf < d.nfixed) continue;
-                    const int r0 = 6 * (kf - d.nfixed);
-                    const double* H = D + d.oHpl + (size_t)e * 18;
-                    for (int a = 0; a < 6; a++)
-                        for (int c = 0; c < 3; c++) {
-                            Wl[(r0 + a) * BA_LD + 3 * pl + c] = H[a * 3 + c];
-                            Yl[(r0 + a) * BA_LD + 3 * pl + c] = H[a * 3] * Hi[c] + H[a * 3 + 1] * Hi[3 + c] + H[a * 3 + 2] * Hi[6 + c];
-                        }
+    const int R = (d.np + 15) >> 4;   /* row tiles */
+    const int cR = d.np >> 4;         /* column tile that holds the rhs column (index np) */
+    ba_d4 acc[BA_MAXT][BA_MAXT];
+#pragma unroll
+    for (int r = 0; r < BA_MAXT; r++)
+#pragma unroll
+        for (int c = 0; c < BA_MAXT; c++) acc[r][c] = (ba_d4){0, 0, 0, 0};
+    for (int i = lane; i < 128 * BA_LD; i += 64) Yl[i] = 0;
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    const int MAXI = (BA_CP * 10 * 6 + 63) / 64; /* edge rows per lane held in registers; longer chunks take the direct path */
+    const int stride = d.G * 4;                  /* waves per window */
+    int ch = g * 4 + wave;
+    int e0 = 0, e1 = 0, e0n = 0, e1n = 0;
+    if (ch < d.nChunks) { e0 = I[d.oPtStart + ch * BA_CP]; e1 = I[d.oPtStart + min(ch * BA_CP + BA_CP, d.npt)]; }
+    if (ch + stride < d.nChunks) { e0n = I[d.oPtStart + (ch + stride) * BA_CP]; e1n = I[d.oPtStart + min((ch + stride) * BA_CP + BA_CP, d.npt)]; }
+    int ipos[MAXI];
+    double ih0[MAXI], ih1[MAXI], ih2[MAXI];
+    double ph[6] = {0, 0, 0, 0, 0, 0}, pb[3] = {0, 0, 0};
+    auto preload = [&](int c, int ea, int eb) {
+        const int p0 = c * BA_CP;
+#pragma unroll
+        for (int j = 0; j < MAXI; j++) {
+            const int it = lane + j * 64;
+            ipos[j] = -1;
+            if (it < (eb - ea) * 6) {
+                const int e = ea + it / 6, a = it - (it / 6) * 6;
+                const tb_ba_obs o = obs[e];
+                if (o.kf >= d.nfixed) {
+                    ipos[j] = ((6 * (o.kf - d.nfixed) + a) * BA_LD + 3 * (o.pt - p0)) | ((o.pt - p0) << 24);
+                    const double* H = D + d.oHpl + (size_t)e * 18 + a * 3;
+                    ih0[j] = H[0]; ih1[j] = H[1]; ih2[j] = H[2];
                 }
             }
         }
-        __syncthreads();
-        /* wave `wave` owns tile row wave (16 rows) x 4 tile columns; K = 96 densified columns */
-        const int arow = 16 * wave + (lane & 15), kofs = lane >> 4;
-        for (int kk = 0; kk < BA_CP * 3; kk += 4) {
-            const double a = Yl[arow * BA_LD + kk + kofs];
+        if (lane < BA_CP && p0 + lane < d.npt) {
 #pragma unroll
-            for (int j = 0; j < 4; j++) {
-                const double b = Wl[(16 * j + (lane & 15)) * BA_LD + kk + kofs];
-                acc[j] = __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, acc[j], 0, 0, 0);
+            for (int i = 0; i < 6; i++) ph[i] = D[d.oHll + (size_t)(p0 + lane) * 6 + i];
+#pragma unroll
+            for (int i = 0; i < 3; i++) pb[i] = D[d.oBl + (size_t)(p0 + lane) * 3 + i];
+        }
+    };
+    if (ch < d.nChunks) preload(ch, e0, e1);
+    for (; ch < d.nChunks; ch += stride) {
+        const int p0 = ch * BA_CP, p1 = min(p0 + BA_CP, d.npt);
+        if (lane < p1 - p0) {
+            double inv[9];
+            const bool ok = ba_inv3(ph, st.lambda, inv);
+            if (!ok) { states[w].sing = 1; for (int i = 0; i < 9; i++) inv[i] = 0; } /* benign race: every writer stores 1 */
+            for (int i = 0; i < 9; i++) Hi[lane * 9 + i] = inv[i];
+            for (int c = 0; c < 3; c++) Wl[d.np * BA_LD + 3 * lane + c] = ok ? pb[c] : 0.0;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        int cpos[MAXI];
+#pragma unroll
+        for (int j = 0; j < MAXI; j++) {
+            cpos[j] = ipos[j];
+            if (ipos[j] >= 0) {
+                const int off = ipos[j] & 0xffffff;
+                const double* inv = Hi + (ipos[j] >> 24) * 9;
+                double* wr = Wl + off;
+                double* yr = Yl + off;
+                wr[0] = ih0[j]; wr[1] = ih1[j]; wr[2] = ih2[j];
+                yr[0] = ih0[j] * inv[0] + ih1[j] * inv[3] + ih2[j] * inv[6];
+                yr[1] = ih0[j] * inv[1] + ih1[j] * inv[4] + ih2[j] * inv[7];
+                yr[2] = ih0[j] * inv[2] + ih1[j] * inv[5] + ih2[j] * inv[8];
             }
+        }
+        for (int it = lane + MAXI * 64; it < (e1 - e0) * 6; it += 64) { /* direct path for very long chunks */
+            const int e = e0 + it / 6, a = it - (it / 6) * 6;
+            const tb_ba_obs o = obs[e];
+            if (o.kf < d.nfixed) continue;
+            const int pl = o.pt - p0, row = 6 * (o.kf - d.nfixed) + a;
+            const double* H = D + d.oHpl + (size_t)e * 18 + a * 3;
+            const double h0 = H[0], h1 = H[1], h2 = H[2];
+            const double* inv = Hi + pl * 9;
+            double* wr = Wl + row * BA_LD + 3 * pl;
+            double* yr = Yl + row * BA_LD + 3 * pl;
+            wr[0] = h0; wr[1] = h1; wr[2] = h2;
+            yr[0] = h0 * inv[0] + h1 * inv[3] + h2 * inv[6];
+            yr[1] = h0 * inv[1] + h1 * inv[4] + h2 * inv[7];
+            yr[2] = h0 * inv[2] + h1 * inv[5] + h2 * inv[8];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        /* issue the next chunk's loads, and the edge range of the one after, before the MFMA phase */
+        const int e0c = e0, e1c = e1;
+        if (ch + stride < d.nChunks) preload(ch + stride, e0n, e1n);
+        e0 = e0n; e1 = e1n;
+        if (ch + 2 * stride < d.nChunks) {
+            e0n = I[d.oPtStart + (ch + 2 * stride) * BA_CP];
+            e1n = I[d.oPtStart + min((ch + 2 * stride) * BA_CP + BA_CP, d.npt)];
+        }
+        const int kofs = lane >> 4, l15 = lane & 15;
+#pragma unroll
+        for (int kk = 0; kk < BA_CP * 3; kk += 4) {
+            double av[BA_MAXT], bv[BA_MAXT];
+#pragma unroll
+            for (int t = 0; t < BA_MAXT; t++) {
+                av[t] = (t < R) ? Yl[(16 * t + l15) * BA_LD + kk + kofs] : 0.0;
+                bv[t] = (t <= cR && t < BA_MAXT) ? Wl[(16 * t + l15) * BA_LD + kk + kofs] : 0.0;
+            }
+#pragma unroll
+            for (int r = 0; r < BA_MAXT; r++)
+#pragma unroll
+                for (int c = 0; c < BA_MAXT; c++)
+                    if (r < R && (c <= r || c == cR))
+                        acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[r], bv[c], acc[r][c], 0, 0, 0);
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        /* clear what this chunk wrote (positions kept in registers) */
+#pragma unroll
+        for (int j = 0; j < MAXI; j++)
+            if (cpos[j] >= 0) {
+                const int off = cpos[j] & 0xffffff;
+                Wl[off] = Wl[off + 1] = Wl[off + 2] = 0;
+                Yl[off] = Yl[off + 1] = Yl[off + 2] = 0;
+            }
+        for (int it = lane + MAXI * 64; it < (e1c - e0c) * 6; it += 64) {
+            const int e = e0c + it / 6, a = it - (it / 6) * 6;
+            const tb_ba_obs o = obs[e];
+            if (o.kf < d.nfixed) continue;
+            const int off = (6 * (o.kf - d.nfixed) + a) * BA_LD + 3 * (o.pt - p0);
+            Wl[off] = Wl[off + 1] = Wl[off + 2] = 0;
+            Yl[off] = Yl[off + 1] = Yl[off + 2] = 0;
+        }
+        if (lane < p1 - p0)
+            for (int c = 0; c < 3; c++) Wl[d.np * BA_LD + 3 * lane + c] = 0;
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    }
+    __syncthreads();
+    /* sum the four waves' accumulators through LDS in wave order (fixed shape), then one partial per block.
+     * C/D map of v_mfma_f64_16x16x4: col = lane & 15, row = (lane >> 4) + 4 * reg */
+    double* sum = lds; /* 64 x 64, reuses the tile storage: every wave is past its last tile read */
+    for (int wv = 0; wv < 4; wv++) {
+        if (wave == wv) {
+#pragma unroll
+            for (int r = 0; r < BA_MAXT; r++)
+#pragma unroll
+                for (int c = 0; c < BA_MAXT; c++)
+                    if (r < R && (c <= r || c == cR))
+                        for (int q = 0; q < 4; q++) {
+                            const int idx = (16 * r + (lane >> 4) + 4 * q) * 64 + 16 * c + (lane & 15);
+                            sum[idx] = (wv == 0) ? acc[r][c][q] : sum[idx] + acc[r][c][q];
+                        }
         }
         __syncthreads();
     }
-    /* C/D map of v_mfma_f64_16x16x4: col = lane & 15, row = (lane >> 4) + 4 * reg */
     double* out = D + d.oPartS + (size_t)g * 64 * 64;
-    for (int j = 0; j < 4; j++)
-        for (int r = 0; r < 4; r++) out[(16 * wave + (lane >> 4) + 4 * r) * 64 + 16 * j + (lane & 15)] = acc[j][r];
+    for (int i = tid; i < 64 * 64; i += BA_T) {
+        const int r = i >> 6, c = i & 63, rt = r >> 4, ct = c >> 4;
+        if (rt < R && (ct <= rt || ct == cR)) out[i] = sum[i];
+    }
 }
 
-/* ---- E: assemble S, Cholesky, pose update */
-__global__ void __launch_bounds__(64)
+/* broadcast of one lane's double through the scalar unit (lane index wave-uniform) */
+__device__ __forceinline__ double ba_readlane(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
+/* ---- E: assemble S (lower triangle), Cholesky in registers, pose update */
+__global__ void __launch_bounds__(BA_T)
 k_ba_solve(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) {
     __shared__ double A[64 * 65];
     __shared__ double rhs[64], x[64];
-    __shared__ int ok;
     const int w = blockIdx.x, tid = threadIdx.x;
     BaState* st = states + w;
     if (st->status) return;
     double* D = dw + (size_t)w * d.wstride;
-    const int np = d.np;
+    const int np = d.np, nPart = d.G;
     const double lambda = st->lambda;
-    for (int i = tid; i < np * np; i += 64) {
+    for (int i = tid; i < np * np; i += BA_T) {
         const int r = i / np, c = i - r * np;
+        if (c > r) continue;
         double s = 0;
-        for (int g = 0; g < d.G; g++) s += D[d.oPartS + (size_t)g * 4096 + r * 64 + c];
+#pragma unroll 6
+        for (int g = 0; g < nPart; g++) s += D[d.oPartS + (size_t)g * 4096 + r * 64 + c]; /* ordered sum, loads in flight together */
         double h = 0;
         if (r / 6 == c / 6) h = D[d.oHpp + (size_t)(r / 6) * 36 + (r % 6) * 6 + (c % 6)];
         if (r == c) h += lambda;
         A[r * 65 + c] = h - s;
     }
-    for (int r = tid; r < np; r += 64) {
+    for (int r = tid; r < np; r += BA_T) {
         double s = 0;
-        for (int g = 0; g < d.G; g++) s += D[d.oPartS + (size_t)g * 4096 + r * 64 + np];
+#pragma unroll 6
+        for (int g = 0; g < nPart; g++) s += D[d.oPartS + (size_t)g * 4096 + r * 64 + np];
         rhs[r] = D[d.oBp + r] - s;
     }
-    if (tid == 0) ok = st->sing ? 0 : 1;
     __syncthreads();
-    for (int j = 0; j < np && ok; j++) {
-        if (tid == 0) {
-            const double dj = A[j * 65 + j];
-            if (!(dj > 0) || !isfinite(dj)) ok = 0;
-            else A[j * 65 + j] = sqrt(dj);
-        }
-        __syncthreads();
-        if (!ok) break;
-        const double dj = A[j * 65 + j];
-        for (int i = j + 1 + tid; i < np; i += 64) A[i * 65 + j] /= dj;
-        __syncthreads();
-        for (int i = j + 1 + tid; i < np; i += 64) {
-            const double lij = A[i * 65 + j];
-            for (int k = j + 1; k <= i; k++) A[i * 65 + k] -= lij * A[k * 65 + j];
-        }
-        __syncthreads();
-    }
-    if (tid == 0) {
-        if (ok) {
-            for (int i = 0; i < np; i++) {
-                double s = rhs[i];
-                for (int k = 0; k < i; k++) s -= A[i * 65 + k] * x[k];
-                x[i] = s / A[i * 65 + i];
+    /* One wave factorises and substitutes with the matrix in REGISTERS: lane i holds row i of the 64 x 64
+     * system (rows >= np are identity, so the padded part factors to itself); column j of L is broadcast
+     * with compile-time lane indices (v_readlane), so the O(n^3) loop is straight-line FMA code with no
+     * LDS round trips and no barriers. Right-looking Cholesky on the lower triangle. */
+    if (tid < 64) {
+        const int i = tid;
+        double row[64];
+#pragma unroll
+        for (int k = 0; k < 64; k++) row[k] = (i < np && k < np) ? ((k <= i) ? A[i * 65 + k] : 0.0) : ((k == i) ? 1.0 : 0.0);
+        bool good = st->sing == 0;
+#pragma unroll
+        for (int j = 0; j < 64; j++) {
+            const double dj = ba_readlane(row[j], j);
+            if (!(dj > 0) || !isfinite(dj)) good = false;
+            const double sj = sqrt(good ? dj : 1.0);
+            const double isj = 1.0 / sj;
+            row[j] = (i == j) ? sj : row[j] * isj; /* lanes i < j hold unused upper-triangle values */
+#pragma unroll
+            for (int k = j + 1; k < 64; k++) {
+                const double lkj = ba_readlane(row[j], k); /* L[k][j] */
+                row[k] -= row[j] * lkj;                    /* only lanes i >= k are ever read back */
             }
-            for (int i = np - 1; i >= 0; i--) {
-                double s = x[i];
-                for (int k = i + 1; k < np; k++) s -= A[k * 65 + i] * x[k];
-                x[i] = s / A[i * 65 + i];
-            }
-        } else {
-            for (int i = 0; i < np; i++) x[i] = 0;
         }
-        double sc = 0;
-        for (int i = 0; i < np; i++) { D[d.oXp + i] = x[i]; sc += x[i] * (lambda * x[i] + D[d.oBp + i]); }
-        st->scale_p = sc;
-        st->ok2 = ok;
+        double xi = (i < np) ? rhs[i] : 0.0;
+#pragma unroll
+        for (int j = 0; j < 64; j++) { /* forward: L y = rhs */
+            const double yj = ba_readlane(xi, j) / ba_readlane(row[j], j);
+            if (i == j) xi = yj;
+            else if (i > j) xi -= row[j] * yj;
+        }
+#pragma unroll
+        for (int j = 63; j >= 0; j--) { /* backward: L^T x = y; L[k][j] sits in lane k, register j */
+            const double sum = po_wave_sum((i > j) ? row[j] * xi : 0.0); /* sum_{k>j} L[k][j] x_k, fixed tree */
+            const double xj = (ba_readlane(xi, j) - sum) / ba_readlane(row[j], j);
+            if (i == j) xi = xj;
+        }
+        if (!good) xi = 0;
+        double term = 0.0;
+        if (i < np) {
+            x[i] = xi;
+            D[d.oXp + i] = xi;
+            term = xi * (lambda * xi + D[d.oBp + i]);
+        }
+        const double sc = po_wave_sum(term);
+        if (i == 0) { st->scale_p = sc; st->ok2 = good ? 1 : 0; }
     }
     __syncthreads();
     const double* T = D + d.oT + (size_t)st->cur * d.nkf * 7;
     double* Tn = D + d.oT + (size_t)(st->cur ^ 1) * d.nkf * 7;
-    for (int k = tid; k < d.nkf; k += 64) {
+    for (int k = tid; k < d.nkf; k += BA_T) {
         const PoSE3 Tk = ba_load_se3(T + k * 7);
         if (k < d.nfixed) ba_store_se3(Tn + k * 7, Tk);
         else {
@@ -564,7 +739,7 @@ static void ba_dims(BaDims& d, int W, const double K[4], int nkf, int nfixed, in
     d.nblkP = (npt + BA_T - 1) / BA_T;
     d.kfChunks = (obs_pitch + BA_KFCH - 1) / BA_KFCH;
     d.nChunks = (npt + BA_CP - 1) / BA_CP;
-    d.G = std::min(std::max(256 / std::max(W, 1), 1), std::max(d.nChunks, 1));
+    d.G = std::min(std::max(512 / std::max(W, 1), 1), std::max((d.nChunks + 3) / 4, 1)); /* ~2 resident blocks per CU (register bound) */
     d.fx = K[0]; d.fy = K[1]; d.cx = K[2]; d.cy = K[3];
     unsigned long long o = 0;
     auto take = [&](unsigned long long n) { unsigned long long r = o; o += (n + 1) & ~1ull; return r; };
@@ -615,14 +790,14 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
     BaState* states = (BaState*)((char*)iw + (size_t)W * d.istride * sizeof(int));
     int* running = (int*)((char*)states + (size_t)W * sizeof(BaState));
     hipStream_t s = ctx->stream;
-    const size_t lds = 2 * 64 * BA_LD * sizeof(double);
+    const size_t lds = std::max<size_t>(4 * (size_t)BA_WAVE_LDS, 64 * 64) * sizeof(double);
     static bool attr = false;
     if (!attr) {
         TB_HIP(ctx, hipFuncSetAttribute((const void*)k_ba_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
         attr = true;
     }
     tb_prof_begin(ctx, "k_ba_setup");
-    hipLaunchKernelGGL(k_ba_setup, dim3(W), dim3(BA_T), 0, s, d, d_poses, d_pts, d_obs, d_counts, dw, iw, states);
+    hipLaunchKernelGGL(k_ba_setup, dim3(nkf + 1, W), dim3(BA_T), 0, s, d, d_poses, d_pts, d_obs, d_counts, dw, iw, states);
     tb_prof_end(ctx);
     TB_HIP(ctx, hipGetLastError());
     int host_running = 1, rounds = 0;
@@ -635,16 +810,16 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
             hipLaunchKernelGGL(k_ba_points, dim3(d.nblkP, W), dim3(BA_T), 0, s, d, d_obs, dw, iw, states);
             tb_prof_end(ctx);
             tb_prof_begin(ctx, "k_ba_kf");
-            hipLaunchKernelGGL(k_ba_kf, dim3(d.kfChunks, d.nfree, W), dim3(BA_T), 0, s, d, d_obs, dw, iw, states);
+            hipLaunchKernelGGL(k_ba_kf, dim3(std::min(BA_KFBLK, d.kfChunks), d.nfree, W), dim3(BA_T), 0, s, d, d_obs, dw, iw, states);
             tb_prof_end(ctx);
             tb_prof_begin(ctx, "k_ba_reduce");
-            hipLaunchKernelGGL(k_ba_reduce, dim3(W), dim3(BA_T), 0, s, d, dw, states);
+            hipLaunchKernelGGL(k_ba_reduce, dim3(W), dim3(BA_T), 0, s, d, dw, iw, states);
             tb_prof_end(ctx);
             tb_prof_begin(ctx, "k_ba_schur");
             hipLaunchKernelGGL(k_ba_schur, dim3(d.G, W), dim3(BA_T), lds, s, d, d_obs, dw, iw, states);
             tb_prof_end(ctx);
             tb_prof_begin(ctx, "k_ba_solve");
-            hipLaunchKernelGGL(k_ba_solve, dim3(W), dim3(64), 0, s, d, dw, states);
+            hipLaunchKernelGGL(k_ba_solve, dim3(W), dim3(BA_T), 0, s, d, dw, states);
             tb_prof_end(ctx);
             tb_prof_begin(ctx, "k_ba_update");
             hipLaunchKernelGGL(k_ba_update, dim3(d.nblkP, W), dim3(BA_T), 0, s, d, d_obs, dw, iw, states);

@@ -179,31 +179,278 @@ __device__ __forceinline__ void ft_process(const uint8_t* __restrict__ img, int 
     }
 }
 
-/* ---- cell mode: grid (cells, images) */
+/* ---- cell mode: one WAVEFRONT per 30-px cell, four cells per workgroup, no workgroup barriers.
+ * Per wave: ROI rows staged into a private LDS tile (32-bit loads when the level is 4-byte aligned);
+ *   stage 1  cardinal test (ring positions 0/4/8/12 hold >= 2 adjacent members of any 9-arc) on every
+ *            pixel, two ROI rows per 64-lane pass, survivors ballot-compacted into an LDS list;
+ *   stage 2  full 16-position arc test on the list, compaction in place;
+ *   stage 3  exact scores of the corners into a private score map;
+ *   stage 4  3x3 strict maximum, initTh / minTh choice by wave ballot, emission through one atomic per
+ *            wave-pass.  LDS per wave = tile + score map + list (sized by the plan's largest ROI). */
+struct FastCellsArgs {
+    int nCells;        /* cells per image */
+    int tileStride;    /* bytes per LDS tile row (multiple of 4) */
+    int tileRows;
+    int listCap;       /* interior pixels of the largest ROI */
+    int waveBytes;     /* LDS bytes per wave */
+};
+
+__device__ __forceinline__ void ft_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+
+template <int ARC>
+__device__ __forceinline__ bool ft_is_corner_s(const uint8_t* c, int S, int th) {
+    const int v = c[0];
+    const int hi = v + th, lo = v - th;
+    int r[16];
+    r[0] = c[3 * S];      r[1] = c[3 * S + 1];   r[2] = c[2 * S + 2];   r[3] = c[S + 3];
+    r[4] = c[3];          r[5] = c[-S + 3];      r[6] = c[-2 * S + 2];  r[7] = c[-3 * S + 1];
+    r[8] = c[-3 * S];     r[9] = c[-3 * S - 1];  r[10] = c[-2 * S - 2]; r[11] = c[-S - 3];
+    r[12] = c[-3];        r[13] = c[S - 3];      r[14] = c[2 * S - 2];  r[15] = c[3 * S - 1];
+    uint32_t B = 0, D = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        B |= (uint32_t)(r[k] > hi) << k;
+        D |= (uint32_t)(r[k] < lo) << k;
+    }
+    B |= B << 16;
+    D |= D << 16;
+    uint32_t xb = B & (B >> 1), xd = D & (D >> 1);
+    xb &= xb >> 2; xd &= xd >> 2;
+    xb &= xb >> 4; xd &= xd >> 4;
+    xb &= B >> 8;  xd &= D >> 8;
+    if (ARC == 10) { xb &= B >> 9; xd &= D >> 9; }
+    return ((xb | xd) & 0xffffu) != 0;
+}
+
+template <int ARC>
+__device__ __forceinline__ int ft_score_s(const uint8_t* c, int S) {
+    const int v = c[0];
+    int d[16];
+    d[0] = v - c[3 * S];      d[1] = v - c[3 * S + 1];   d[2] = v - c[2 * S + 2];   d[3] = v - c[S + 3];
+    d[4] = v - c[3];          d[5] = v - c[-S + 3];      d[6] = v - c[-2 * S + 2];  d[7] = v - c[-3 * S + 1];
+    d[8] = v - c[-3 * S];     d[9] = v - c[-3 * S - 1];  d[10] = v - c[-2 * S - 2]; d[11] = v - c[-S - 3];
+    d[12] = v - c[-3];        d[13] = v - c[S - 3];      d[14] = v - c[2 * S - 2];  d[15] = v - c[3 * S - 1];
+    int best = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++) {
+        int mn = d[k], mx = d[k];
+#pragma unroll
+        for (int i = 1; i < ARC; i++) {
+            mn = min(mn, d[(k + i) & 15]);
+            mx = max(mx, d[(k + i) & 15]);
+        }
+        best = max(best, max(mn, -mx));
+    }
+    return best - 1;
+}
+
+template <int ST> /* ST = LDS tile row stride in bytes (0 = runtime value): a constant folds every ring offset into the
+                     ds_read immediate field */
 __global__ void __launch_bounds__(256)
 k_fast_cells(PlanGeom g, const uint8_t* __restrict__ slab, const CellDesc* __restrict__ cells,
-             uint32_t* __restrict__ cand, int32_t* __restrict__ candCount, int init_th, int min_th) {
-    const CellDesc c = cells[blockIdx.x];
+             uint32_t* __restrict__ cand, int32_t* __restrict__ candCount, int init_th, int min_th, FastCellsArgs A) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    /* wave-uniform values are made scalar so the cell / level descriptors come through the scalar cache */
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int cellId = blockIdx.x * 4 + wave;
+    if (cellId >= A.nCells) return;
     const int b = blockIdx.y;
+    const CellDesc c = cells[cellId];
     const LevelGeom& L = g.lv[c.level];
     int stride;
     const uint8_t* img = tb_level_ptr(g, slab, b, c.level, &stride);
-    FastRegion R;
-    R.lx0 = c.x0; R.ly0 = c.y0; R.lx1 = c.x1; R.ly1 = c.y1;
-    R.sx0 = c.x0 + 3; R.sy0 = c.y0 + 3; R.sx1 = c.x1 - 3; R.sy1 = c.y1 - 3;
-    R.ox0 = R.sx0; R.oy0 = R.sy0; R.ox1 = R.sx1; R.oy1 = R.sy1;
-    ft_process<9>(img, stride, R, init_th, min_th, true, true, TB_BORDER, TB_BORDER,
-                  cand + (size_t)b * g.candPerImage + L.candOff, L.candCap, candCount + b * TB_MAX_LEVELS + c.level);
+    const int S = ST ? ST : A.tileStride;
+    uint8_t* tile = smem + (size_t)wave * A.waveBytes;
+    uint8_t* sc = tile + S * A.tileRows;
+    uint16_t* list = reinterpret_cast<uint16_t*>(sc + S * A.tileRows);
+
+    /* ---- stage 0: ROI rows -> LDS. LDS column 0 = image column ax0 (x0 rounded down to 4) */
+    const int rw = c.x1 - c.x0, rh = c.y1 - c.y0;
+    const int ax0 = c.x0 & ~3, cx0 = c.x0 - ax0;
+    const int nd = (cx0 + rw + 3) >> 2; /* dwords per row */
+    const bool aligned = ((stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(img) & 3) == 0) && (ax0 + nd * 4 <= stride);
+    if (aligned) {
+        const int per = 64 / nd; /* rows per pass (nd <= 18) */
+        const int rr = lane / nd, dd = lane - rr * nd;
+        const uint8_t* src = img + (size_t)c.y0 * stride + ax0 + 4 * dd;
+        for (int y0 = 0; y0 < rh; y0 += 8 * per) { /* up to 8 row loads in flight per lane before the LDS stores */
+            uint32_t v[8];
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int y = y0 + j * per + rr;
+                v[j] = 0;
+                if (rr < per && y < rh) v[j] = *reinterpret_cast<const uint32_t*>(src + (size_t)y * stride);
+            }
+#pragma unroll
+            for (int j = 0; j < 8; j++) {
+                const int y = y0 + j * per + rr;
+                if (rr < per && y < rh) {
+                    *reinterpret_cast<uint32_t*>(tile + y * S + 4 * dd) = v[j];
+                    *reinterpret_cast<uint32_t*>(sc + y * S + 4 * dd) = 0;
+                }
+            }
+        }
+    } else {
+        for (int y = 0; y < rh; y++)
+            for (int x = lane; x < nd * 4; x += 64) {
+                const int ax = ax0 + x;
+                tile[y * S + x] = (ax >= c.x0 && ax < c.x1) ? img[(size_t)(c.y0 + y) * stride + ax] : 0;
+                sc[y * S + x] = 0;
+            }
+    }
+    ft_lds_fence();
+
+    /* ---- stage 1: cardinal test on every scanned pixel, FOUR pixels per lane, SWAR on 16-bit sub-lanes.
+     * With V the centre, X a ring pixel, t the threshold, per 16-bit lane:
+     *   X > V + t  <=>  bit 9 of  X + (511 - t - V)        (value in [1, 766]: no carry between lanes)
+     *   X < V - t  <=>  bit 9 of  (V + 511 - t) - X        (value in [1, 766]: no borrow)
+     * A 9-arc holds two adjacent cardinals, i.e. one of {0, 8} and one of {4, 12}. */
+    const int sw = rw - 6, sh = rh - 6;
+    const int thA = min(init_th, min_th);
+    int nlist = 0;
+    if (sw > 0 && sh > 0) {
+        const int cA = cx0 + 3, cB = cx0 + rw - 3;   /* scanned LDS columns [cA, cB) */
+        const int gA = cA >> 2, ng = ((cB - 1) >> 2) - gA + 1;
+        const int rowsPer = 64 / ng;
+        const int rr = lane / ng, gg = lane - rr * ng;
+        const uint32_t K = (uint32_t)(511 - thA) * 0x00010001u;
+        const uint32_t M = 0x00ff00ffu;
+        const int col0 = 4 * (gA + gg);
+        /* valid pixels of this lane's group */
+        uint32_t vmask = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) vmask |= (uint32_t)((col0 + i >= cA) && (col0 + i < cB)) << i;
+        for (int y = 0; y < sh; y += rowsPer) {
+            const int yy = y + rr;
+            uint32_t m = 0;
+            const int base = (3 + yy) * S + col0;
+            if (rr < rowsPer && yy < sh) {
+                const uint32_t C = *reinterpret_cast<const uint32_t*>(tile + base);
+                const uint32_t Lw = *reinterpret_cast<const uint32_t*>(tile + base - 4);
+                const uint32_t Rw = *reinterpret_cast<const uint32_t*>(tile + base + 4);
+                const uint32_t Tt = *reinterpret_cast<const uint32_t*>(tile + base - 3 * S);
+                const uint32_t Bt = *reinterpret_cast<const uint32_t*>(tile + base + 3 * S);
+                const uint32_t X12 = __builtin_amdgcn_alignbyte(C, Lw, 1);
+                const uint32_t X4 = __builtin_amdgcn_alignbyte(Rw, C, 3);
+                const uint32_t VE = C & M, VO = (C >> 8) & M;
+                const uint32_t AE = K - VE, AO = K - VO, CE = K + VE, CO = K + VO;
+                uint32_t x, xe, xo;
+                x = Bt; xe = x & M; xo = (x >> 8) & M;
+                uint32_t b08e = xe + AE, b08o = xo + AO, d08e = CE - xe, d08o = CO - xo;
+                x = Tt; xe = x & M; xo = (x >> 8) & M;
+                b08e |= xe + AE; b08o |= xo + AO; d08e |= CE - xe; d08o |= CO - xo;
+                x = X4; xe = x & M; xo = (x >> 8) & M;
+                uint32_t b4e = xe + AE, b4o = xo + AO, d4e = CE - xe, d4o = CO - xo;
+                x = X12; xe = x & M; xo = (x >> 8) & M;
+                b4e |= xe + AE; b4o |= xo + AO; d4e |= CE - xe; d4o |= CO - xo;
+                const uint32_t re = ((b08e & b4e) | (d08e & d4e)) & 0x02000200u;
+                const uint32_t ro = ((b08o & b4o) | (d08o & d4o)) & 0x02000200u;
+                m = (((re >> 9) & 1u) | (((ro >> 9) & 1u) << 1) | (((re >> 25) & 1u) << 2) | (((ro >> 25) & 1u) << 3)) & vmask;
+            }
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                const bool pass = (m >> i) & 1u;
+                const unsigned long long bm = __ballot(pass);
+                if (pass) list[nlist + __popcll(bm & ((1ull << lane) - 1))] = (uint16_t)(base + i);
+                nlist += __popcll(bm);
+            }
+        }
+    }
+    ft_lds_fence();
+
+    /* ---- stage 2: full arc test on the survivors, compaction in place (reads run ahead of the writes) */
+    int ncorner = 0;
+    for (int base = 0; base < nlist; base += 64) {
+        const int i = base + lane;
+        bool cn = false;
+        int idx = 0;
+        if (i < nlist) {
+            idx = list[i];
+            cn = ft_is_corner_s<9>(tile + idx, S, thA);
+        }
+        const unsigned long long m = __ballot(cn);
+        ft_lds_fence();
+        if (cn) list[ncorner + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)idx;
+        ncorner += __popcll(m);
+        ft_lds_fence();
+    }
+
+    /* ---- stage 3: exact scores */
+    for (int i = lane; i < ncorner; i += 64) {
+        const int idx = list[i];
+        sc[idx] = (uint8_t)min(max(ft_score_s<9>(tile + idx, S), 0), 255);
+    }
+    ft_lds_fence();
+
+    /* ---- stage 4: NMS, threshold choice, emit */
+    bool any_hi = false;
+    for (int base = 0; base < ncorner; base += 64) {
+        const int i = base + lane;
+        bool hit = false;
+        if (i < ncorner) {
+            const int idx = list[i];
+            const int s = sc[idx];
+            const bool keep = s > 0 && s > sc[idx - 1] && s > sc[idx + 1] && s > sc[idx - S - 1] && s > sc[idx - S] &&
+                              s > sc[idx - S + 1] && s > sc[idx + S - 1] && s > sc[idx + S] && s > sc[idx + S + 1];
+            if (!keep) list[i] = 0xffff;
+            else hit = s >= init_th;
+        }
+        any_hi = any_hi || (__ballot(hit) != 0);
+    }
+    ft_lds_fence();
+    const int th = any_hi ? init_th : min_th;
+    uint32_t* out = cand + (size_t)b * g.candPerImage + L.candOff;
+    int* count = candCount + b * TB_MAX_LEVELS + c.level;
+    for (int base = 0; base < ncorner; base += 64) {
+        const int i = base + lane;
+        bool e = false;
+        uint32_t rec = 0;
+        if (i < ncorner) {
+            const int idx = list[i];
+            if (idx != 0xffff) {
+                const int s = sc[idx];
+                if (s >= th) {
+                    const int y = idx / S, x = idx - y * S;
+                    e = true;
+                    rec = ((uint32_t)s << 24) | ((uint32_t)(c.y0 + y - TB_BORDER) << 12) | (uint32_t)(ax0 + x - TB_BORDER);
+                }
+            }
+        }
+        const unsigned long long m = __ballot(e);
+        if (m) {
+            int wbase = 0;
+            if (lane == 0) wbase = atomicAdd(count, __popcll(m));
+            wbase = __shfl(wbase, 0, TB_WAVE);
+            if (e) {
+                const int slot = wbase + __popcll(m & ((1ull << lane) - 1));
+                if (slot < L.candCap) out[slot] = rec;
+            }
+        }
+    }
 }
 
 int tbk_fast_cells(tb_extractor* ex, int n, int init_th, int min_th) {
     tb_ctx* ctx = ex->ctx;
     TB_HIP(ctx, hipMemsetAsync(ex->d_candCount, 0, sizeof(int32_t) * TB_MAX_LEVELS * n, ctx->stream));
     if (ex->nCellsTotal == 0) return TB_OK;
-    dim3 grid(ex->nCellsTotal, n);
+    FastCellsArgs A;
+    A.nCells = ex->nCellsTotal;
+    A.tileStride = (ex->maxRoiW + 3 + 3 + 4) & ~3; /* ROI + alignment slack, multiple of 4 */
+    A.tileRows = ex->maxRoiH;
+    A.listCap = (ex->maxRoiW - 6) * (ex->maxRoiH - 6);
+    if (A.listCap < 64) A.listCap = 64;
+    dim3 grid((ex->nCellsTotal + 3) / 4, n);
+    void (*kern)(PlanGeom, const uint8_t*, const CellDesc*, uint32_t*, int32_t*, int, int, FastCellsArgs) = k_fast_cells<0>;
+    if (A.tileStride <= 44) { A.tileStride = 44; kern = k_fast_cells<44>; }
+    else if (A.tileStride <= 48) { A.tileStride = 48; kern = k_fast_cells<48>; }
+    else if (A.tileStride <= 56) { A.tileStride = 56; kern = k_fast_cells<56>; }
+    else if (A.tileStride <= 76) { A.tileStride = 76; kern = k_fast_cells<76>; }
+    A.waveBytes = (2 * A.tileStride * A.tileRows + 2 * A.listCap + 15) & ~15;
+    const size_t lds = 4 * (size_t)A.waveBytes;
+    TB_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
     tb_prof_begin(ctx, "k_fast_cells");
-    hipLaunchKernelGGL(k_fast_cells, grid, dim3(256), 0, ctx->stream, ex->g, ex->d_slab, ex->d_cells, ex->d_cand,
-                       ex->d_candCount, init_th, min_th);
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, ex->g, ex->d_slab, ex->d_cells, ex->d_cand, ex->d_candCount,
+                       init_th, min_th, A);
     tb_prof_end(ctx);
     TB_HIP(ctx, hipGetLastError());
     return TB_OK;

@@ -330,6 +330,8 @@ int tb_extractor_create(tb_ctx* ctx, int width, int height, int nlevels, const f
                     c.cellIdx = i * L.nCols + j;
                     cells.push_back(c);
                     L.nCells++;
+                    ex->maxRoiW = std::max(ex->maxRoiW, (int)(c.x1 - c.x0));
+                    ex->maxRoiH = std::max(ex->maxRoiH, (int)(c.y1 - c.y0));
                 }
             }
             /* DistributeOctTree, ORBextractor.cpp:498-500 (nIni < 1 clamped, see k_octree.hip) */

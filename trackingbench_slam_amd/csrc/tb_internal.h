@@ -107,6 +107,7 @@ struct tb_extractor {
     uint8_t* d_slab = nullptr;          /* [max_images][slabBytes] */
     uint8_t* d_img0_copy = nullptr;     /* [max_images][h][stride0] for host-provided frames */
     CellDesc* d_cells = nullptr; int nCellsTotal = 0;
+    int maxRoiW = 7, maxRoiH = 7;        /* largest FAST cell ROI of the plan */
     ResizeX* d_rx[TB_MAX_LEVELS]; ResizeY* d_ry[TB_MAX_LEVELS];
     uint32_t* d_cand = nullptr;         /* [max_images][candPerImage] packed score<<24|y<<12|x */
     int32_t* d_candCount = nullptr;     /* [max_images][TB_MAX_LEVELS] */

@@ -16,19 +16,27 @@ __device__ inline void po_quat_from_R(const double* R, PoSE3& s) {
         s.qx = (R[7] - R[5]) * t;
         s.qy = (R[2] - R[6]) * t;
         s.qz = (R[3] - R[1]) * t;
-    } else {
-        int i = 0;
-        if (R[4] > R[0]) i = 1;
-        if (R[8] > R[i * 3 + i]) i = 2;
-        const int j = (i + 1) % 3, k = (j + 1) % 3;
-        t = sqrt(R[i * 3 + i] - R[j * 3 + j] - R[k * 3 + k] + 1.0);
-        double c[3];
-        c[i] = 0.5 * t;
+    } else if (R[0] >= R[4] && R[0] >= R[8]) { /* Eigen picks the largest diagonal entry: i = 0 */
+        t = sqrt(R[0] - R[4] - R[8] + 1.0);
+        s.qx = 0.5 * t;
         t = 0.5 / t;
-        s.qw = (R[k * 3 + j] - R[j * 3 + k]) * t;
-        c[j] = (R[j * 3 + i] + R[i * 3 + j]) * t;
-        c[k] = (R[k * 3 + i] + R[i * 3 + k]) * t;
-        s.qx = c[0]; s.qy = c[1]; s.qz = c[2];
+        s.qw = (R[7] - R[5]) * t;
+        s.qy = (R[3] + R[1]) * t;
+        s.qz = (R[6] + R[2]) * t;
+    } else if (R[4] > R[0] && R[4] >= R[8]) { /* i = 1 */
+        t = sqrt(R[4] - R[8] - R[0] + 1.0);
+        s.qy = 0.5 * t;
+        t = 0.5 / t;
+        s.qw = (R[2] - R[6]) * t;
+        s.qz = (R[7] + R[5]) * t;
+        s.qx = (R[1] + R[3]) * t;
+    } else { /* i = 2 */
+        t = sqrt(R[8] - R[0] - R[4] + 1.0);
+        s.qz = 0.5 * t;
+        t = 0.5 / t;
+        s.qw = (R[3] - R[1]) * t;
+        s.qx = (R[2] + R[6]) * t;
+        s.qy = (R[5] + R[7]) * t;
     }
 }
 __device__ inline void po_normalize(PoSE3& s) {
@@ -138,13 +146,15 @@ __device__ __forceinline__ double po_wave_sum(double v) {
 }
 /* block sum of NV per-thread values; result valid in every thread; red: LDS >= 4*NV doubles */
 template <int NV>
-__device__ inline void po_block_sum(double* v, double* red) {
+__device__ __forceinline__ void po_block_sum(double (&v)[NV], double* red) {
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
 #pragma unroll
     for (int i = 0; i < NV; i++) v[i] = po_wave_sum(v[i]);
     __syncthreads();
-    if (lane == 0)
+    if (lane == 0) {
+#pragma unroll
         for (int i = 0; i < NV; i++) red[wave * NV + i] = v[i];
+    }
     __syncthreads();
 #pragma unroll
     for (int i = 0; i < NV; i++) v[i] = (red[i] + red[NV + i]) + (red[2 * NV + i] + red[3 * NV + i]);
