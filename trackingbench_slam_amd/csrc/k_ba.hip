@@ -519,6 +519,7 @@ __device__ __forceinline__ double ba_readlane(double v, int lane) {
 }
 
 /* ---- E: assemble S (lower triangle), Cholesky in registers, pose update */
+template <int NS> /* padded system size: np rounded up to 16 */
 __global__ void __launch_bounds__(BA_T)
 k_ba_solve(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) {
     __shared__ double A[64 * 65];
@@ -553,34 +554,36 @@ k_ba_solve(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) {
      * LDS round trips and no barriers. Right-looking Cholesky on the lower triangle. */
     if (tid < 64) {
         const int i = tid;
-        double row[64];
+        double row[NS];
 #pragma unroll
-        for (int k = 0; k < 64; k++) row[k] = (i < np && k < np) ? ((k <= i) ? A[i * 65 + k] : 0.0) : ((k == i) ? 1.0 : 0.0);
+        for (int k = 0; k < NS; k++) row[k] = (i < np && k < np) ? ((k <= i) ? A[i * 65 + k] : 0.0) : ((k == i) ? 1.0 : 0.0);
         bool good = st->sing == 0;
+        double dinv = 1.0; /* 1 / L[i][i] of this lane's row */
 #pragma unroll
-        for (int j = 0; j < 64; j++) {
+        for (int j = 0; j < NS; j++) {
             const double dj = ba_readlane(row[j], j);
             if (!(dj > 0) || !isfinite(dj)) good = false;
             const double sj = sqrt(good ? dj : 1.0);
             const double isj = 1.0 / sj;
+            if (i == j) dinv = isj;
             row[j] = (i == j) ? sj : row[j] * isj; /* lanes i < j hold unused upper-triangle values */
 #pragma unroll
-            for (int k = j + 1; k < 64; k++) {
+            for (int k = j + 1; k < NS; k++) {
                 const double lkj = ba_readlane(row[j], k); /* L[k][j] */
                 row[k] -= row[j] * lkj;                    /* only lanes i >= k are ever read back */
             }
         }
         double xi = (i < np) ? rhs[i] : 0.0;
 #pragma unroll
-        for (int j = 0; j < 64; j++) { /* forward: L y = rhs */
-            const double yj = ba_readlane(xi, j) / ba_readlane(row[j], j);
+        for (int j = 0; j < NS; j++) { /* forward: L y = rhs */
+            const double yj = ba_readlane(xi, j) * ba_readlane(dinv, j);
             if (i == j) xi = yj;
             else if (i > j) xi -= row[j] * yj;
         }
 #pragma unroll
-        for (int j = 63; j >= 0; j--) { /* backward: L^T x = y; L[k][j] sits in lane k, register j */
-            const double sum = po_wave_sum((i > j) ? row[j] * xi : 0.0); /* sum_{k>j} L[k][j] x_k, fixed tree */
-            const double xj = (ba_readlane(xi, j) - sum) / ba_readlane(row[j], j);
+        for (int j = NS - 1; j >= 0; j--) { /* backward: L^T x = y; L[k][j] sits in lane k, register j */
+            const double sum = po_wave_sum((i > j && i < NS) ? row[j] * xi : 0.0); /* sum_{k>j} L[k][j] x_k, fixed tree */
+            const double xj = (ba_readlane(xi, j) - sum) * ba_readlane(dinv, j);
             if (i == j) xi = xj;
         }
         if (!good) xi = 0;
@@ -819,7 +822,10 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
             hipLaunchKernelGGL(k_ba_schur, dim3(d.G, W), dim3(BA_T), lds, s, d, d_obs, dw, iw, states);
             tb_prof_end(ctx);
             tb_prof_begin(ctx, "k_ba_solve");
-            hipLaunchKernelGGL(k_ba_solve, dim3(W), dim3(BA_T), 0, s, d, dw, states);
+            if (d.np <= 16) hipLaunchKernelGGL(k_ba_solve<16>, dim3(W), dim3(BA_T), 0, s, d, dw, states);
+            else if (d.np <= 32) hipLaunchKernelGGL(k_ba_solve<32>, dim3(W), dim3(BA_T), 0, s, d, dw, states);
+            else if (d.np <= 48) hipLaunchKernelGGL(k_ba_solve<48>, dim3(W), dim3(BA_T), 0, s, d, dw, states);
+            else hipLaunchKernelGGL(k_ba_solve<64>, dim3(W), dim3(BA_T), 0, s, d, dw, states);
             tb_prof_end(ctx);
             tb_prof_begin(ctx, "k_ba_update");
             hipLaunchKernelGGL(k_ba_update, dim3(d.nblkP, W), dim3(BA_T), 0, s, d, d_obs, dw, iw, states);

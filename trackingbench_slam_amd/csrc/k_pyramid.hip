@@ -47,9 +47,85 @@ k_resize(PlanGeom g, uint8_t* __restrict__ slab, const ResizeX* __restrict__ rx,
     *reinterpret_cast<uint32_t*>(dst + dx0) = packed;
 }
 
+/* LDS-staged variant: one wavefront per tile of 256 x RS_ROWS destination pixels. Every source row the
+ * tile needs is copied once, as aligned dwords (coalesced), into LDS; the wave's four coefficient entries per
+ * lane stay in registers across the tile's rows, and the 16 taps of every output group come from LDS instead
+ * of 16 scattered global byte loads. Requires 4-byte aligned source rows; tile footprint given by the launcher. */
+#define RS_ROWS 8
+
+__global__ void __launch_bounds__(64)
+k_resize_lds(PlanGeom g, uint8_t* __restrict__ slab, const ResizeX* __restrict__ rx, const ResizeY* __restrict__ ry,
+             int level, int rowBytes) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t rows[];
+    const int b = blockIdx.z, dy0 = blockIdx.y * RS_ROWS, lane = threadIdx.x;
+    const LevelGeom& D = g.lv[level];
+    const int X0 = blockIdx.x * 256;
+    int sstride;
+    const uint8_t* src = tb_level_ptr(g, slab, b, level - 1, &sstride);
+    const int dy1 = min(dy0 + RS_ROWS, D.h) - 1;
+    const int xl = min(X0 + 255, D.w - 1);
+    const int sxa = rx[X0].sx & ~3, sxb = rx[xl].sx1;
+    const int ndw = ((sxb - sxa) >> 2) + 1;
+    const int sya = ry[dy0].sy0, syb = ry[dy1].sy1;
+    const int nrows = syb - sya + 1;
+    for (int r = 0; r < nrows; r++) {
+        const uint8_t* S = src + (size_t)(sya + r) * sstride + sxa;
+        for (int dd = lane; dd < ndw; dd += 64)
+            *reinterpret_cast<uint32_t*>(rows + r * rowBytes + 4 * dd) = *reinterpret_cast<const uint32_t*>(S + 4 * dd);
+    }
+    __syncthreads();
+    const int dx0 = X0 + 4 * lane;
+    if (dx0 >= D.stride) return;
+    int o0[4], o1[4], a0[4], a1[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int dx = min(dx0 + i, D.w - 1);
+        const ResizeX xx = rx[dx];
+        o0[i] = xx.sx - sxa; o1[i] = xx.sx1 - sxa; a0[i] = xx.a0; a1[i] = xx.a1;
+    }
+    for (int dy = dy0; dy <= dy1; dy++) {
+        const ResizeY yy = ry[dy];
+        const uint8_t* R0 = rows + (yy.sy0 - sya) * rowBytes;
+        const uint8_t* R1 = rows + (yy.sy1 - sya) * rowBytes;
+        const int b0 = yy.b0, b1 = yy.b1;
+        uint32_t packed = 0;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (dx0 + i < D.w) {
+                const int r0 = R0[o0[i]] * a0[i] + R0[o1[i]] * a1[i];
+                const int r1 = R1[o0[i]] * a0[i] + R1[o1[i]] * a1[i];
+                int v = (((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2;
+                v = min(max(v, 0), 255);
+                packed |= (uint32_t)v << (8 * i);
+            }
+        }
+        *reinterpret_cast<uint32_t*>(slab + (size_t)b * g.slabBytes + D.off + (size_t)dy * D.stride + dx0) = packed;
+    }
+}
+
 int tbk_resize_level(tb_extractor* ex, int level, int n) {
     tb_ctx* ctx = ex->ctx;
     const LevelGeom& D = ex->g.lv[level];
+    const LevelGeom& Sg = ex->g.lv[level - 1];
+    /* source alignment check for the LDS-staged kernel */
+    const bool ext0 = (level - 1 == 0) && ex->g.img0 != nullptr;
+    const int sstride = ext0 ? ex->g.img0_stride : Sg.stride;
+    const uintptr_t sbase = ext0 ? reinterpret_cast<uintptr_t>(ex->g.img0) : 0;
+    const unsigned long long spitch = ext0 ? ex->g.img0_pitch : 0;
+    const bool aligned = (sstride % 4 == 0) && (sbase % 4 == 0) && (spitch % 4 == 0) && (sstride >= ((Sg.w + 3) & ~3));
+    const double rx_ratio = (double)Sg.w / (double)D.w, ry_ratio = (double)Sg.h / (double)D.h;
+    const int rowBytes = (((int)(256.0 * rx_ratio) + 16 + 3) & ~3) + 4;
+    const int srows = (int)(RS_ROWS * ry_ratio) + 3;
+    const size_t lds = (size_t)rowBytes * srows;
+    if (aligned && lds <= 48 * 1024) {
+        dim3 grid((D.stride + 255) / 256, (D.h + RS_ROWS - 1) / RS_ROWS, n);
+        tb_prof_begin(ctx, "k_resize");
+        hipLaunchKernelGGL(k_resize_lds, grid, dim3(64), lds, ctx->stream, ex->g, ex->d_slab, ex->d_rx[level], ex->d_ry[level], level,
+                           rowBytes);
+        tb_prof_end(ctx);
+        TB_HIP(ctx, hipGetLastError());
+        return TB_OK;
+    }
     const int groups = (D.stride >> 2) * D.h;
     dim3 grid((groups + 255) / 256, n);
     tb_prof_begin(ctx, "k_resize");
