@@ -150,3 +150,37 @@ def test_fastgrid_extract(ctx, kitti_pair, golden):
     occ = np.zeros(2000, np.uint8); occ[::3] = 1
     for target, th, o in ((1000, 20.0, None), (200, 5.0, None), (500, 10.0, occ)):
         _eq_struct(ctx.fastgrid_extract(lv, isf, target, th, o), oracle.fastgrid_extract(lv, isf, target, th, o))
+
+
+def test_config_4k_stereo_8000_keypoints(ctx):
+    """BASELINE.json configs[4] geometry: 3840x2160, 8 levels, N=8000 (quadtree lists near the LDS capacity)."""
+    img = synth.frame(50, 3840, 2160)
+    ex = capi.Extractor(ctx, 3840, 2160, 8, 0.8, 1, 8000)
+    ex.set_images_host(img)
+    ex.build_pyramid(1)
+    ex.orb(1, 8000, 80, 30)
+    k, d = ex.results(0, 9000)
+    lv, sf = oracle.pyramid(img, 8, 0.8)
+    for l in (1, 4, 7):
+        assert np.array_equal(ex.get_level(0, l), lv[l])
+    ko, do, _ = oracle.orb_extract(lv, sf, 8000, 80, 30)
+    _eq_struct(k, ko)
+    assert np.array_equal(d, do)
+    assert len(k) >= 8000
+    ex.close()
+
+
+def test_config_640x480_mono_1000_keypoints(ctx):
+    """BASELINE.json configs[1]: 640x480 mono, 8 levels, 1000 keypoints, extract + match between two frames."""
+    a, b = synth.frame(60, 640, 480, stereo=True)
+    ra, rb = [], []
+    for img in (a, b):
+        lv, sf = ctx.pyramid(img, 8, 0.8)
+        k, d, _ = ctx.orb_extract(lv, sf, 1000, 80, 30)
+        lvo, _ = oracle.pyramid(img, 8, 0.8)
+        ko, do, _ = oracle.orb_extract(lvo, sf, 1000, 80, 30)
+        _eq_struct(k, ko)
+        assert np.array_equal(d, do)
+        ra.append(d)
+    m = ctx.search_by_bf(ra[0], ra[1], 10, 30)
+    _eq_struct(m, oracle.search_by_bf(ra[0], ra[1], 10, 30))
