@@ -59,9 +59,25 @@ def algorithmic_bytes(kernel, w, h, nlevels, scale, target, nimg, npairs):
     return 0
 
 
-def schur_flops_per_launch(ba_pts, nwindows):
-    """k_ba_schur: dense 64x64 tile x (3 densified columns per point) per window per LM trial."""
-    return 2.0 * 64 * 64 * 3 * ba_pts * nwindows
+def schur_flops_per_launch(ba_pts, nwindows, ba_kf, nfixed=2):
+    """k_ba_schur, ALGORITHMIC flops of one launch (one LM trial of every window): the lower triangle of the
+    np x np Schur block plus the reduced right-hand side, K = 3 densified columns per point. (The kernel
+    executes more: 16x16 tiles pad np = 48 to 9 tiles of 256 entries.)"""
+    np_ = 6 * (ba_kf - nfixed)
+    return 2.0 * (np_ * (np_ + 1) / 2 + np_) * 3 * ba_pts * nwindows
+
+
+def pmc_traffic(kernel, frames):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/, collected at 64
+    frames per step with the guide's gfx950 FETCH_SIZE correction), scaled to this run's batch; None if absent."""
+    path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")
+    try:
+        with open(path) as f:
+            rec = json.load(f)["kernels"]
+        key = kernel if kernel in rec else {"k_resize": "k_resize_lds"}.get(kernel, kernel)
+        return int(rec[key]["hbm_bytes_per_launch"] * frames / 64.0)
+    except (OSError, KeyError, ValueError):
+        return None
 
 
 def cpu_baseline(args, seconds=20.0):
@@ -166,16 +182,16 @@ def main():
         avg_ms_per_step = tot_ms / max(args.steps, 1)
         kern_ms = {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items())}
         if name == "k_ba_schur":
-            fl = schur_flops_per_launch(args.ba_pts, args.frames)
+            fl = schur_flops_per_launch(args.ba_pts, args.frames, args.ba_kf)
             achieved = fl / 1e12 / (tot_ms / max(calls, 1) / 1e3)
             roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": F64_MFMA_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(achieved / F64_MFMA_PEAK_TFLOPS, 5), "traffic": None,
+                        "unit": "TFLOP/s", "frac": round(achieved / F64_MFMA_PEAK_TFLOPS, 5), "traffic": pmc_traffic(name, args.frames),
                         "launches_per_step": launches_per_step, "avg_launch_ms": round(tot_ms / max(calls, 1), 5),
                         "algorithmic_flops_per_launch": fl, "kernels_ms_per_step": kern_ms}
         else:
             achieved = (abytes / 1e9) / (avg_ms_per_step / 1e3) if avg_ms_per_step > 0 else 0.0
             roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": None,
+                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(name, args.frames),
                         "launches_per_step": launches_per_step, "avg_launch_ms": round(tot_ms / max(calls, 1), 5),
                         "algorithmic_bytes_per_step": abytes, "kernels_ms_per_step": kern_ms}
         out = {
