@@ -158,14 +158,14 @@ def main():
     for _ in range(args.warmup):
         one_step()
     fence()
-    pipe.ctx.profile_enable(True)
+    pipe.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
     fence()
     el = time.perf_counter() - t0
-    prof = pipe.ctx.profile_report()
-    pipe.ctx.profile_enable(False)
+    prof = pipe.profile_report()
+    pipe.profile_enable(False)
     t = torch.tensor([el], dtype=torch.float64, device="cuda")
     if world > 1:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -55,15 +55,37 @@ class TrackingPipeline:
         self.trk_kps = torch.zeros((F, cap, 7), dtype=torch.float32, device=self.dev)
         self.trk_desc = torch.zeros((F, cap, 32), dtype=torch.uint8, device=self.dev)
         self.trk_counts = torch.zeros(F, dtype=torch.int32, device=self.dev)
+        # Local BA runs on its own HIP stream and context: its LM rounds are a chain of small, latency-bound
+        # kernels (64-block solves, one-block decisions) that leave most CUs idle, while the extractor kernels
+        # are throughput bound -- the two overlap on the chip instead of queueing behind each other.
         self.with_ba = with_ba
         self.ba = None
+        self.ba_stream = None
+        self.ctx_ba = None
+        self._step_done = None
         if with_ba:
             from .ba import BatchedLocalBA
-            self.ba = BatchedLocalBA(self.ctx, F, ba_kf, ba_pts, ba_iters, seed, self.dev)
+            self.ba_stream = torch.cuda.Stream(device=self.dev)
+            self.ctx_ba = capi.Context(device, stream=self.ba_stream.cuda_stream)
+            self.ba = BatchedLocalBA(self.ctx_ba, F, ba_kf, ba_pts, ba_iters, seed, self.dev)
 
     def close(self):
+        torch.cuda.synchronize(self.dev)
         self.ex.close()
         self.ctx.close()
+        if self.ctx_ba is not None:
+            self.ctx_ba.close()
+
+    def profile_enable(self, on=True):
+        self.ctx.profile_enable(on)
+        if self.ctx_ba is not None:
+            self.ctx_ba.profile_enable(on)
+
+    def profile_report(self):
+        rep = self.ctx.profile_report()
+        if self.ctx_ba is not None:
+            rep.update(self.ctx_ba.profile_report())
+        return rep
 
     # ---- inputs
     def set_stereo_frames(self, left, right):
@@ -84,6 +106,7 @@ class TrackingPipeline:
     # ---- one pass of the hot path
     def step(self):
         F, ex, ctx, L = self.F, self.ex, self.ctx, capi.lib()
+        main = torch.cuda.current_stream(self.dev)
         ex.build_pyramid(2 * F)
         ex.orb(2 * F, self.target, self.init_th, self.min_th)
         pitch = self.kp_cap * 32
@@ -97,9 +120,18 @@ class TrackingPipeline:
                                           C.c_void_p(self.obs.data_ptr()), C.c_void_p(self.match_counts.data_ptr()),
                                           self.obs_pitch, C.c_void_p(self.outlier.data_ptr()), C.c_void_p(self.Tout.data_ptr()),
                                           C.c_void_p(self.n_inliers.data_ptr()), C.c_void_p(self.pose_stats.data_ptr())))
-        if self.ba is not None:
-            self.ba.run()
         ex.copy_results_dev(F, self.trk_kps.data_ptr(), self.trk_desc.data_ptr(), self.trk_counts.data_ptr(), self.kp_cap)
+        if self.ba is not None:
+            # everything above is only enqueued; the BA windows now run beside it on their own stream. (The BA
+            # driver synchronises its stream once per call -- LM termination is data dependent -- which blocks
+            # this host thread while the extractor stream keeps executing.)
+            if self._step_done is not None:
+                self.ba_stream.wait_event(self._step_done)  # the previous step's consumers of the BA buffers are done
+            with torch.cuda.stream(self.ba_stream):
+                self.ba.run()
+            main.wait_stream(self.ba_stream)   # the step is complete when both streams are
+            self._step_done = torch.cuda.Event()
+            self._step_done.record(main)
 
     # ---- outputs (host copies, for tests)
     def frame_results(self, f):
