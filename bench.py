@@ -116,7 +116,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=64, help="stereo frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=128, help="stereo frames per GPU per step")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--levels", type=int, default=8)

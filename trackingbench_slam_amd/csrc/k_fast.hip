@@ -195,6 +195,11 @@ struct FastCellsArgs {
     int waveBytes;     /* LDS bytes per wave */
 };
 
+typedef short ft_s16x2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ ft_s16x2 ft_pack(int a, int b) { return (ft_s16x2){(short)a, (short)b}; }
+__device__ __forceinline__ ft_s16x2 ft_min(ft_s16x2 a, ft_s16x2 b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ ft_s16x2 ft_max(ft_s16x2 a, ft_s16x2 b) { return __builtin_elementwise_max(a, b); }
+
 __device__ __forceinline__ void ft_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
 template <int ARC>
@@ -358,29 +363,50 @@ k_fast_cells(PlanGeom g, const uint8_t* __restrict__ slab, const CellDesc* __res
     }
     ft_lds_fence();
 
-    /* ---- stage 2: full arc test on the survivors, compaction in place (reads run ahead of the writes) */
+    /* ---- stage 2 + 3: exact FAST score of every survivor, TWO survivors per lane in packed 16-bit halves.
+     * score = max over the 16 arcs of min(d) and of min(-d), minus 1, with d = centre - ring; the min over a
+     * 9-arc is a doubling network (2, 4, 8, 8+1), every step one v_pk_min_i16 / v_pk_max_i16 for both pixels.
+     * A survivor is a corner at thA iff score >= thA; corners are compacted in place. */
     int ncorner = 0;
-    for (int base = 0; base < nlist; base += 64) {
-        const int i = base + lane;
-        bool cn = false;
-        int idx = 0;
-        if (i < nlist) {
-            idx = list[i];
-            cn = ft_is_corner_s<9>(tile + idx, S, thA);
+    for (int base = 0; base < nlist; base += 128) {
+        const int iA = base + lane, iB = base + 64 + lane;
+        const bool vA = iA < nlist, vB = iB < nlist;
+        const int idxA = vA ? list[iA] : (3 * S + 4), idxB = vB ? list[iB] : (3 * S + 4);
+        const uint8_t* pA = tile + idxA;
+        const uint8_t* pB = tile + idxB;
+        const ft_s16x2 vv = ft_pack(pA[0], pB[0]);
+        ft_s16x2 d[16];
+        d[0] = vv - ft_pack(pA[3 * S], pB[3 * S]);           d[1] = vv - ft_pack(pA[3 * S + 1], pB[3 * S + 1]);
+        d[2] = vv - ft_pack(pA[2 * S + 2], pB[2 * S + 2]);   d[3] = vv - ft_pack(pA[S + 3], pB[S + 3]);
+        d[4] = vv - ft_pack(pA[3], pB[3]);                   d[5] = vv - ft_pack(pA[-S + 3], pB[-S + 3]);
+        d[6] = vv - ft_pack(pA[-2 * S + 2], pB[-2 * S + 2]); d[7] = vv - ft_pack(pA[-3 * S + 1], pB[-3 * S + 1]);
+        d[8] = vv - ft_pack(pA[-3 * S], pB[-3 * S]);         d[9] = vv - ft_pack(pA[-3 * S - 1], pB[-3 * S - 1]);
+        d[10] = vv - ft_pack(pA[-2 * S - 2], pB[-2 * S - 2]); d[11] = vv - ft_pack(pA[-S - 3], pB[-S - 3]);
+        d[12] = vv - ft_pack(pA[-3], pB[-3]);                d[13] = vv - ft_pack(pA[S - 3], pB[S - 3]);
+        d[14] = vv - ft_pack(pA[2 * S - 2], pB[2 * S - 2]);  d[15] = vv - ft_pack(pA[3 * S - 1], pB[3 * S - 1]);
+        ft_s16x2 lo2[16], hi2[16], lo4[16], hi4[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) { lo2[k] = ft_min(d[k], d[(k + 1) & 15]); hi2[k] = ft_max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+        for (int k = 0; k < 16; k++) { lo4[k] = ft_min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = ft_max(hi2[k], hi2[(k + 2) & 15]); }
+        ft_s16x2 best = (ft_s16x2){0, 0};
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            const ft_s16x2 lo9 = ft_min(ft_min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);   /* min over the 9-arc starting at k */
+            const ft_s16x2 hi9 = ft_max(ft_max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
+            best = ft_max(best, ft_max(lo9, -hi9));
         }
-        const unsigned long long m = __ballot(cn);
-        ft_lds_fence();
-        if (cn) list[ncorner + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)idx;
-        ncorner += __popcll(m);
+        const int sA = (int)best.x - 1, sB = (int)best.y - 1;
+        const bool cA = vA && sA >= thA && sA > 0, cB = vB && sB >= thA && sB > 0;
+        ft_lds_fence(); /* every lane has read its two list entries before the compaction overwrites them */
+        const unsigned long long mA = __ballot(cA);
+        if (cA) { list[ncorner + __popcll(mA & ((1ull << lane) - 1))] = (uint16_t)idxA; sc[idxA] = (uint8_t)min(sA, 255); }
+        ncorner += __popcll(mA);
+        const unsigned long long mB = __ballot(cB);
+        if (cB) { list[ncorner + __popcll(mB & ((1ull << lane) - 1))] = (uint16_t)idxB; sc[idxB] = (uint8_t)min(sB, 255); }
+        ncorner += __popcll(mB);
         ft_lds_fence();
     }
-
-    /* ---- stage 3: exact scores */
-    for (int i = lane; i < ncorner; i += 64) {
-        const int idx = list[i];
-        sc[idx] = (uint8_t)min(max(ft_score_s<9>(tile + idx, S), 0), 255);
-    }
-    ft_lds_fence();
 
     /* ---- stage 4: NMS, threshold choice, emit */
     bool any_hi = false;
@@ -401,6 +427,25 @@ k_fast_cells(PlanGeom g, const uint8_t* __restrict__ slab, const CellDesc* __res
     const int th = any_hi ? init_th : min_th;
     uint32_t* out = cand + (size_t)b * g.candPerImage + L.candOff;
     int* count = candCount + b * TB_MAX_LEVELS + c.level;
+    /* ONE returning atomic per cell (a returning atomic per 64-lane pass cost 30-50 % of this kernel: every
+     * wave stalls on the round trip to a counter shared by the ~900 cells of its level): count the survivors
+     * first, reserve the range, then write */
+    int total = 0;
+    for (int base = 0; base < ncorner; base += 64) {
+        const int i = base + lane;
+        bool e = false;
+        if (i < ncorner) {
+            const int idx = list[i];
+            e = idx != 0xffff && sc[idx] >= th;
+            if (!e) list[i] = 0xffff;
+        }
+        total += __popcll(__ballot(e));
+    }
+    ft_lds_fence();
+    if (total == 0) return;
+    int wbase = 0;
+    if (lane == 0) wbase = atomicAdd(count, total);
+    wbase = __shfl(wbase, 0, TB_WAVE);
     for (int base = 0; base < ncorner; base += 64) {
         const int i = base + lane;
         bool e = false;
@@ -408,24 +453,17 @@ k_fast_cells(PlanGeom g, const uint8_t* __restrict__ slab, const CellDesc* __res
         if (i < ncorner) {
             const int idx = list[i];
             if (idx != 0xffff) {
-                const int s = sc[idx];
-                if (s >= th) {
-                    const int y = idx / S, x = idx - y * S;
-                    e = true;
-                    rec = ((uint32_t)s << 24) | ((uint32_t)(c.y0 + y - TB_BORDER) << 12) | (uint32_t)(ax0 + x - TB_BORDER);
-                }
+                const int y = idx / S, x = idx - y * S;
+                e = true;
+                rec = ((uint32_t)sc[idx] << 24) | ((uint32_t)(c.y0 + y - TB_BORDER) << 12) | (uint32_t)(ax0 + x - TB_BORDER);
             }
         }
         const unsigned long long m = __ballot(e);
-        if (m) {
-            int wbase = 0;
-            if (lane == 0) wbase = atomicAdd(count, __popcll(m));
-            wbase = __shfl(wbase, 0, TB_WAVE);
-            if (e) {
-                const int slot = wbase + __popcll(m & ((1ull << lane) - 1));
-                if (slot < L.candCap) out[slot] = rec;
-            }
+        if (e) {
+            const int slot = wbase + __popcll(m & ((1ull << lane) - 1));
+            if (slot < L.candCap) out[slot] = rec;
         }
+        wbase += __popcll(m);
     }
 }
 
