@@ -130,6 +130,7 @@ def main():
     ap.add_argument("--no-ba", action="store_true", help="diagnostic only: drop the local-BA stage")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--ba-split", type=int, default=2, help="partitions of the BA windows, one stream + host thread each")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic stereo pairs tiled over the batch")
     args = ap.parse_args()
 
@@ -142,7 +143,7 @@ def main():
 
     pipe = TrackingPipeline(args.width, args.height, args.levels, args.scale, args.target, args.init_th, args.min_th,
                             frames=args.frames, device=dev, with_ba=not args.no_ba, ba_kf=args.ba_kf, ba_pts=args.ba_pts,
-                            ba_iters=args.ba_iters, seed=rank)
+                            ba_iters=args.ba_iters, seed=rank, ba_split=args.ba_split)
     pipe.set_synthetic(distinct=args.distinct, first=rank * args.frames)
 
     def one_step():

@@ -968,6 +968,7 @@ int tb_local_ba_batch_dev(tb_ctx* ctx, int nwindows, const double K[4], int nkf,
         nfixed > nkf || iters < 0)
         return TB_EINVAL;
     if (nwindows == 0) return TB_OK;
+    TB_HIP(ctx, hipSetDevice(ctx->device)); /* callers may drive a context from their own host thread */
     const size_t wb = tbk_local_ba_work_bytes(nwindows, nkf, nfixed, npt, obs_pitch);
     void* dwork;
     int rc = tb_scratch(ctx, 6, wb, &dwork);

@@ -21,7 +21,7 @@ KITTI_K = (718.856, 718.856, 607.1928, 185.2157)  # hard-coded in the reference,
 class TrackingPipeline:
     def __init__(self, width=1280, height=720, nlevels=8, scale=0.8, target=2000, init_th=80.0, min_th=30.0,
                  frames=16, bf_ratio=10.0, bf_min_th=30.0, device=0, with_ba=True, ba_kf=10, ba_pts=5000, ba_iters=10,
-                 seed=0):
+                 seed=0, ba_split=2):
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
         self.F = int(frames)
@@ -59,33 +59,48 @@ class TrackingPipeline:
         # kernels (64-block solves, one-block decisions) that leave most CUs idle, while the extractor kernels
         # are throughput bound -- the two overlap on the chip instead of queueing behind each other.
         self.with_ba = with_ba
-        self.ba = None
-        self.ba_stream = None
-        self.ctx_ba = None
+        self.bas = []          # (BatchedLocalBA, torch stream, context) per partition of the windows
         self._step_done = None
+        self._pool = None
         if with_ba:
+            from concurrent.futures import ThreadPoolExecutor
             from .ba import BatchedLocalBA
-            self.ba_stream = torch.cuda.Stream(device=self.dev)
-            self.ctx_ba = capi.Context(device, stream=self.ba_stream.cuda_stream)
-            self.ba = BatchedLocalBA(self.ctx_ba, F, ba_kf, ba_pts, ba_iters, seed, self.dev)
+            nsplit = max(1, min(int(ba_split), F))
+            bounds = [F * i // nsplit for i in range(nsplit + 1)]
+            for i in range(nsplit):
+                st = torch.cuda.Stream(device=self.dev)
+                cx = capi.Context(device, stream=st.cuda_stream)
+                self.bas.append((BatchedLocalBA(cx, bounds[i + 1] - bounds[i], ba_kf, ba_pts, ba_iters, seed * 16 + i, self.dev), st, cx))
+            # each partition's driver blocks on its own stream once per call (LM termination is data dependent):
+            # one host thread per partition keeps the partitions' kernel chains in flight together
+            self._pool = ThreadPoolExecutor(max_workers=nsplit)
 
     def close(self):
         torch.cuda.synchronize(self.dev)
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
         self.ex.close()
         self.ctx.close()
-        if self.ctx_ba is not None:
-            self.ctx_ba.close()
+        for _, _, cx in self.bas:
+            cx.close()
 
     def profile_enable(self, on=True):
         self.ctx.profile_enable(on)
-        if self.ctx_ba is not None:
-            self.ctx_ba.profile_enable(on)
+        for _, _, cx in self.bas:
+            cx.profile_enable(on)
 
     def profile_report(self):
-        rep = self.ctx.profile_report()
-        if self.ctx_ba is not None:
-            rep.update(self.ctx_ba.profile_report())
+        rep = dict(self.ctx.profile_report())
+        for _, _, cx in self.bas:
+            for k, (calls, ms) in cx.profile_report().items():
+                c0, m0 = rep.get(k, (0, 0.0))
+                rep[k] = (c0 + calls, m0 + ms)
         return rep
+
+    def _run_ba(self, ba, st):
+        torch.cuda.set_device(self.dev)  # the current device is per host thread
+        with torch.cuda.stream(st):
+            ba.run()
 
     # ---- inputs
     def set_stereo_frames(self, left, right):
@@ -107,6 +122,12 @@ class TrackingPipeline:
     def step(self):
         F, ex, ctx, L = self.F, self.ex, self.ctx, capi.lib()
         main = torch.cuda.current_stream(self.dev)
+        futures = []
+        for ba, st, _ in self.bas:
+            # the BA windows run beside the extractor chain on their own streams (and host threads)
+            if self._step_done is not None:
+                st.wait_event(self._step_done)   # the previous step's consumers of the BA buffers are done
+            futures.append(self._pool.submit(self._run_ba, ba, st))
         ex.build_pyramid(2 * F)
         ex.orb(2 * F, self.target, self.init_th, self.min_th)
         pitch = self.kp_cap * 32
@@ -121,15 +142,11 @@ class TrackingPipeline:
                                           self.obs_pitch, C.c_void_p(self.outlier.data_ptr()), C.c_void_p(self.Tout.data_ptr()),
                                           C.c_void_p(self.n_inliers.data_ptr()), C.c_void_p(self.pose_stats.data_ptr())))
         ex.copy_results_dev(F, self.trk_kps.data_ptr(), self.trk_desc.data_ptr(), self.trk_counts.data_ptr(), self.kp_cap)
-        if self.ba is not None:
-            # everything above is only enqueued; the BA windows now run beside it on their own stream. (The BA
-            # driver synchronises its stream once per call -- LM termination is data dependent -- which blocks
-            # this host thread while the extractor stream keeps executing.)
-            if self._step_done is not None:
-                self.ba_stream.wait_event(self._step_done)  # the previous step's consumers of the BA buffers are done
-            with torch.cuda.stream(self.ba_stream):
-                self.ba.run()
-            main.wait_stream(self.ba_stream)   # the step is complete when both streams are
+        for fu in futures:
+            fu.result()
+        for _, st, _ in self.bas:
+            main.wait_stream(st)                 # the step is complete when every stream is
+        if self.bas:
             self._step_done = torch.cuda.Event()
             self._step_done.record(main)
 
