@@ -344,7 +344,9 @@ k_ba_reduce(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, BaSta
 #define BA_MAXT 4 /* 16-row tiles per side (np <= 60) */
 #define BA_WAVE_LDS (2 * 64 * BA_LD + BA_CP * 9) /* doubles per wave */
 
-__global__ void __launch_bounds__(BA_T)
+template <int R, int cR> /* R = 16-row tiles of the pose block, cR = column tile holding the rhs column: compile-time tile
+                            set, so the MFMA phase is straight-line code with the accumulators pinned in AGPRs */
+__global__ void __launch_bounds__(BA_T, 2)
 k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw, const int* __restrict__ iw,
            BaState* __restrict__ states) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -358,8 +360,6 @@ k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ 
     const tb_ba_obs* obs = obsAll + (size_t)w * d.obs_pitch;
     double* D = dw + (size_t)w * d.wstride;
     const int* I = iw + (size_t)w * d.istride;
-    const int R = (d.np + 15) >> 4;   /* row tiles */
-    const int cR = d.np >> 4;         /* column tile that holds the rhs column (index np) */
     ba_d4 acc[BA_MAXT][BA_MAXT];
 #pragma unroll
     for (int r = 0; r < BA_MAXT; r++)
@@ -794,11 +794,6 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
     int* running = (int*)((char*)states + (size_t)W * sizeof(BaState));
     hipStream_t s = ctx->stream;
     const size_t lds = std::max<size_t>(4 * (size_t)BA_WAVE_LDS, 64 * 64) * sizeof(double);
-    static bool attr = false;
-    if (!attr) {
-        TB_HIP(ctx, hipFuncSetAttribute((const void*)k_ba_schur, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        attr = true;
-    }
     tb_prof_begin(ctx, "k_ba_setup");
     hipLaunchKernelGGL(k_ba_setup, dim3(nkf + 1, W), dim3(BA_T), 0, s, d, d_poses, d_pts, d_obs, d_counts, dw, iw, states);
     tb_prof_end(ctx);
@@ -819,7 +814,19 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
             hipLaunchKernelGGL(k_ba_reduce, dim3(W), dim3(BA_T), 0, s, d, dw, iw, states);
             tb_prof_end(ctx);
             tb_prof_begin(ctx, "k_ba_schur");
-            hipLaunchKernelGGL(k_ba_schur, dim3(d.G, W), dim3(BA_T), lds, s, d, d_obs, dw, iw, states);
+            {
+                const int R = (d.np + 15) >> 4, cR = d.np >> 4;
+                void (*ks)(BaDims, const tb_ba_obs*, double*, const int*, BaState*) = nullptr;
+                if (R == 1 && cR == 0) ks = k_ba_schur<1, 0>;
+                else if (R == 1) ks = k_ba_schur<1, 1>;
+                else if (R == 2 && cR == 1) ks = k_ba_schur<2, 1>;
+                else if (R == 2) ks = k_ba_schur<2, 2>;
+                else if (R == 3 && cR == 2) ks = k_ba_schur<3, 2>;
+                else if (R == 3) ks = k_ba_schur<3, 3>;
+                else ks = k_ba_schur<4, 3>;
+                TB_HIP(ctx, hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                hipLaunchKernelGGL(ks, dim3(d.G, W), dim3(BA_T), lds, s, d, d_obs, dw, iw, states);
+            }
             tb_prof_end(ctx);
             tb_prof_begin(ctx, "k_ba_solve");
             if (d.np <= 16) hipLaunchKernelGGL(k_ba_solve<16>, dim3(W), dim3(BA_T), 0, s, d, dw, states);
