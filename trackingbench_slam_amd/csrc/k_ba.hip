@@ -22,6 +22,7 @@
  * Every cross-thread sum has a fixed shape (per-block trees + ordered partial sums), so results are
  * reproducible run to run.  Bound: FP64 MFMA for D (utilisation reported by bench.py), VALU/latency else.
  */
+#include <type_traits>
 #include "tb_internal.h"
 #include "tb_device.h"
 #include "tb_se3.h"
@@ -29,13 +30,15 @@
 #define BA_T 256
 #define BA_CP 4               /* points per Schur chunk (one wavefront each) */
 #define BA_LD (BA_CP * 3 + 1) /* LDS row stride (doubles) of the densified tiles */
+#define BA_MAXI ((BA_CP * 10 * 6 + 63) / 64) /* edge rows (6 per edge) per lane the Schur kernel keeps in registers per chunk */
 #define BA_KFCH 1024          /* edges per keyframe-pass chunk */
 #define BA_KFBLK 4            /* workgroups per keyframe in the keyframe pass */
 
 struct BaState {
     double lambda, ni, currentChi, chi0, scale_p, rho;
     int iter, qmax, status, need_lin, cur, ok2, done_iters, err;
-    int sing, pad0, pad1, pad2; /* sing: a point block was singular in this trial (solve fails, as in the CPU solver) */
+    int sing, long_chunks, pad1, pad2; /* long_chunks: some 4-point chunk has more edge rows than the Schur register path holds;
+                                          sing: a point block was singular in this trial (solve fails, as in the CPU solver) */
 };
 
 struct BaDims {
@@ -43,7 +46,7 @@ struct BaDims {
     int nblkP, kfChunks, G, nChunks;
     double fx, fy, cx, cy;
     /* per-window offsets, in doubles, into the double workspace */
-    unsigned long long wstride, oT, oP, oErr, oWgt, oHpl, oHll, oBl, oHpp, oBp, oXp, oPartKF, oPartP, oPartS;
+    unsigned long long wstride, oT, oP, oErr, oWgt, oHpl, oHll, oBl, oHq, oHpp, oBp, oXp, oPartKF, oPartP, oPartS;
     /* per-window offsets, in ints, into the int workspace */
     unsigned long long istride, oPtStart, oKfStart, oKfEdges, oScan;
 };
@@ -144,7 +147,7 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
     if (tid == 0) {
         st->lambda = 0; st->ni = 2; st->currentChi = 0; st->chi0 = 0; st->scale_p = 0; st->rho = 0;
         st->iter = 0; st->qmax = 0; st->status = (d.iters > 0 && nobs > 0) ? 0 : 1; st->need_lin = 1; st->cur = 0; st->ok2 = 1;
-        st->done_iters = 0; st->err = 0; st->sing = 0;
+        st->done_iters = 0; st->err = 0; st->sing = 0; st->long_chunks = 0;
     }
     __syncthreads();
     for (int e = tid; e < nobs; e += BA_T) {
@@ -170,6 +173,8 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
         D[d.oP + (size_t)d.npt * 3 + i] = v;
     }
     __syncthreads();
+    for (int c = tid; c < d.nChunks; c += BA_T)
+        if ((I[d.oPtStart + min(c * BA_CP + BA_CP, d.npt)] - I[d.oPtStart + c * BA_CP]) * 6 > BA_MAXI * 64) st->long_chunks = 1;
     if (tid == 0 && st->err) st->status = 1;
 }
 
@@ -332,6 +337,34 @@ k_ba_reduce(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, BaSta
     }
 }
 
+/* ---- C2: damped point-block inverses for this trial's lambda, one thread per point: the 6 unique entries of
+ * (Hll + lambda I)^-1 (ba_inv3's result is symmetric bit for bit) followed by bl, or zeros for a singular block.
+ * The Schur wavefronts fetch these 9-double records with their edge rows instead of inverting on 4 lanes. */
+__global__ void __launch_bounds__(BA_T)
+k_ba_hinv(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) {
+    const int w = blockIdx.y, p = blockIdx.x * BA_T + threadIdx.x;
+    const BaState st = states[w];
+    if (st.status || p >= d.npt) return;
+    double* D = dw + (size_t)w * d.wstride;
+    double ph[6], inv[9];
+#pragma unroll
+    for (int i = 0; i < 6; i++) ph[i] = D[d.oHll + (size_t)p * 6 + i];
+    const bool ok = ba_inv3(ph, st.lambda, inv);
+    if (!ok) states[w].sing = 1; /* benign race: every writer stores 1 */
+    double* q = D + d.oHq + (size_t)p * 9;
+    q[0] = ok ? inv[0] : 0.0; q[1] = ok ? inv[1] : 0.0; q[2] = ok ? inv[2] : 0.0;
+    q[3] = ok ? inv[4] : 0.0; q[4] = ok ? inv[5] : 0.0; q[5] = ok ? inv[8] : 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) q[6 + c] = ok ? D[d.oBl + (size_t)p * 3 + c] : 0.0;
+}
+
+/* broadcast of one lane's double through the scalar unit (lane index wave-uniform) */
+__device__ __forceinline__ double ba_readlane(double v, int lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
+    return __hiloint2double(hi, lo);
+}
+
 /* ---- D: Schur complement S' (np x np, lower triangle) and reduced rhs as an FP64 MFMA block GEMM.
  * Every WAVEFRONT works on its own 4-point chunks with private LDS tiles (no workgroup barrier in the
  * loop; three workgroups per CU keep three waves per SIMD so one wave's scatter overlaps another's MFMAs):
@@ -342,10 +375,15 @@ k_ba_reduce(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, BaSta
  * The loads of the wave's next chunk are issued before the MFMA phase (software pipeline). The four waves'
  * accumulators are summed through LDS in wave order; one partial tile per workgroup goes to k_ba_solve. */
 #define BA_MAXT 4 /* 16-row tiles per side (np <= 60) */
-#define BA_WAVE_LDS (2 * 64 * BA_LD + BA_CP * 9) /* doubles per wave */
+/* The Schur tiles are private to one wavefront and the LDS executes a wavefront's instructions in issue order, so
+ * cross-lane visibility needs no counter wait: a wavefront-scope fence only pins the compiler's ordering (a
+ * workgroup-scope one would also drain vmcnt, i.e. the prefetched edge rows, on every phase change). */
+__device__ __forceinline__ void ba_wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+#define BA_TRASH (2 * 64 * BA_LD + BA_CP * 9)  /* wave-relative offset of a 4-double sink for masked-out row items */
+#define BA_WAVE_LDS (BA_TRASH + 4)           /* doubles per wave */
 
-template <int R, int cR> /* R = 16-row tiles of the pose block, cR = column tile holding the rhs column: compile-time tile
-                            set, so the MFMA phase is straight-line code with the accumulators pinned in AGPRs */
+template <int R> /* R = 16-row tiles of the pose block: compile-time tile set (lower triangle), so the MFMA phase is
+                     straight-line code with the accumulators pinned in registers */
 __global__ void __launch_bounds__(BA_T, 2)
 k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw, const int* __restrict__ iw,
            BaState* __restrict__ states) {
@@ -366,125 +404,174 @@ k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ 
 #pragma unroll
         for (int c = 0; c < BA_MAXT; c++) acc[r][c] = (ba_d4){0, 0, 0, 0};
     for (int i = lane; i < 128 * BA_LD; i += 64) Yl[i] = 0;
-    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-    const int MAXI = (BA_CP * 10 * 6 + 63) / 64; /* edge rows per lane held in registers; longer chunks take the direct path */
-    const int stride = d.G * 4;                  /* waves per window */
-    int ch = g * 4 + wave;
-    int e0 = 0, e1 = 0, e0n = 0, e1n = 0;
-    if (ch < d.nChunks) { e0 = I[d.oPtStart + ch * BA_CP]; e1 = I[d.oPtStart + min(ch * BA_CP + BA_CP, d.npt)]; }
-    if (ch + stride < d.nChunks) { e0n = I[d.oPtStart + (ch + stride) * BA_CP]; e1n = I[d.oPtStart + min((ch + stride) * BA_CP + BA_CP, d.npt)]; }
-    int ipos[MAXI];
-    double ih0[MAXI], ih1[MAXI], ih2[MAXI];
-    double ph[6] = {0, 0, 0, 0, 0, 0}, pb[3] = {0, 0, 0};
-    auto preload = [&](int c, int ea, int eb) {
-        const int p0 = c * BA_CP;
+    ba_wave_lds_fence();
+    constexpr int MAXI = BA_MAXI;
+    const int stride = d.G * 4; /* waves per window */
+    constexpr bool TWO = R < 4; /* two register sets in flight; the 10-tile case has room for one */
+    const int pf = TWO ? 2 * stride : stride; /* chunk distance between a set's consecutive fills */
+    /* The edge rows (6 x 3 doubles per edge, one row per lane item) and the (inverse, bl) records of a chunk are
+     * fetched TWO chunks ahead into one of two register sets: a set's loads are issued back to back right after its
+     * previous contents were scattered, nothing looks at them until that set's next scatter, and the other set's
+     * whole chunk (scatter + MFMA phase) lies in between -- enough to cover an HBM miss under load.
+     * Everything on the fetch path is unconditional (clamped indices, a sink for dead items, the tail re-fetches the
+     * last chunk): the number of loads in flight is then the same on every path and the compiler can wait for one
+     * set with vmcnt(N) while the other stays in flight; any data-dependent branch or loop with loads in between
+     * degrades that to vmcnt(0). Windows with over-long chunks (st.long_chunks, set by k_ba_setup) therefore run a
+     * second instance of the loop that has the direct path for the rows past the register capacity. */
+    struct Pre {
+        int kf[MAXI], pt[MAXI];
+        double h0[MAXI], h1[MAXI], h2[MAXI];
+        double hq;      /* lane < 9 * BA_CP: one double of the chunk's (inverse, bl) records */
+        int e0, e1;     /* edge range of the chunk held */
+        int ne0, ne1;   /* edge range of the chunk this set fetches next */
+    };
+    const int lastCh = d.nChunks - 1, lastE = d.obs_pitch - 1;
+    const double* Hpl = D + d.oHpl;
+    const double* Hq = D + d.oHq;
+    auto range = [&](Pre& X, int c) {
+        c = min(c, lastCh);
+        X.ne0 = I[d.oPtStart + c * BA_CP];
+        X.ne1 = I[d.oPtStart + min(c * BA_CP + BA_CP, d.npt)];
+    };
+    auto preload = [&](Pre& X, int c) { /* X.ne0/ne1 = edge range of chunk min(c, lastCh) */
+        const int p0 = min(c, lastCh) * BA_CP, ea = X.ne0, eb = X.ne1;
+        X.e0 = ea; X.e1 = eb;
 #pragma unroll
         for (int j = 0; j < MAXI; j++) {
             const int it = lane + j * 64;
-            ipos[j] = -1;
-            if (it < (eb - ea) * 6) {
-                const int e = ea + it / 6, a = it - (it / 6) * 6;
-                const tb_ba_obs o = obs[e];
-                if (o.kf >= d.nfixed) {
-                    ipos[j] = ((6 * (o.kf - d.nfixed) + a) * BA_LD + 3 * (o.pt - p0)) | ((o.pt - p0) << 24);
-                    const double* H = D + d.oHpl + (size_t)e * 18 + a * 3;
-                    ih0[j] = H[0]; ih1[j] = H[1]; ih2[j] = H[2];
+            const unsigned e = (unsigned)min(ea + it / 6, lastE), a = (unsigned)(it - (it / 6) * 6);
+            const int kf = obs[e].kf; /* unsigned 32-bit indices: scalar base + vector offset addressing */
+            X.pt[j] = obs[e].pt;
+            X.kf[j] = (it < (eb - ea) * 6) ? kf : -1;
+            const double* H = Hpl + (e * 18u + a * 3u);
+            X.h0[j] = H[0]; X.h1[j] = H[1]; X.h2[j] = H[2];
+        }
+        X.hq = Hq[min((unsigned)p0 * 9u + (unsigned)min(lane, BA_CP * 9 - 1), (unsigned)d.npt * 9u - 1u)];
+        range(X, c + pf);
+    };
+    const int kofs = lane >> 4, l15 = lane & 15;
+    double rhs = 0; /* lane = row: this wave's part of sum_l Y bl */
+    auto chunk = [&](Pre& X, int c, auto longTag) {
+        constexpr bool LONG = decltype(longTag)::value;
+        const int p0 = c * BA_CP, p1 = min(p0 + BA_CP, d.npt);
+        if (lane < BA_CP * 9) Hi[lane] = X.hq;
+        ba_wave_lds_fence();
+        /* branch-free scatter: row items of fixed keyframes (and the lanes past the chunk's end) go to a sink */
+        int cpos[MAXI];
+#pragma unroll
+        for (int jj = 0; jj < MAXI; jj += 2) { /* two items at a time: 12 inverse entries in flight per lane */
+            double q[2][6];
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int j = jj + u;
+                if (j < MAXI) {
+                    const bool live = X.kf[j] >= d.nfixed;
+                    const int it = lane + j * 64, a = it - (it / 6) * 6, pl = live ? X.pt[j] - p0 : 0;
+                    cpos[j] = live ? (6 * (X.kf[j] - d.nfixed) + a) * BA_LD + 3 * pl : BA_TRASH;
+#pragma unroll
+                    for (int i = 0; i < 6; i++) q[u][i] = Hi[pl * 9 + i];
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < 2; u++) {
+                const int j = jj + u;
+                if (j < MAXI) {
+                    const int off = cpos[j];
+                    double* yr = Yl + off;
+                    double* wr = Yl + ((off == BA_TRASH) ? BA_TRASH : off + 64 * BA_LD);
+                    wr[0] = X.h0[j]; wr[1] = X.h1[j]; wr[2] = X.h2[j];
+                    yr[0] = X.h0[j] * q[u][0] + X.h1[j] * q[u][1] + X.h2[j] * q[u][2];
+                    yr[1] = X.h0[j] * q[u][1] + X.h1[j] * q[u][3] + X.h2[j] * q[u][4];
+                    yr[2] = X.h0[j] * q[u][2] + X.h1[j] * q[u][4] + X.h2[j] * q[u][5];
                 }
             }
         }
-        if (lane < BA_CP && p0 + lane < d.npt) {
-#pragma unroll
-            for (int i = 0; i < 6; i++) ph[i] = D[d.oHll + (size_t)(p0 + lane) * 6 + i];
-#pragma unroll
-            for (int i = 0; i < 3; i++) pb[i] = D[d.oBl + (size_t)(p0 + lane) * 3 + i];
-        }
-    };
-    if (ch < d.nChunks) preload(ch, e0, e1);
-    for (; ch < d.nChunks; ch += stride) {
-        const int p0 = ch * BA_CP, p1 = min(p0 + BA_CP, d.npt);
-        if (lane < p1 - p0) {
-            double inv[9];
-            const bool ok = ba_inv3(ph, st.lambda, inv);
-            if (!ok) { states[w].sing = 1; for (int i = 0; i < 9; i++) inv[i] = 0; } /* benign race: every writer stores 1 */
-            for (int i = 0; i < 9; i++) Hi[lane * 9 + i] = inv[i];
-            for (int c = 0; c < 3; c++) Wl[d.np * BA_LD + 3 * lane + c] = ok ? pb[c] : 0.0;
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        int cpos[MAXI];
-#pragma unroll
-        for (int j = 0; j < MAXI; j++) {
-            cpos[j] = ipos[j];
-            if (ipos[j] >= 0) {
-                const int off = ipos[j] & 0xffffff;
-                const double* inv = Hi + (ipos[j] >> 24) * 9;
-                double* wr = Wl + off;
-                double* yr = Yl + off;
-                wr[0] = ih0[j]; wr[1] = ih1[j]; wr[2] = ih2[j];
-                yr[0] = ih0[j] * inv[0] + ih1[j] * inv[3] + ih2[j] * inv[6];
-                yr[1] = ih0[j] * inv[1] + ih1[j] * inv[4] + ih2[j] * inv[7];
-                yr[2] = ih0[j] * inv[2] + ih1[j] * inv[5] + ih2[j] * inv[8];
+        const int e0c = X.e0, e1c = X.e1;
+        if constexpr (LONG)
+            for (int it = lane + MAXI * 64; it < (e1c - e0c) * 6; it += 64) { /* rows past the register capacity */
+                const int e = e0c + it / 6, a = it - (it / 6) * 6;
+                const tb_ba_obs o = obs[e];
+                if (o.kf < d.nfixed) continue;
+                const int pl = o.pt - p0, row = 6 * (o.kf - d.nfixed) + a;
+                const double* H = D + d.oHpl + (size_t)e * 18 + a * 3;
+                const double h0 = H[0], h1 = H[1], h2 = H[2];
+                const double* q6 = Hi + pl * 9;
+                double* wr = Wl + row * BA_LD + 3 * pl;
+                double* yr = Yl + row * BA_LD + 3 * pl;
+                wr[0] = h0; wr[1] = h1; wr[2] = h2;
+                yr[0] = h0 * q6[0] + h1 * q6[1] + h2 * q6[2];
+                yr[1] = h0 * q6[1] + h1 * q6[3] + h2 * q6[4];
+                yr[2] = h0 * q6[2] + h1 * q6[4] + h2 * q6[5];
             }
+        ba_wave_lds_fence();
+        /* this set is free again: issue the loads of the chunk it holds next, before the MFMA phase */
+        double bl[BA_CP * 3]; /* the chunk's bl, broadcast from the record registers (wave-uniform) */
+#pragma unroll
+        for (int k = 0; k < BA_CP * 3; k++) bl[k] = ba_readlane(X.hq, (k / 3) * 9 + 6 + (k % 3));
+        preload(X, c + pf);
+        /* reduced right-hand side on the vector ALU: lane = row of Y, 3 * BA_CP products per chunk (as a 17th column
+         * of the block product it would cost R more MFMA tiles per k-step for one useful column) */
+#pragma unroll
+        for (int k = 0; k < BA_CP * 3; k++) {
+            const double b = (k / 3 < p1 - p0) ? bl[k] : 0.0;
+            rhs = fma(Yl[lane * BA_LD + k], b, rhs);
         }
-        for (int it = lane + MAXI * 64; it < (e1 - e0) * 6; it += 64) { /* direct path for very long chunks */
-            const int e = e0 + it / 6, a = it - (it / 6) * 6;
-            const tb_ba_obs o = obs[e];
-            if (o.kf < d.nfixed) continue;
-            const int pl = o.pt - p0, row = 6 * (o.kf - d.nfixed) + a;
-            const double* H = D + d.oHpl + (size_t)e * 18 + a * 3;
-            const double h0 = H[0], h1 = H[1], h2 = H[2];
-            const double* inv = Hi + pl * 9;
-            double* wr = Wl + row * BA_LD + 3 * pl;
-            double* yr = Yl + row * BA_LD + 3 * pl;
-            wr[0] = h0; wr[1] = h1; wr[2] = h2;
-            yr[0] = h0 * inv[0] + h1 * inv[3] + h2 * inv[6];
-            yr[1] = h0 * inv[1] + h1 * inv[4] + h2 * inv[7];
-            yr[2] = h0 * inv[2] + h1 * inv[5] + h2 * inv[8];
-        }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-        /* issue the next chunk's loads, and the edge range of the one after, before the MFMA phase */
-        const int e0c = e0, e1c = e1;
-        if (ch + stride < d.nChunks) preload(ch + stride, e0n, e1n);
-        e0 = e0n; e1 = e1n;
-        if (ch + 2 * stride < d.nChunks) {
-            e0n = I[d.oPtStart + (ch + 2 * stride) * BA_CP];
-            e1n = I[d.oPtStart + min((ch + 2 * stride) * BA_CP + BA_CP, d.npt)];
-        }
-        const int kofs = lane >> 4, l15 = lane & 15;
 #pragma unroll
         for (int kk = 0; kk < BA_CP * 3; kk += 4) {
             double av[BA_MAXT], bv[BA_MAXT];
 #pragma unroll
             for (int t = 0; t < BA_MAXT; t++) {
                 av[t] = (t < R) ? Yl[(16 * t + l15) * BA_LD + kk + kofs] : 0.0;
-                bv[t] = (t <= cR && t < BA_MAXT) ? Wl[(16 * t + l15) * BA_LD + kk + kofs] : 0.0;
+                bv[t] = (t < R) ? Wl[(16 * t + l15) * BA_LD + kk + kofs] : 0.0;
             }
 #pragma unroll
             for (int r = 0; r < BA_MAXT; r++)
 #pragma unroll
-                for (int c = 0; c < BA_MAXT; c++)
-                    if (r < R && (c <= r || c == cR))
-                        acc[r][c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[r], bv[c], acc[r][c], 0, 0, 0);
+                for (int cc = 0; cc < BA_MAXT; cc++)
+                    if (r < R && cc <= r)
+                        acc[r][cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[r], bv[cc], acc[r][cc], 0, 0, 0);
         }
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        ba_wave_lds_fence();
         /* clear what this chunk wrote (positions kept in registers) */
 #pragma unroll
-        for (int j = 0; j < MAXI; j++)
-            if (cpos[j] >= 0) {
-                const int off = cpos[j] & 0xffffff;
+        for (int j = 0; j < MAXI; j++) {
+            const int off = cpos[j], woff = (off == BA_TRASH) ? BA_TRASH : off + 64 * BA_LD;
+            Yl[woff] = Yl[woff + 1] = Yl[woff + 2] = 0;
+            Yl[off] = Yl[off + 1] = Yl[off + 2] = 0;
+        }
+        if constexpr (LONG)
+            for (int it = lane + MAXI * 64; it < (e1c - e0c) * 6; it += 64) {
+                const int e = e0c + it / 6, a = it - (it / 6) * 6;
+                const tb_ba_obs o = obs[e];
+                if (o.kf < d.nfixed) continue;
+                const int off = (6 * (o.kf - d.nfixed) + a) * BA_LD + 3 * (o.pt - p0);
                 Wl[off] = Wl[off + 1] = Wl[off + 2] = 0;
                 Yl[off] = Yl[off + 1] = Yl[off + 2] = 0;
             }
-        for (int it = lane + MAXI * 64; it < (e1c - e0c) * 6; it += 64) {
-            const int e = e0c + it / 6, a = it - (it / 6) * 6;
-            const tb_ba_obs o = obs[e];
-            if (o.kf < d.nfixed) continue;
-            const int off = (6 * (o.kf - d.nfixed) + a) * BA_LD + 3 * (o.pt - p0);
-            Wl[off] = Wl[off + 1] = Wl[off + 2] = 0;
-            Yl[off] = Yl[off + 1] = Yl[off + 2] = 0;
+        ba_wave_lds_fence();
+    };
+    auto run = [&](auto longTag) {
+        Pre A;
+        int ch = g * 4 + wave;
+        range(A, ch);
+        if constexpr (TWO) {
+            Pre B;
+            range(B, ch + stride);
+            preload(A, ch);
+            preload(B, ch + stride);
+            for (; ch + stride < d.nChunks; ch += 2 * stride) {
+                chunk(A, ch, longTag);
+                chunk(B, ch + stride, longTag);
+            }
+            if (ch < d.nChunks) chunk(A, ch, longTag);
+        } else {
+            preload(A, ch);
+            for (; ch < d.nChunks; ch += stride) chunk(A, ch, longTag);
         }
-        if (lane < p1 - p0)
-            for (int c = 0; c < 3; c++) Wl[d.np * BA_LD + 3 * lane + c] = 0;
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    };
+    if (d.nChunks > 0) {
+        if (st.long_chunks) run(std::true_type{});
+        else run(std::false_type{});
     }
     __syncthreads();
     /* sum the four waves' accumulators through LDS in wave order (fixed shape), then one partial per block.
@@ -496,26 +583,23 @@ k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ 
             for (int r = 0; r < BA_MAXT; r++)
 #pragma unroll
                 for (int c = 0; c < BA_MAXT; c++)
-                    if (r < R && (c <= r || c == cR))
+                    if (r < R && c <= r)
                         for (int q = 0; q < 4; q++) {
                             const int idx = (16 * r + (lane >> 4) + 4 * q) * 64 + 16 * c + (lane & 15);
                             sum[idx] = (wv == 0) ? acc[r][c][q] : sum[idx] + acc[r][c][q];
                         }
+            ba_wave_lds_fence();
+            /* column np = reduced rhs (k_ba_solve reads it there); it may lie inside a diagonal tile, whose entries
+             * in that column are products with the all-zero row np of W: overwritten / added on top */
+            if (lane < d.np) sum[lane * 64 + d.np] = (wv == 0) ? rhs : sum[lane * 64 + d.np] + rhs;
         }
         __syncthreads();
     }
     double* out = D + d.oPartS + (size_t)g * 64 * 64;
     for (int i = tid; i < 64 * 64; i += BA_T) {
         const int r = i >> 6, c = i & 63, rt = r >> 4, ct = c >> 4;
-        if (rt < R && (ct <= rt || ct == cR)) out[i] = sum[i];
+        if (rt < R && (ct <= rt || (c == d.np && r < d.np))) out[i] = sum[i];
     }
-}
-
-/* broadcast of one lane's double through the scalar unit (lane index wave-uniform) */
-__device__ __forceinline__ double ba_readlane(double v, int lane) {
-    const int lo = __builtin_amdgcn_readlane(__double2loint(v), lane);
-    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
-    return __hiloint2double(hi, lo);
 }
 
 /* ---- E: assemble S (lower triangle), Cholesky in registers, pose update */
@@ -753,6 +837,7 @@ static void ba_dims(BaDims& d, int W, const double K[4], int nkf, int nfixed, in
     d.oHpl = take(18ull * obs_pitch);
     d.oHll = take(6ull * npt);
     d.oBl = take(3ull * npt);
+    d.oHq = take(9ull * npt);
     d.oHpp = take(36ull * std::max(d.nfree, 1));
     d.oBp = take(64);
     d.oXp = take(64);
@@ -813,17 +898,14 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
             tb_prof_begin(ctx, "k_ba_reduce");
             hipLaunchKernelGGL(k_ba_reduce, dim3(W), dim3(BA_T), 0, s, d, dw, iw, states);
             tb_prof_end(ctx);
+            tb_prof_begin(ctx, "k_ba_hinv");
+            hipLaunchKernelGGL(k_ba_hinv, dim3(d.nblkP, W), dim3(BA_T), 0, s, d, dw, states);
+            tb_prof_end(ctx);
             tb_prof_begin(ctx, "k_ba_schur");
             {
-                const int R = (d.np + 15) >> 4, cR = d.np >> 4;
-                void (*ks)(BaDims, const tb_ba_obs*, double*, const int*, BaState*) = nullptr;
-                if (R == 1 && cR == 0) ks = k_ba_schur<1, 0>;
-                else if (R == 1) ks = k_ba_schur<1, 1>;
-                else if (R == 2 && cR == 1) ks = k_ba_schur<2, 1>;
-                else if (R == 2) ks = k_ba_schur<2, 2>;
-                else if (R == 3 && cR == 2) ks = k_ba_schur<3, 2>;
-                else if (R == 3) ks = k_ba_schur<3, 3>;
-                else ks = k_ba_schur<4, 3>;
+                const int R = (d.np + 15) >> 4;
+                void (*ks)(BaDims, const tb_ba_obs*, double*, const int*, BaState*) =
+                    R == 1 ? k_ba_schur<1> : R == 2 ? k_ba_schur<2> : R == 3 ? k_ba_schur<3> : k_ba_schur<4>;
                 TB_HIP(ctx, hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
                 hipLaunchKernelGGL(ks, dim3(d.G, W), dim3(BA_T), lds, s, d, d_obs, dw, iw, states);
             }
