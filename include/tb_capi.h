@@ -137,13 +137,14 @@ int tb_pose_opt_batch_dev(tb_ctx* ctx, int nproblems, const double K[4], const f
                           const tb_obs* obs, const int32_t* counts, int obs_pitch, uint8_t* outlier,
                           float* Tcw_out, int32_t* n_inliers, double* stats);
 /* Multi-keyframe local BA -- north-star extension, NO reference counterpart.
- * poses: nkf x 16 (in/out, first nfixed held), pts: npt x 3 (in/out). stats (nullable, 8 doubles):
+ * poses: nkf x 16 (in/out, first nfixed held), pts: npt x 3 (in/out). A point is observed at most once per
+ * keyframe (repeated (kf, pt) pairs are rejected like out-of-range indices). stats (nullable, 8 doubles):
  * iterations, initial chi2, final chi2, final lambda. */
 int tb_local_ba(tb_ctx* ctx, const double K[4], int nkf, int nfixed, float* poses, int npt, float* pts,
                 const tb_ba_obs* obs, int nobs, int iters, double* stats);
 /* Batched device form: nwindows equally sized windows; window w uses poses + w*nkf*16, pts + w*npt*3,
  * obs + w*obs_pitch (obs_counts[w] rows, GROUPED BY ASCENDING POINT INDEX), stats + 8w (nullable;
- * stats[7] = -1 flags a window whose observations were out of range / not grouped). Device pointers.
+ * stats[7] = -1 flags a window whose observations were out of range / not grouped / repeated). Device pointers.
  * Synchronises the stream once (LM termination is data dependent). */
 int tb_local_ba_batch_dev(tb_ctx* ctx, int nwindows, const double K[4], int nkf, int nfixed, float* poses, int npt,
                           float* pts, const tb_ba_obs* obs, const int32_t* obs_counts, int obs_pitch, int iters,

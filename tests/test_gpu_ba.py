@@ -46,6 +46,20 @@ def test_local_ba_vs_cpu_solver(ctx, seed, nkf, npt, nfixed, iters):
     assert sg[2] < sg[1]
 
 
+@pytest.mark.parametrize("seed,nkf,npt,nfixed,per_pt", [(11, 10, 600, 2, 10),  # every keyframe sees every point
+                                                         (12, 6, 300, 1, 6), (13, 4, 120, 1, 4), (14, 3, 90, 2, 3),
+                                                         (15, 12, 150, 2, 12), (16, 10, 203, 0, 2)])
+def test_local_ba_chunk_capacities(ctx, seed, nkf, npt, nfixed, per_pt):
+    """The Schur kernel keeps 64 M Hpl rows per 4-point chunk in registers, M picked per window from its longest
+    chunk (M <= R = ceil(6 nfree / 16)): sparse to fully dense windows walk through every instance."""
+    Pt, Pi, Xt, Xi, obs = synth.ba_problem(seed, nkf, npt, K, obs_per_pt=per_pt)
+    io, Po, Xo, so = oracle.local_ba(K, Pi, nfixed, Xi, obs, 6)
+    ig, Pg, Xg, sg = ctx.local_ba(K, Pi, nfixed, Xi, obs, 6)
+    _close(Pg, Po)
+    _close(Xg, Xo)
+    assert np.isclose(sg[2], so[2], rtol=1e-6, atol=1e-9) and np.isclose(sg[1], so[1], rtol=1e-9)
+
+
 def test_local_ba_batched_windows(ctx):
     import torch
     from trackingbench_slam_amd.ba import BatchedLocalBA
@@ -70,6 +84,8 @@ def test_local_ba_rejects_bad_input(ctx):
     bad = obs.copy(); bad["kf"][0] = 99
     with pytest.raises(capi.TBError):
         ctx.local_ba(K, Pi, 2, Xi, bad, 5)
+    with pytest.raises(capi.TBError):  # a point seen twice by one keyframe
+        ctx.local_ba(K, Pi, 2, Xi, np.concatenate([obs, obs[5:6]]), 5)
     with pytest.raises(capi.TBError) as e:  # more free keyframes than one 64x64 Schur tile holds
         P2 = np.tile(np.eye(4, dtype=np.float32), (14, 1, 1))
         ctx.local_ba(K, P2, 2, Xi, obs, 5)

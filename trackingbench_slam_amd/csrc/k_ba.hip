@@ -30,14 +30,13 @@
 #define BA_T 256
 #define BA_CP 4               /* points per Schur chunk (one wavefront each) */
 #define BA_LD (BA_CP * 3 + 1) /* LDS row stride (doubles) of the densified tiles */
-#define BA_MAXI ((BA_CP * 10 * 6 + 63) / 64) /* edge rows (6 per edge) per lane the Schur kernel keeps in registers per chunk */
 #define BA_KFCH 1024          /* edges per keyframe-pass chunk */
 #define BA_KFBLK 4            /* workgroups per keyframe in the keyframe pass */
 
 struct BaState {
     double lambda, ni, currentChi, chi0, scale_p, rho;
     int iter, qmax, status, need_lin, cur, ok2, done_iters, err;
-    int sing, long_chunks, pad1, pad2; /* long_chunks: some 4-point chunk has more edge rows than the Schur register path holds;
+    int sing, max_rows, pad1, pad2; /* max_rows: most Hpl rows (6 per free-keyframe edge) any BA_CP-point Schur chunk has;
                                           sing: a point block was singular in this trial (solve fails, as in the CPU solver) */
 };
 
@@ -48,7 +47,7 @@ struct BaDims {
     /* per-window offsets, in doubles, into the double workspace */
     unsigned long long wstride, oT, oP, oErr, oWgt, oHpl, oHll, oBl, oHq, oHpp, oBp, oXp, oPartKF, oPartP, oPartS;
     /* per-window offsets, in ints, into the int workspace */
-    unsigned long long istride, oPtStart, oKfStart, oKfEdges, oScan;
+    unsigned long long istride, oPtStart, oPtFree, oKfStart, oKfEdges, oScan, oFreeKP;
 };
 
 typedef double ba_d4 __attribute__((ext_vector_type(4)));
@@ -103,9 +102,10 @@ __device__ __forceinline__ double ba_block_max1(double v, double* red) {
 }
 
 /* ---- setup: CSR by point (observations must be grouped by ascending point index) and by keyframe.
- * grid (nkf + 1, W): block k < nkf lists keyframe k's edges in ascending edge order (its base offset is
+ * grid (nkf + 2, W): block k < nkf lists keyframe k's edges in ascending edge order (its base offset is
  * the count of edges with a smaller keyframe index, recounted per block so blocks stay independent);
- * block nkf initialises the LM state, checks the input, builds ptStart and converts poses / points. */
+ * block nkf initialises the LM state, checks the input, builds ptStart and converts poses / points;
+ * block nkf + 1 numbers the free-keyframe edges compactly (Hpl rows, key list, ptFree). */
 __global__ void __launch_bounds__(BA_T)
 k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ pts, const tb_ba_obs* __restrict__ obsAll,
            const int32_t* __restrict__ obsCounts, double* __restrict__ dw, int* __restrict__ iw, BaState* __restrict__ states) {
@@ -144,15 +144,55 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
         }
         return;
     }
+    if (k == d.nkf + 1) {
+        /* compact numbering of the free-keyframe edges (the only ones with an Hpl block): ce = rank among the free
+         * edges in edge order, so a point's / a chunk's free edges are contiguous in Hpl and in the key list
+         * freeKP[ce] = pt << 6 | free keyframe index; ptFree[p] = first compact edge of point p */
+        if (tid == 0) srun = 0;
+        __syncthreads();
+        for (int e0 = 0; e0 < nobs; e0 += BA_T) {
+            const int e = e0 + tid;
+            const int kf = (e < nobs) ? obs[e].kf : -1;
+            const int f = (kf >= d.nfixed) ? 1 : 0;
+            sflags[tid] = f;
+            __syncthreads();
+            const int total = tb_block_excl_scan(sflags, BA_T, tmp);
+            const int ce = srun + sflags[tid];
+            if (e < nobs) I[d.oScan + e] = ce;
+            if (f) I[d.oFreeKP + ce] = (int)(((unsigned)obs[e].pt << 6) | ((unsigned)(kf - d.nfixed) & 63u));
+            __syncthreads();
+            if (tid == 0) srun += total;
+            __syncthreads();
+        }
+        const int nfreeE = srun;
+        for (int p = tid; p <= d.npt; p += BA_T) {
+            int lo = 0, hi = nobs;
+            while (lo < hi) { const int mid = (lo + hi) >> 1; if (obs[mid].pt < p) lo = mid + 1; else hi = mid; }
+            I[d.oPtFree + p] = (lo < nobs) ? I[d.oScan + lo] : nfreeE;
+        }
+        __syncthreads();
+        int mr = 0; /* most edge rows in a Schur chunk: picks how many the kernel keeps in registers per lane */
+        for (int c = tid; c < d.nChunks; c += BA_T)
+            mr = max(mr, (I[d.oPtFree + min(c * BA_CP + BA_CP, d.npt)] - I[d.oPtFree + c * BA_CP]) * 6);
+        mr = tb_wave_max_i(mr);
+        if ((tid & 63) == 0) tmp[tid >> 6] = mr;
+        __syncthreads();
+        if (tid == 0) st->max_rows = max(max(tmp[0], tmp[1]), max(tmp[2], tmp[3]));
+        return;
+    }
     if (tid == 0) {
         st->lambda = 0; st->ni = 2; st->currentChi = 0; st->chi0 = 0; st->scale_p = 0; st->rho = 0;
         st->iter = 0; st->qmax = 0; st->status = (d.iters > 0 && nobs > 0) ? 0 : 1; st->need_lin = 1; st->cur = 0; st->ok2 = 1;
-        st->done_iters = 0; st->err = 0; st->sing = 0; st->long_chunks = 0;
+        st->done_iters = 0; st->err = 0; st->sing = 0;
     }
     __syncthreads();
     for (int e = tid; e < nobs; e += BA_T) {
         const tb_ba_obs o = obs[e];
         if (o.kf < 0 || o.kf >= d.nkf || o.pt < 0 || o.pt >= d.npt || (e > 0 && o.pt < obs[e - 1].pt)) st->err = 1;
+        /* a point is observed at most once per keyframe (the Schur tiles hold one Hpl block per (keyframe, point));
+         * the first repeat within a point's run lies at most nkf edges after its earlier occurrence */
+        for (int b = 1; b <= d.nkf && e - b >= 0 && obs[e - b].pt == o.pt; b++)
+            if (obs[e - b].kf == o.kf) st->err = 1;
     }
     for (int p = tid; p <= d.npt; p += BA_T) { /* first edge with pt >= p */
         int lo = 0, hi = nobs;
@@ -173,8 +213,6 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
         D[d.oP + (size_t)d.npt * 3 + i] = v;
     }
     __syncthreads();
-    for (int c = tid; c < d.nChunks; c += BA_T)
-        if ((I[d.oPtStart + min(c * BA_CP + BA_CP, d.npt)] - I[d.oPtStart + c * BA_CP]) * 6 > BA_MAXI * 64) st->long_chunks = 1;
     if (tid == 0 && st->err) st->status = 1;
 }
 
@@ -200,6 +238,7 @@ k_ba_points(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
     if (p < d.npt) {
         double Hll[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
         const double X[3] = {P[3 * p], P[3 * p + 1], P[3 * p + 2]};
+        int ce = I[d.oPtFree + p]; /* compact index of the point's next free-keyframe edge */
         for (int e = I[d.oPtStart + p]; e < I[d.oPtStart + p + 1]; e++) {
             const tb_ba_obs o = obs[e];
             const PoSE3 Tk = ba_load_se3(sT + o.kf * 7);
@@ -230,7 +269,8 @@ k_ba_points(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
             Hll[5] += ww * (Jl[2] * Jl[2] + Jl[5] * Jl[5]);
             if (o.kf >= d.nfixed) {
                 ba_jac_pose(pc, d.fx, d.fy, Jp);
-                double* H = D + d.oHpl + (size_t)e * 18;
+                double* H = D + d.oHpl + (size_t)ce * 18;
+                ce++;
                 for (int a = 0; a < 6; a++)
                     for (int c = 0; c < 3; c++) H[a * 3 + c] = ww * (Jp[a] * Jl[c] + Jp[6 + a] * Jl[3 + c]);
             }
@@ -382,6 +422,17 @@ __device__ __forceinline__ void ba_wave_lds_fence() { __builtin_amdgcn_fence(__A
 #define BA_TRASH (2 * 64 * BA_LD + BA_CP * 9)  /* wave-relative offset of a 4-double sink for masked-out row items */
 #define BA_WAVE_LDS (BA_TRASH + 4)           /* doubles per wave */
 
+/* one prefetched Schur chunk: M edge rows per lane */
+template <int M>
+struct BaPre {
+    static constexpr int N = M;
+    int key[M];     /* pt << 6 | free keyframe index, -1 = no item */
+    double h0[M], h1[M], h2[M];
+    double hq;      /* lane < 9 * BA_CP: one double of the chunk's (inverse, bl) records */
+    int e0, e1;     /* compact edge range of the chunk held */
+    int ne0, ne1;   /* compact edge range of the chunk this set fetches next */
+};
+
 template <int R> /* R = 16-row tiles of the pose block: compile-time tile set (lower triangle), so the MFMA phase is
                      straight-line code with the accumulators pinned in registers */
 __global__ void __launch_bounds__(BA_T, 2)
@@ -405,7 +456,6 @@ k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ 
         for (int c = 0; c < BA_MAXT; c++) acc[r][c] = (ba_d4){0, 0, 0, 0};
     for (int i = lane; i < 128 * BA_LD; i += 64) Yl[i] = 0;
     ba_wave_lds_fence();
-    constexpr int MAXI = BA_MAXI;
     const int stride = d.G * 4; /* waves per window */
     constexpr bool TWO = R < 4; /* two register sets in flight; the 10-tile case has room for one */
     const int pf = TWO ? 2 * stride : stride; /* chunk distance between a set's consecutive fills */
@@ -416,33 +466,26 @@ k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ 
      * Everything on the fetch path is unconditional (clamped indices, a sink for dead items, the tail re-fetches the
      * last chunk): the number of loads in flight is then the same on every path and the compiler can wait for one
      * set with vmcnt(N) while the other stays in flight; any data-dependent branch or loop with loads in between
-     * degrades that to vmcnt(0). Windows with over-long chunks (st.long_chunks, set by k_ba_setup) therefore run a
-     * second instance of the loop that has the direct path for the rows past the register capacity. */
-    struct Pre {
-        int kf[MAXI], pt[MAXI];
-        double h0[MAXI], h1[MAXI], h2[MAXI];
-        double hq;      /* lane < 9 * BA_CP: one double of the chunk's (inverse, bl) records */
-        int e0, e1;     /* edge range of the chunk held */
-        int ne0, ne1;   /* edge range of the chunk this set fetches next */
-    };
+     * degrades that to vmcnt(0). */
     const int lastCh = d.nChunks - 1, lastE = d.obs_pitch - 1;
     const double* Hpl = D + d.oHpl;
     const double* Hq = D + d.oHq;
-    auto range = [&](Pre& X, int c) {
+    const int* KP = I + d.oFreeKP;
+    auto range = [&](auto& X, int c) {
         c = min(c, lastCh);
-        X.ne0 = I[d.oPtStart + c * BA_CP];
-        X.ne1 = I[d.oPtStart + min(c * BA_CP + BA_CP, d.npt)];
+        X.ne0 = I[d.oPtFree + c * BA_CP];
+        X.ne1 = I[d.oPtFree + min(c * BA_CP + BA_CP, d.npt)];
     };
-    auto preload = [&](Pre& X, int c) { /* X.ne0/ne1 = edge range of chunk min(c, lastCh) */
+    auto preload = [&](auto& X, int c) { /* X.ne0/ne1 = edge range of chunk min(c, lastCh) */
+        constexpr int MAXI = std::remove_reference_t<decltype(X)>::N;
         const int p0 = min(c, lastCh) * BA_CP, ea = X.ne0, eb = X.ne1;
         X.e0 = ea; X.e1 = eb;
 #pragma unroll
         for (int j = 0; j < MAXI; j++) {
             const int it = lane + j * 64;
             const unsigned e = (unsigned)min(ea + it / 6, lastE), a = (unsigned)(it - (it / 6) * 6);
-            const int kf = obs[e].kf; /* unsigned 32-bit indices: scalar base + vector offset addressing */
-            X.pt[j] = obs[e].pt;
-            X.kf[j] = (it < (eb - ea) * 6) ? kf : -1;
+            const int key = KP[e]; /* unsigned 32-bit indices: scalar base + vector offset addressing */
+            X.key[j] = (it < (eb - ea) * 6) ? key : -1;
             const double* H = Hpl + (e * 18u + a * 3u);
             X.h0[j] = H[0]; X.h1[j] = H[1]; X.h2[j] = H[2];
         }
@@ -451,8 +494,8 @@ k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ 
     };
     const int kofs = lane >> 4, l15 = lane & 15;
     double rhs = 0; /* lane = row: this wave's part of sum_l Y bl */
-    auto chunk = [&](Pre& X, int c, auto longTag) {
-        constexpr bool LONG = decltype(longTag)::value;
+    auto chunk = [&](auto& X, int c) {
+        constexpr int MAXI = std::remove_reference_t<decltype(X)>::N;
         const int p0 = c * BA_CP, p1 = min(p0 + BA_CP, d.npt);
         if (lane < BA_CP * 9) Hi[lane] = X.hq;
         ba_wave_lds_fence();
@@ -465,9 +508,9 @@ k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ 
             for (int u = 0; u < 2; u++) {
                 const int j = jj + u;
                 if (j < MAXI) {
-                    const bool live = X.kf[j] >= d.nfixed;
-                    const int it = lane + j * 64, a = it - (it / 6) * 6, pl = live ? X.pt[j] - p0 : 0;
-                    cpos[j] = live ? (6 * (X.kf[j] - d.nfixed) + a) * BA_LD + 3 * pl : BA_TRASH;
+                    const bool live = X.key[j] >= 0;
+                    const int it = lane + j * 64, a = it - (it / 6) * 6, pl = live ? (X.key[j] >> 6) - p0 : 0;
+                    cpos[j] = live ? (6 * (X.key[j] & 63) + a) * BA_LD + 3 * pl : BA_TRASH;
 #pragma unroll
                     for (int i = 0; i < 6; i++) q[u][i] = Hi[pl * 9 + i];
                 }
@@ -486,23 +529,6 @@ k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ 
                 }
             }
         }
-        const int e0c = X.e0, e1c = X.e1;
-        if constexpr (LONG)
-            for (int it = lane + MAXI * 64; it < (e1c - e0c) * 6; it += 64) { /* rows past the register capacity */
-                const int e = e0c + it / 6, a = it - (it / 6) * 6;
-                const tb_ba_obs o = obs[e];
-                if (o.kf < d.nfixed) continue;
-                const int pl = o.pt - p0, row = 6 * (o.kf - d.nfixed) + a;
-                const double* H = D + d.oHpl + (size_t)e * 18 + a * 3;
-                const double h0 = H[0], h1 = H[1], h2 = H[2];
-                const double* q6 = Hi + pl * 9;
-                double* wr = Wl + row * BA_LD + 3 * pl;
-                double* yr = Yl + row * BA_LD + 3 * pl;
-                wr[0] = h0; wr[1] = h1; wr[2] = h2;
-                yr[0] = h0 * q6[0] + h1 * q6[1] + h2 * q6[2];
-                yr[1] = h0 * q6[1] + h1 * q6[3] + h2 * q6[4];
-                yr[2] = h0 * q6[2] + h1 * q6[4] + h2 * q6[5];
-            }
         ba_wave_lds_fence();
         /* this set is free again: issue the loads of the chunk it holds next, before the MFMA phase */
         double bl[BA_CP * 3]; /* the chunk's bl, broadcast from the record registers (wave-uniform) */
@@ -539,39 +565,36 @@ k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ 
             Yl[woff] = Yl[woff + 1] = Yl[woff + 2] = 0;
             Yl[off] = Yl[off + 1] = Yl[off + 2] = 0;
         }
-        if constexpr (LONG)
-            for (int it = lane + MAXI * 64; it < (e1c - e0c) * 6; it += 64) {
-                const int e = e0c + it / 6, a = it - (it / 6) * 6;
-                const tb_ba_obs o = obs[e];
-                if (o.kf < d.nfixed) continue;
-                const int off = (6 * (o.kf - d.nfixed) + a) * BA_LD + 3 * (o.pt - p0);
-                Wl[off] = Wl[off + 1] = Wl[off + 2] = 0;
-                Yl[off] = Yl[off + 1] = Yl[off + 2] = 0;
-            }
         ba_wave_lds_fence();
     };
-    auto run = [&](auto longTag) {
-        Pre A;
+    auto run = [&](auto mTag) {
+        constexpr int M = decltype(mTag)::value;
+        BaPre<M> A;
         int ch = g * 4 + wave;
         range(A, ch);
         if constexpr (TWO) {
-            Pre B;
+            BaPre<M> B;
             range(B, ch + stride);
             preload(A, ch);
             preload(B, ch + stride);
             for (; ch + stride < d.nChunks; ch += 2 * stride) {
-                chunk(A, ch, longTag);
-                chunk(B, ch + stride, longTag);
+                chunk(A, ch);
+                chunk(B, ch + stride);
             }
-            if (ch < d.nChunks) chunk(A, ch, longTag);
+            if (ch < d.nChunks) chunk(A, ch);
         } else {
             preload(A, ch);
-            for (; ch < d.nChunks; ch += stride) chunk(A, ch, longTag);
+            for (; ch < d.nChunks; ch += stride) chunk(A, ch);
         }
     };
+    /* rows per lane held in registers: the smallest M with 64 M >= the window's longest chunk; M = R always
+     * suffices (BA_CP points seen at most once by every free keyframe: 24 nfree <= 64 R; k_ba_setup rejects repeats) */
     if (d.nChunks > 0) {
-        if (st.long_chunks) run(std::true_type{});
-        else run(std::false_type{});
+        const int mr = st.max_rows;
+        if (mr <= 64 || R == 1) run(std::integral_constant<int, 1>{});
+        else if (mr <= 128 || R == 2) run(std::integral_constant<int, (R >= 2 ? 2 : 1)>{});
+        else if (mr <= 192 || R == 3) run(std::integral_constant<int, (R >= 3 ? 3 : 1)>{});
+        else run(std::integral_constant<int, R>{});
     }
     __syncthreads();
     /* sum the four waves' accumulators through LDS in wave order (fixed shape), then one partial per block.
@@ -719,17 +742,21 @@ k_ba_update(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
     if (p < d.npt) {
         double r[3] = {D[d.oBl + (size_t)p * 3], D[d.oBl + (size_t)p * 3 + 1], D[d.oBl + (size_t)p * 3 + 2]};
         const double bl[3] = {r[0], r[1], r[2]};
-        double xl[3] = {0, 0, 0}, Hi[9];
-        if (st.ok2 && ba_inv3(D + d.oHll + (size_t)p * 6, st.lambda, Hi)) {
-            for (int e = I[d.oPtStart + p]; e < I[d.oPtStart + p + 1]; e++) {
-                const int kf = obs[e].kf;
-                if (kf < d.nfixed) continue;
-                const double* H = D + d.oHpl + (size_t)e * 18;
-                const double* xp = sx + 6 * (kf - d.nfixed);
+        double xl[3] = {0, 0, 0};
+        if (st.ok2) {
+            /* k_ba_hinv's record: the damped inverse of this trial (all zero for a singular block: xl stays 0) */
+            const double* q = D + d.oHq + (size_t)p * 9;
+            const double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5];
+            for (int ce = I[d.oPtFree + p]; ce < I[d.oPtFree + p + 1]; ce++) {
+                const int kfree = I[d.oFreeKP + ce] & 63;
+                const double* H = D + d.oHpl + (size_t)ce * 18;
+                const double* xp = sx + 6 * kfree;
                 for (int c = 0; c < 3; c++)
                     for (int a = 0; a < 6; a++) r[c] -= H[a * 3 + c] * xp[a];
             }
-            for (int a = 0; a < 3; a++) xl[a] = Hi[a * 3] * r[0] + Hi[a * 3 + 1] * r[1] + Hi[a * 3 + 2] * r[2];
+            xl[0] = q0 * r[0] + q1 * r[1] + q2 * r[2];
+            xl[1] = q1 * r[0] + q3 * r[1] + q4 * r[2];
+            xl[2] = q2 * r[0] + q4 * r[1] + q5 * r[2];
         }
         double X[3];
         for (int a = 0; a < 3; a++) {
@@ -848,9 +875,11 @@ static void ba_dims(BaDims& d, int W, const double K[4], int nkf, int nfixed, in
     unsigned long long io = 0;
     auto itake = [&](unsigned long long n) { unsigned long long r = io; io += (n + 3) & ~3ull; return r; };
     d.oPtStart = itake(npt + 1);
+    d.oPtFree = itake(npt + 1);
     d.oKfStart = itake(nkf + 1);
     d.oKfEdges = itake(obs_pitch);
-    d.oScan = itake(obs_pitch);
+    d.oScan = itake(obs_pitch + 1);
+    d.oFreeKP = itake(obs_pitch);
     d.istride = io;
 }
 
@@ -869,6 +898,7 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
     if (nfree < 1 || nfree > 10)
         return tb_fail(ctx, TB_EUNSUPPORTED, "local BA: %d free keyframes (this build supports 1..10: one 64x64 Schur tile)", nfree);
     if (nkf > TB_MAX_LEVELS * 8) return tb_fail(ctx, TB_EUNSUPPORTED, "local BA: too many keyframes");
+    if (npt > (1 << 25)) return tb_fail(ctx, TB_EUNSUPPORTED, "local BA: more than 2^25 points per window");
     BaDims d;
     ba_dims(d, W, K, nkf, nfixed, npt, obs_pitch, iters);
     if (tbk_local_ba_work_bytes(W, nkf, nfixed, npt, obs_pitch) > work_bytes) return tb_fail(ctx, TB_ENOMEM, "local BA workspace too small");
@@ -880,7 +910,7 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
     hipStream_t s = ctx->stream;
     const size_t lds = std::max<size_t>(4 * (size_t)BA_WAVE_LDS, 64 * 64) * sizeof(double);
     tb_prof_begin(ctx, "k_ba_setup");
-    hipLaunchKernelGGL(k_ba_setup, dim3(nkf + 1, W), dim3(BA_T), 0, s, d, d_poses, d_pts, d_obs, d_counts, dw, iw, states);
+    hipLaunchKernelGGL(k_ba_setup, dim3(nkf + 2, W), dim3(BA_T), 0, s, d, d_poses, d_pts, d_obs, d_counts, dw, iw, states);
     tb_prof_end(ctx);
     TB_HIP(ctx, hipGetLastError());
     int host_running = 1, rounds = 0;

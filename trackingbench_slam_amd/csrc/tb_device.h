@@ -36,6 +36,12 @@ __device__ __forceinline__ int tb_wave_sum(int v) {
     return v;
 }
 
+__device__ __forceinline__ int tb_wave_max_i(int v) {
+#pragma unroll
+    for (int d = TB_WAVE / 2; d > 0; d >>= 1) v = max(v, __shfl_xor(v, d, TB_WAVE));
+    return v;
+}
+
 /* In-place exclusive scan of arr[0..n) in LDS by the whole block; returns the total.
  * tmp: LDS, >= (blockDim.x/64 + 1) ints.  Deterministic (fixed chunking).  Ends with a barrier. */
 __device__ inline int tb_block_excl_scan(int* arr, int n, int* tmp) {
