@@ -59,23 +59,31 @@ def algorithmic_bytes(kernel, w, h, nlevels, scale, target, nimg, npairs):
     return 0
 
 
-def schur_flops_per_launch(ba_pts, nwindows, ba_kf, nfixed=2):
-    """k_ba_schur, ALGORITHMIC flops of one launch (one LM trial of every window): the lower triangle of the
-    np x np Schur block plus the reduced right-hand side, K = 3 densified columns per point. (The kernel
-    executes more: 16x16 tiles pad np = 48 to 9 tiles of 256 entries.)"""
+def schur_roofs(ba_pts, nwin, ba_kf, free_edges, nfixed=2):
+    """k_ba_schur, ALGORITHMIC work of one launch (one LM trial of `nwin` windows), DESIGN.md 'Roofline accounting':
+    flops = lower triangle of the np x np Schur block plus the reduced right-hand side, K = 3 densified columns per
+    point (the kernel executes more: 16x16 tiles pad the triangle); bytes = one 144 B Hpl block + 4 B key per
+    free-keyframe edge, one 72 B (inverse, bl) record per point, the per-workgroup partial blocks written."""
     np_ = 6 * (ba_kf - nfixed)
-    return 2.0 * (np_ * (np_ + 1) / 2 + np_) * 3 * ba_pts * nwindows
+    flops = 2.0 * (np_ * (np_ + 1) / 2 + np_) * 3 * ba_pts * nwin
+    R = (np_ + 15) // 16
+    nchunks = (ba_pts + 3) // 4
+    G = min(max(512 // max(nwin, 1), 1), max((nchunks + 3) // 4, 1))      # ba_dims() in k_ba.hip
+    out = G * (R * (R + 1) // 2 * 256 + np_) * 8
+    nbytes = free_edges * (144 + 4) + nwin * (ba_pts * 72 + out)
+    return flops, nbytes
 
 
-def pmc_traffic(kernel, frames):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/, collected at 64
-    frames per step with the guide's gfx950 FETCH_SIZE correction), scaled to this run's batch; None if absent."""
+def pmc_traffic(kernel, units):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/, collected with 64
+    images-pairs / BA windows per launch, the guide's gfx950 FETCH_SIZE correction applied), scaled to this run's
+    units per launch; None if absent."""
     path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")
     try:
         with open(path) as f:
             rec = json.load(f)["kernels"]
         key = kernel if kernel in rec else {"k_resize": "k_resize_lds"}.get(kernel, kernel)
-        return int(rec[key]["hbm_bytes_per_launch"] * frames / 64.0)
+        return int(rec[key]["hbm_bytes_per_launch"] * units / 64.0)
     except (OSError, KeyError, ValueError):
         return None
 
@@ -172,6 +180,20 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     el = float(t.item())
 
+    # after the timed region: the BA partition alone on an otherwise idle GPU (its kernels share the chip with the
+    # extractor chain and the other partition during the timed region, which stretches their HIP-event durations)
+    iso = {}
+    if rank == 0 and pipe.bas:
+        ba0, st0, cx0 = pipe.bas[0]
+        cx0.profile_report()
+        cx0.profile_enable(True)
+        with torch.cuda.stream(st0):
+            ba0.run()
+            ba0.run()
+        torch.cuda.synchronize()
+        iso = {k: v[1] / max(v[0], 1) for k, v in cx0.profile_report().items()}
+        cx0.profile_enable(False)
+
     if rank == 0:
         frames_total = args.frames * world * args.steps
         nimg, npairs = 2 * args.frames, args.frames
@@ -183,12 +205,29 @@ def main():
         avg_ms_per_step = tot_ms / max(args.steps, 1)
         kern_ms = {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items())}
         if name == "k_ba_schur":
-            fl = schur_flops_per_launch(args.ba_pts, args.frames, args.ba_kf)
-            achieved = fl / 1e12 / (tot_ms / max(calls, 1) / 1e3)
-            roofline = {"bound": "mfma", "kernel": name, "achieved": round(achieved, 3), "peak": F64_MFMA_PEAK_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(achieved / F64_MFMA_PEAK_TFLOPS, 5), "traffic": pmc_traffic(name, args.frames),
-                        "launches_per_step": launches_per_step, "avg_launch_ms": round(tot_ms / max(calls, 1), 5),
-                        "algorithmic_flops_per_launch": fl, "kernels_ms_per_step": kern_ms}
+            # one launch = one LM trial of one partition of the windows; both roofs are reported, `bound` is the
+            # nearer one (the kernel streams every Hpl block once per trial AND multiplies it on the FP64 matrix cores)
+            nwin = pipe.bas[0][0].W
+            free_edges = sum(b.free_edges for b, _, _ in pipe.bas) / max(len(pipe.bas), 1)
+            fl, nb = schur_roofs(args.ba_pts, nwin, args.ba_kf, free_edges)
+            launch_s = tot_ms / max(calls, 1) / 1e3
+            tf, gbs = fl / 1e12 / launch_s, nb / 1e9 / launch_s
+            common = {"kernel": name, "traffic": pmc_traffic(name, nwin), "launches_per_step": launches_per_step,
+                      "avg_launch_ms": round(1e3 * launch_s, 5), "algorithmic_bytes_per_launch": int(nb),
+                      "algorithmic_flops_per_launch": fl, "windows_per_launch": nwin,
+                      "hbm_frac": round(gbs / HBM_PEAK_GBS, 5), "mfma_f64_frac": round(tf / F64_MFMA_PEAK_TFLOPS, 5),
+                      "kernels_ms_per_step": kern_ms}
+            if iso.get(name):
+                il = iso[name] / 1e3
+                common["isolated"] = {"note": "same launch, BA partition alone on the GPU (after the timed region)",
+                                      "avg_launch_ms": round(iso[name], 5), "hbm_frac": round(nb / 1e9 / il / HBM_PEAK_GBS, 5),
+                                      "mfma_f64_frac": round(fl / 1e12 / il / F64_MFMA_PEAK_TFLOPS, 5)}
+            if gbs / HBM_PEAK_GBS >= tf / F64_MFMA_PEAK_TFLOPS:
+                roofline = {"bound": "hbm", "achieved": round(gbs, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(gbs / HBM_PEAK_GBS, 5), **common}
+            else:
+                roofline = {"bound": "mfma", "achieved": round(tf, 3), "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(tf / F64_MFMA_PEAK_TFLOPS, 5), **common}
         else:
             achieved = (abytes / 1e9) / (avg_ms_per_step / 1e3) if avg_ms_per_step > 0 else 0.0
             roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",

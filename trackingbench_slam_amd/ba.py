@@ -26,6 +26,9 @@ class BatchedLocalBA:
             poses[w] = Pi.reshape(nkf, 16)
             pts[w] = Xi
         self.host = dict(obs=obs, counts=cnt, poses=poses, pts=pts)
+        # edges with a free keyframe carry an Hpl block (bench.py's roofline accounting)
+        self.free_edges = int(sum(int((obs[w, :cnt[w]]["kf"] >= nfixed).sum()) for w in range(self.W)))
+        self.edges = int(cnt.sum())
         dev = device
         self.obs = torch.from_numpy(obs.view(np.uint8).reshape(self.W, self.obs_pitch, capi.BA_OBS.itemsize)).to(dev)
         self.counts = torch.from_numpy(cnt).to(dev)

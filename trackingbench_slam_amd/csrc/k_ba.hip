@@ -51,6 +51,7 @@ struct BaDims {
 };
 
 typedef double ba_d4 __attribute__((ext_vector_type(4)));
+typedef double ba_d2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ void ba_jac_pose(const double* pc, double fx, double fy, double* J) {
     const double x = pc[0], y = pc[1], invz = 1.0 / pc[2], invz_2 = invz * invz;
@@ -251,8 +252,7 @@ k_ba_points(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
             const double r1 = (c2 <= delta * delta) ? 1.0 : delta / sqrt(c2);
             const double ww = r1 * wgt;
             chi += ba_huber_rho0(c2, delta);
-            D[d.oErr + 2 * (size_t)e] = e0;
-            D[d.oErr + 2 * (size_t)e + 1] = e1;
+            *(ba_d2*)__builtin_assume_aligned(D + d.oErr + 2 * (size_t)e, 16) = (ba_d2){e0, e1};
             D[d.oWgt + e] = ww;
             po_to_R(Tk, R);
             const double x = pc[0], y = pc[1], z = pc[2];
@@ -269,10 +269,16 @@ k_ba_points(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
             Hll[5] += ww * (Jl[2] * Jl[2] + Jl[5] * Jl[5]);
             if (o.kf >= d.nfixed) {
                 ba_jac_pose(pc, d.fx, d.fy, Jp);
-                double* H = D + d.oHpl + (size_t)ce * 18;
+                /* one Hpl block = 144 B at a 16-byte aligned address: nine 16-byte stores per lane */
+                ba_d2* H = (ba_d2*)__builtin_assume_aligned(D + d.oHpl + (size_t)ce * 18, 16);
                 ce++;
+                double h[18];
+#pragma unroll
                 for (int a = 0; a < 6; a++)
-                    for (int c = 0; c < 3; c++) H[a * 3 + c] = ww * (Jp[a] * Jl[c] + Jp[6 + a] * Jl[3 + c]);
+#pragma unroll
+                    for (int c = 0; c < 3; c++) h[a * 3 + c] = ww * (Jp[a] * Jl[c] + Jp[6 + a] * Jl[3 + c]);
+#pragma unroll
+                for (int i = 0; i < 9; i++) H[i] = (ba_d2){h[2 * i], h[2 * i + 1]};
             }
         }
         for (int a = 0; a < 6; a++) D[d.oHll + (size_t)p * 6 + a] = Hll[a];
