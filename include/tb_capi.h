@@ -125,6 +125,27 @@ int tb_search_by_violence(tb_ctx* ctx, const tb_keypoint* k1, const uint8_t* d1,
                           int min_level, int max_level, float radius, int th_low, float nratio,
                           int histo_len, int check_orientation, tb_match* out, int cap, int* count);
 
+/* SURVEY 8(f) row 1 -- Matcher::searchByProjection(F1, F2), matcher.cpp:406-531 (+ Frame::GetFeaturesInArea,
+ * Frame.cpp:202-255; PinholeCamera::World2Cam, CameraModel.cpp:63-93; CameraModel::IsInFrame, CameraModel.h:33-39).
+ * F1 = current frame: pose Tcw1 (row-major 4x4), camera, level-0 image size (lookup-grid factors), keys k1,
+ * descriptors d1 (n1 x 32), taken1[i] != 0 iff F1->GetMapPoint(i) has Observations() > 0 (nullable = none).
+ * F2 = reference frame: keys k2 (octave, angle) and, aligned with them, its map points mp2 (bad != 0 also for "no
+ * map point") with descriptors mp2_desc (n2 x 32). scale_factors = F1->GetScaleFactors() (nlevels entries).
+ * Matches: queryIdx = F1 key, trainIdx = i2, imgIdx = -1, distance = Hamming; order as the reference emits them. */
+int tb_search_by_projection(tb_ctx* ctx, const float Tcw1[16], const tb_camera* cam1, int img1_width, int img1_height,
+                            const tb_keypoint* k1, const uint8_t* d1, const uint8_t* taken1, int n1,
+                            const tb_keypoint* k2, const tb_mappoint* mp2, const uint8_t* mp2_desc, int n2,
+                            const float* scale_factors, int nlevels, float nratio, int th_high, int histo_len,
+                            int check_orientation, tb_match* out, int cap, int* count);
+/* Matcher::searchByProjection(map, F1, radio), matcher.cpp:539-617 (+ Frame::IsInFrustum, Frame.cpp:370-412, entered
+ * with viewingCosLimit 0.5; the predicted level is the reference's constant 0). mps = map->GetAllMapPoints() in
+ * order; trainIdx = index into mps. */
+int tb_search_by_projection_map(tb_ctx* ctx, const float Tcw1[16], const tb_camera* cam1, int img1_width, int img1_height,
+                                const tb_keypoint* k1, const uint8_t* d1, const uint8_t* taken1, int n1,
+                                const tb_mappoint* mps, const uint8_t* mp_desc, int nmp,
+                                const float* scale_factors, int nlevels, float nratio, float radio, int th_high,
+                                tb_match* out, int cap, int* count);
+
 /* ---------------------------------------------------------------- pose optimisation / local BA
  * LocalBA::PoseOptimization, LocalBA.cpp:291-490. K = fx,fy,cx,cy. Tcw_in/out: row-major 4x4.
  * outlier: n in/out flags (Frame::GetOutlier/SetOutlier). *n_inliers = nInitialCorrespondences - nBad.

@@ -46,6 +46,26 @@ typedef struct tb_obs {
     float inv_sigma2;
 } tb_obs;
 
+/* Pinhole camera as the projection matchers use it (reference PinholeCamera, CameraModel.cpp:63-93 and
+ * CameraModel.h:33-39): focal lengths, principal point, image size for IsInFrame, and the radial-tangential
+ * coefficients d[0..4] (k1 k2 p1 p2 k3) applied iff has_distortion. */
+typedef struct tb_camera {
+    float fx, fy, cx, cy;
+    int32_t width, height;
+    int32_t has_distortion;
+    float d[5];
+} tb_camera;
+
+/* A map point as Matcher::searchByProjection / Frame::IsInFrustum read it (reference MapPoint: GetWorldPos,
+ * GetNormal, Get{Min,Max}DistanceInvariance, isBad). bad != 0 also stands for "this key has no map point" where
+ * the array is aligned with a frame's keys. Descriptors travel separately (32 bytes each). */
+typedef struct tb_mappoint {
+    float pos[3];
+    float normal[3];
+    float min_dist, max_dist;
+    int32_t bad;
+} tb_mappoint;
+
 /* One local-BA observation: keyframe index, point index, pixel, information scale. */
 typedef struct tb_ba_obs {
     int32_t kf, pt;

@@ -22,6 +22,9 @@ MATCH = np.dtype([("queryIdx", "<i4"), ("trainIdx", "<i4"), ("imgIdx", "<i4"), (
 CORNER = np.dtype([("x", "<i4"), ("y", "<i4"), ("score", "<i4")])
 OBS = np.dtype([("u", "<f4"), ("v", "<f4"), ("X", "<f4"), ("Y", "<f4"), ("Z", "<f4"), ("inv_sigma2", "<f4")])
 BA_OBS = np.dtype([("kf", "<i4"), ("pt", "<i4"), ("u", "<f4"), ("v", "<f4"), ("inv_sigma2", "<f4")])
+CAMERA = np.dtype([("fx", "<f4"), ("fy", "<f4"), ("cx", "<f4"), ("cy", "<f4"), ("width", "<i4"), ("height", "<i4"),
+                   ("has_distortion", "<i4"), ("d", "<f4", (5,))])
+MAPPOINT = np.dtype([("pos", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_dist", "<f4"), ("max_dist", "<f4"), ("bad", "<i4")])
 
 
 def build(force=False):
@@ -245,6 +248,50 @@ def search_by_violence(k1, d1, k2, d2, img2_w, img2_h, min_level=0, max_level=1,
     n = _chk(lib().orc_search_by_violence(_p(k1), _p(d1), len(k1), _p(k2), _p(d2), len(k2), int(img2_w), int(img2_h),
                                           int(min_level), int(max_level), C.c_float(radius), int(th_low),
                                           C.c_float(nratio), int(histo_len), int(check_orientation), _p(out), len(out)))
+    return out[:n].copy()
+
+
+def camera(fx, fy, cx, cy, width, height, dist=None):
+    """tb_camera record (PinholeCamera of the reference); dist = (k1, k2, p1, p2, k3) or None."""
+    c = np.zeros(1, CAMERA)
+    c["fx"], c["fy"], c["cx"], c["cy"], c["width"], c["height"] = fx, fy, cx, cy, width, height
+    if dist is not None:
+        c["has_distortion"] = 1
+        c["d"][0] = np.asarray(dist, np.float32)
+    return c
+
+
+def search_by_projection(Tcw1, cam1, img1_w, img1_h, k1, d1, taken1, k2, mp2, mp2_desc, scale_factors, nratio,
+                         th_high=100, histo_len=30, check_orientation=True):
+    """Matcher::searchByProjection(F1, F2) (matcher.cpp:406-531); mp2 / mp2_desc aligned with F2's keys."""
+    Tcw1 = np.ascontiguousarray(Tcw1, np.float32).reshape(16)
+    cam1 = np.ascontiguousarray(cam1, CAMERA)
+    k1 = np.ascontiguousarray(k1, KEYPOINT); k2 = np.ascontiguousarray(k2, KEYPOINT)
+    d1, mp2_desc = _desc(d1), _desc(mp2_desc)
+    taken1 = np.ascontiguousarray(taken1, np.uint8)
+    mp2 = np.ascontiguousarray(mp2, MAPPOINT)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    out = np.zeros(max(len(k2), 1), MATCH)
+    n = _chk(lib().orc_search_by_projection(_p(Tcw1), _p(cam1), int(img1_w), int(img1_h), _p(k1), _p(d1), _p(taken1), len(k1),
+                                            _p(k2), _p(mp2), _p(mp2_desc), len(k2), _p(sf), len(sf), C.c_float(nratio),
+                                            int(th_high), int(histo_len), int(check_orientation), _p(out), len(out)))
+    return out[:n].copy()
+
+
+def search_by_projection_map(Tcw1, cam1, img1_w, img1_h, k1, d1, taken1, mps, mp_desc, scale_factors, nratio, radio,
+                             th_high=100):
+    """Matcher::searchByProjection(map, F1, radio) (matcher.cpp:539-617)."""
+    Tcw1 = np.ascontiguousarray(Tcw1, np.float32).reshape(16)
+    cam1 = np.ascontiguousarray(cam1, CAMERA)
+    k1 = np.ascontiguousarray(k1, KEYPOINT)
+    d1, mp_desc = _desc(d1), _desc(mp_desc)
+    taken1 = np.ascontiguousarray(taken1, np.uint8)
+    mps = np.ascontiguousarray(mps, MAPPOINT)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    out = np.zeros(max(len(mps), 1), MATCH)
+    n = _chk(lib().orc_search_by_projection_map(_p(Tcw1), _p(cam1), int(img1_w), int(img1_h), _p(k1), _p(d1), _p(taken1),
+                                                len(k1), _p(mps), _p(mp_desc), len(mps), _p(sf), len(sf),
+                                                C.c_float(nratio), C.c_float(radio), int(th_high), _p(out), len(out)))
     return out[:n].copy()
 
 

@@ -71,6 +71,21 @@ int orc_search_by_violence(const tb_keypoint* k1, const uint8_t* d1, int n1,
                            int th_low, float nratio, int histo_len, int check_orientation,
                            tb_match* out, int cap);
 
+/* SURVEY 8(f) row 1 -- Matcher::searchByProjection(F1, F2), matcher.cpp:406-531 (PARITY UNPINNED, see the .cpp).
+ * mp2 / mp2_desc are aligned with F2's keys (bad != 0: no usable map point); taken1[i] != 0: F1's key i already
+ * has a map point with observations; img1_w/h = level-0 size of F1 (grid factors). */
+int orc_search_by_projection(const float Tcw1[16], const tb_camera* cam1, int img1_w, int img1_h,
+                             const tb_keypoint* k1, const uint8_t* d1, const uint8_t* taken1, int n1,
+                             const tb_keypoint* k2, const tb_mappoint* mp2, const uint8_t* mp2_desc, int n2,
+                             const float* scale_factors, int nlevels, float nratio, int th_high, int histo_len,
+                             int check_orientation, tb_match* out, int cap);
+/* Matcher::searchByProjection(map, F1, radio), matcher.cpp:539-617 + Frame::IsInFrustum, Frame.cpp:370-412. */
+int orc_search_by_projection_map(const float Tcw1[16], const tb_camera* cam1, int img1_w, int img1_h,
+                                 const tb_keypoint* k1, const uint8_t* d1, const uint8_t* taken1, int n1,
+                                 const tb_mappoint* mps, const uint8_t* mp_desc, int nmp,
+                                 const float* scale_factors, int nlevels, float nratio, float radio, int th_high,
+                                 tb_match* out, int cap);
+
 /* LocalBA::PoseOptimization, LocalBA.cpp:291-490 (g2o LM restated).
  * K = fx,fy,cx,cy. Tcw_in: row-major 4x4 float (vertex reset value). outlier: in/out flags.
  * Returns nInitialCorrespondences - nBad (>=0) or <0 on error. */

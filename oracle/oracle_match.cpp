@@ -206,3 +206,210 @@ int orc_search_by_violence(const tb_keypoint* k1, const uint8_t* d1, int n1,
 }
 
 }  // extern "C"
+
+/* ------------------------------------------------------------------------------------------------
+ * Matcher::searchByProjection, both overloads (matcher.cpp:406-617), with
+ * Frame::GetFeaturesInArea (Frame.cpp:202-255), Frame::IsInFrustum (Frame.cpp:370-412),
+ * PinholeCamera::World2Cam (CameraModel.cpp:63-93) and CameraModel::IsInFrame (CameraModel.h:33-39).
+ * PARITY UNPINNED: the reference holds no vectors for these functions and its float results depend on the Eigen
+ * version and compiler flags of its build. Restated here with Eigen 3.3's fixed-size reduction order
+ * (c0 + (c1 + c2), redux_novec_unroller) and no FMA contraction; the HIP path is checked against this. */
+namespace {
+struct Grid {
+    static const int ROWS = 36, COLS = 120;
+    float heightInv, widthInv; /* swapped in the reference (Frame.cpp:30-31); kept */
+    std::vector<std::vector<int>> cells;
+    Grid(const tb_keypoint* k, int n, int img_w, int img_h) : cells((size_t)COLS * ROWS) {
+        heightInv = (float)COLS / (float)img_w;
+        widthInv = (float)ROWS / (float)img_h;
+        for (int i = 0; i < n; i++) { /* Frame::AssignFeaturesToGrid + PosInGrid, Frame.cpp:187-200,257-265 */
+            const int posX = (int)std::round(k[i].x * widthInv), posY = (int)std::round(k[i].y * heightInv);
+            if (posX < 0 || posX >= COLS || posY < 0 || posY >= ROWS) continue;
+            cells[(size_t)posX * ROWS + posY].push_back(i);
+        }
+    }
+    /* Frame::GetFeaturesInArea, Frame.cpp:202-255 */
+    void area(const tb_keypoint* k, float x, float y, float r, int minLevel, int maxLevel, std::vector<int>& out) const {
+        out.clear();
+        const int nMinCellX = std::max(0, (int)std::floor((x - r) * widthInv));
+        if (nMinCellX >= COLS) return;
+        const int nMaxCellX = std::min(COLS - 1, (int)std::ceil((x + r) * widthInv));
+        if (nMaxCellX < 0) return;
+        const int nMinCellY = std::max(0, (int)std::floor((y - r) * heightInv));
+        if (nMinCellY >= ROWS) return;
+        const int nMaxCellY = std::min(ROWS - 1, (int)std::ceil((y + r) * heightInv));
+        if (nMaxCellY < 0) return;
+        const bool bCheckLevels = (minLevel > 0) || (maxLevel >= 0);
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+            for (int iy = nMinCellY; iy <= nMaxCellY; iy++)
+                for (int j : cells[(size_t)ix * ROWS + iy]) {
+                    if (bCheckLevels) {
+                        if (k[j].octave < minLevel) continue;
+                        if (maxLevel >= 0 && k[j].octave > maxLevel) continue;
+                    }
+                    const float distx = k[j].x - x, disty = k[j].y - y;
+                    if (std::fabs(distx) < r && std::fabs(disty) < r) out.push_back(j);
+                }
+    }
+};
+
+/* Rcw * X + tcw, row-major 4x4 T; each coefficient c0 + (c1 + c2), then + t */
+inline void se3_map(const float* T, const float* X, float* Pc) {
+    for (int i = 0; i < 3; i++) {
+        const float c0 = T[4 * i] * X[0], c1 = T[4 * i + 1] * X[1], c2 = T[4 * i + 2] * X[2];
+        Pc[i] = (c0 + (c1 + c2)) + T[4 * i + 3];
+    }
+}
+/* PinholeCamera::World2Cam(xyz_c), CameraModel.cpp:63-93 */
+inline void world2cam(const tb_camera* cam, const float* Pc, float* px) {
+    const float x = Pc[0] / Pc[2], y = Pc[1] / Pc[2];
+    if (!cam->has_distortion) {
+        px[0] = cam->fx * x + cam->cx;
+        px[1] = cam->fy * y + cam->cy;
+    } else {
+        const float* md = cam->d;
+        const float r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+        const float a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
+        const float cdist = 1 + md[0] * r2 + md[1] * r4 + md[4] * r6;
+        const float xd = x * cdist + md[2] * a1 + md[3] * a2;
+        const float yd = y * cdist + md[2] * a3 + md[3] * a1;
+        px[0] = xd * cam->fx + cam->cx;
+        px[1] = yd * cam->fy + cam->cy;
+    }
+}
+/* IsInFrame(uv.cast<int>()), CameraModel.h:33-39: the cast truncates; a non-finite or out-of-int-range
+ * coordinate converts to INT_MIN on x86 (cvttss2si) and fails the test */
+inline bool in_frame(const tb_camera* cam, const float* px) {
+    if (!(std::fabs(px[0]) < 2147483648.f) || !(std::fabs(px[1]) < 2147483648.f)) return false;
+    const int u = (int)px[0], v = (int)px[1];
+    return u >= 0 && u < (int)((float)cam->width * 1.f) && v >= 0 && v < (int)((float)cam->height * 1.f);
+}
+}  // namespace
+
+extern "C" {
+
+/* Matcher::searchByProjection(F1, F2), matcher.cpp:406-531. mp2 / mp2_desc are aligned with F2's keys. */
+int orc_search_by_projection(const float Tcw1[16], const tb_camera* cam1, int img1_w, int img1_h,
+                             const tb_keypoint* k1, const uint8_t* d1, const uint8_t* taken1, int n1,
+                             const tb_keypoint* k2, const tb_mappoint* mp2, const uint8_t* mp2_desc, int n2,
+                             const float* scale_factors, int nlevels, float nratio, int th_high, int histo_len,
+                             int check_orientation, tb_match* out, int cap) {
+    if (n1 < 0 || n2 < 0 || histo_len < 1 || nlevels < 1) return TB_EINVAL;
+    const Grid grid(k1, n1, img1_w, img1_h);
+    std::vector<tb_match> matches;
+    std::vector<std::vector<int>> rotHist(histo_len);
+    const float factor = 1.0f / (float)histo_len;
+    std::vector<int> cand;
+    for (int i2 = 0; i2 < n2; i2++) {
+        if (mp2[i2].bad) continue;
+        float Pc[3], uv[2];
+        se3_map(Tcw1, mp2[i2].pos, Pc);
+        const float invzc = 1.0f / Pc[2];
+        if (invzc < 0) continue;
+        world2cam(cam1, Pc, uv);
+        if (!in_frame(cam1, uv)) continue;
+        const int nLastOctave = k2[i2].octave;
+        if (nLastOctave < 0 || nLastOctave >= nlevels) return TB_EINVAL; /* the reference indexes out of range */
+        const float radius = nratio * scale_factors[nLastOctave];
+        grid.area(k1, uv[0], uv[1], radius, nLastOctave - 1, nLastOctave + 1, cand);
+        if (cand.empty()) continue;
+        int bestDist = 256, bestIdx1 = -1;
+        for (int i1 : cand) {
+            if (taken1 && taken1[i1]) continue; /* F1->GetMapPoint(i1) with Observations() > 0 */
+            const int dist = orc_descriptor_distance(mp2_desc + 32 * (size_t)i2, d1 + 32 * (size_t)i1);
+            if (dist < bestDist) { bestDist = dist; bestIdx1 = i1; }
+        }
+        if (bestDist <= th_high && bestIdx1 >= 0) {
+            tb_match m{bestIdx1, i2, -1, (float)bestDist};
+            matches.push_back(m);
+            if (check_orientation) {
+                float rot = k2[i2].angle - k1[bestIdx1].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)std::roundf(rot * factor);
+                if (bin == histo_len) bin = 0;
+                if (bin < 0 || bin >= histo_len) return TB_EUNSUPPORTED; /* reference asserts */
+                rotHist[bin].push_back((int)matches.size() - 1);
+            }
+        }
+    }
+    std::vector<tb_match> good;
+    if (check_orientation) {
+        std::vector<int> sizes(histo_len);
+        for (int i = 0; i < histo_len; i++) sizes[i] = (int)rotHist[i].size();
+        int ind[3] = {-1, -1, -1};
+        orc_three_maxima(sizes.data(), histo_len, &ind[0], &ind[1], &ind[2]);
+        for (int i = 0; i < histo_len; i++)
+            if (i == ind[0] || i == ind[1] || i == ind[2])
+                for (int item : rotHist[i]) good.push_back(matches[item]);
+    } else {
+        good = matches;
+    }
+    if (out) {
+        if ((int)good.size() > cap) return TB_ECAPACITY;
+        std::copy(good.begin(), good.end(), out);
+    }
+    return (int)good.size();
+}
+
+/* Matcher::searchByProjection(map, F1, radio), matcher.cpp:539-617, over Frame::IsInFrustum (Frame.cpp:370-412;
+ * viewingCosLimit enters as 0.5, the predicted level is the constant 0 of the reference's TODO). */
+int orc_search_by_projection_map(const float Tcw1[16], const tb_camera* cam1, int img1_w, int img1_h,
+                                 const tb_keypoint* k1, const uint8_t* d1, const uint8_t* taken1, int n1,
+                                 const tb_mappoint* mps, const uint8_t* mp_desc, int nmp,
+                                 const float* scale_factors, int nlevels, float nratio, float radio, int th_high,
+                                 tb_match* out, int cap) {
+    if (n1 < 0 || nmp < 0 || nlevels < 1) return TB_EINVAL;
+    const Grid grid(k1, n1, img1_w, img1_h);
+    /* Frame::SetPose, Frame.cpp:50-62: mOw = -Rcw^T * tcw */
+    float Ow[3];
+    for (int i = 0; i < 3; i++) {
+        const float c0 = -Tcw1[i] * Tcw1[3], c1 = -Tcw1[4 + i] * Tcw1[7], c2 = -Tcw1[8 + i] * Tcw1[11];
+        Ow[i] = c0 + (c1 + c2);
+    }
+    const bool bFactor = nratio != 1.0;
+    std::vector<tb_match> matches;
+    std::vector<int> cand;
+    for (int im = 0; im < nmp; im++) {
+        const tb_mappoint& mp = mps[im];
+        if (mp.bad) continue;
+        /* IsInFrustum */
+        float Pc[3], uv[2];
+        se3_map(Tcw1, mp.pos, Pc);
+        if (Pc[2] < 0.0f) continue;
+        world2cam(cam1, Pc, uv);
+        if (!in_frame(cam1, uv)) continue;
+        const float PO[3] = {mp.pos[0] - Ow[0], mp.pos[1] - Ow[1], mp.pos[2] - Ow[2]};
+        const float dist3 = std::sqrt(PO[0] * PO[0] + (PO[1] * PO[1] + PO[2] * PO[2]));
+        if (dist3 < mp.min_dist || dist3 > mp.max_dist) continue;
+        const float viewCos = (PO[0] * mp.normal[0] + (PO[1] * mp.normal[1] + PO[2] * mp.normal[2])) / dist3;
+        if (viewCos < 0.5f) continue;
+        const int nPredictedLevel = 0;
+        float r = 4.f;
+        if (viewCos > 0.998) r = 2.5;
+        if (bFactor) r *= nratio;
+        grid.area(k1, uv[0], uv[1], r * scale_factors[nPredictedLevel], nPredictedLevel - 1, nPredictedLevel, cand);
+        if (cand.empty()) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int idx : cand) {
+            if (taken1 && taken1[idx]) continue;
+            const int dist = orc_descriptor_distance(mp_desc + 32 * (size_t)im, d1 + 32 * (size_t)idx);
+            if (dist < bestDist) {
+                bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = k1[idx].octave; bestIdx = idx;
+            } else if (dist < bestDist2) {
+                bestLevel2 = k1[idx].octave; bestDist2 = dist;
+            }
+        }
+        if (bestDist <= th_high && bestIdx >= 0) {
+            if (bestLevel == bestLevel2 && (float)bestDist > radio * (float)bestDist2) continue;
+            tb_match m{bestIdx, im, -1, (float)bestDist};
+            matches.push_back(m);
+        }
+    }
+    if (out) {
+        if ((int)matches.size() > cap) return TB_ECAPACITY;
+        std::copy(matches.begin(), matches.end(), out);
+    }
+    return (int)matches.size();
+}
+
+}  // extern "C"

@@ -1,0 +1,70 @@
+"""GPU parity tests (pytest -m gpu): Matcher::searchByProjection, both overloads (reference
+matcher.cpp:406-617), through the C ABI against the oracle -- bit exact (indices, Hamming distances, order).
+PARITY UNPINNED against the reference itself: it holds no vectors for these functions (see oracle/oracle_match.cpp)."""
+import numpy as np
+import pytest
+
+import oracle
+from trackingbench_slam_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+DIST = (-0.02, 0.004, 0.0002, 0.00002, 0.001)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    c = capi.Context(0)
+    yield c
+    c.close()
+
+
+def _same(a, b):
+    assert len(a) == len(b)
+    for f in ("queryIdx", "trainIdx", "imgIdx", "distance"):
+        assert np.array_equal(a[f], b[f]), f
+
+
+@pytest.mark.parametrize("seed,n1,nmp,dist", [(1, 1500, 1200, None), (2, 2000, 2000, None), (3, 2000, 1500, DIST),
+                                              (7, 300, 5000, None), (8, 4000, 64, None)])
+def test_projection_frames(ctx, seed, n1, nmp, dist):
+    c = synth.projection_case(seed, n1=n1, nmp=nmp, distortion=dist)
+    for nratio, th, check in ((8.0, 100, True), (3.0, 60, False), (15.0, 100, True)):
+        a = (c["Tcw"], c["cam"], c["width"], c["height"], c["k1"], c["d1"], c["taken1"], c["k2"], c["mp"], c["mp_desc"], c["sf"], nratio)
+        mo = oracle.search_by_projection(*a, th_high=th, check_orientation=check)
+        mg = ctx.search_by_projection(*a, th_high=th, check_orientation=check)
+        assert len(mo) > 0
+        _same(mg, mo)
+
+
+@pytest.mark.parametrize("seed,n1,nmp,dist", [(4, 2000, 3000, None), (5, 2000, 1500, DIST), (9, 500, 20000, None)])
+def test_projection_map(ctx, seed, n1, nmp, dist):
+    c = synth.projection_case(seed, n1=n1, nmp=nmp, distortion=dist)
+    c["k1"]["octave"][::2] = 0
+    for nratio, radio in ((3.0, 0.8), (1.0, 0.6), (6.0, 1.0)):
+        a = (c["Tcw"], c["cam"], c["width"], c["height"], c["k1"], c["d1"], c["taken1"], c["mp"], c["mp_desc"], c["sf"], nratio, radio)
+        mo = oracle.search_by_projection_map(*a)
+        mg = ctx.search_by_projection_map(*a)
+        assert len(mo) > 0
+        _same(mg, mo)
+
+
+def test_projection_edges(ctx):
+    c = synth.projection_case(6, n1=200, nmp=100)
+    args = (c["Tcw"], c["cam"], c["width"], c["height"])
+    sf = c["sf"]
+    assert len(ctx.search_by_projection(*args, c["k1"], c["d1"], c["taken1"], c["k2"][:0], c["mp"][:0], c["mp_desc"][:0], sf, 8.0)) == 0
+    assert len(ctx.search_by_projection(*args, c["k1"][:0], c["d1"][:0], c["taken1"][:0], c["k2"], c["mp"], c["mp_desc"], sf, 8.0)) == 0
+    bad = c["mp"].copy(); bad["bad"] = 1
+    assert len(ctx.search_by_projection(*args, c["k1"], c["d1"], c["taken1"], c["k2"], bad, c["mp_desc"], sf, 8.0)) == 0
+    assert len(ctx.search_by_projection_map(*args, c["k1"], c["d1"], c["taken1"], bad, c["mp_desc"], sf, 3.0, 0.8)) == 0
+    assert len(ctx.search_by_projection(*args, c["k1"], c["d1"], np.ones(200, np.uint8), c["k2"], c["mp"], c["mp_desc"], sf, 8.0)) == 0
+    k2 = c["k2"].copy(); k2["octave"][:] = 9
+    with pytest.raises(capi.TBError):
+        ctx.search_by_projection(*args, c["k1"], c["d1"], c["taken1"], k2, c["mp"], c["mp_desc"], sf, 8.0)
+    # points exactly behind / at the camera plane and non-finite positions are skipped, not matched
+    odd = c["mp"].copy()
+    odd["pos"][:10] = np.nan
+    odd["pos"][10:20] = np.inf
+    mo = oracle.search_by_projection(*args, c["k1"], c["d1"], c["taken1"], c["k2"], odd, c["mp_desc"], sf, 8.0)
+    mg = ctx.search_by_projection(*args, c["k1"], c["d1"], c["taken1"], c["k2"], odd, c["mp_desc"], sf, 8.0)
+    _same(mg, mo)

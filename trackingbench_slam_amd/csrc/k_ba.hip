@@ -452,7 +452,6 @@ k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ 
     double* Yl = lds + (size_t)wave * BA_WAVE_LDS; /* [64][BA_LD]: Hpl * (Hll + lambda I)^-1 */
     double* Wl = Yl + 64 * BA_LD;                  /* [64][BA_LD]: Hpl; row np holds bl */
     double* Hi = Wl + 64 * BA_LD;                  /* [BA_CP][9] */
-    const tb_ba_obs* obs = obsAll + (size_t)w * d.obs_pitch;
     double* D = dw + (size_t)w * d.wstride;
     const int* I = iw + (size_t)w * d.istride;
     ba_d4 acc[BA_MAXT][BA_MAXT];

@@ -199,3 +199,173 @@ int tbk_window_match(tb_ctx* ctx, const tb_keypoint* d_k1, const uint8_t* d_d1, 
     TB_HIP(ctx, hipGetLastError());
     return TB_OK;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * SURVEY 8(f) row 1 -- Matcher::searchByProjection, both overloads (matcher.cpp:406-617).
+ * Two steps on the device: (1) one thread per map point projects it into F1 and derives its search window
+ * (k_project_frame: matcher.cpp:431-458; k_project_map: Frame::IsInFrustum, Frame.cpp:370-412, and
+ * matcher.cpp:558-567), (2) one thread per query walks F1's 120x36 lookup grid in the reference's order
+ * (ix, iy, insertion) and keeps best / second best with their levels (k_window_q). Float arithmetic: one rounding
+ * per reference operation, fixed-size Eigen 3.3 reduction order c0 + (c1 + c2), no FMA contraction. */
+#pragma clang fp contract(off)
+struct ProjPose { float T[16]; };
+struct ProjQuery { float u, v, r; int32_t minL, maxL; };  /* r < 0: no search for this map point */
+
+__device__ __forceinline__ void pj_se3_map(const ProjPose& P, const float* X, float* Pc) {
+#pragma unroll
+    for (int i = 0; i < 3; i++) {
+        const float c0 = P.T[4 * i] * X[0], c1 = P.T[4 * i + 1] * X[1], c2 = P.T[4 * i + 2] * X[2];
+        Pc[i] = (c0 + (c1 + c2)) + P.T[4 * i + 3];
+    }
+}
+__device__ __forceinline__ void pj_world2cam(const tb_camera& cam, const float* Pc, float* px) {
+    const float x = Pc[0] / Pc[2], y = Pc[1] / Pc[2];
+    if (!cam.has_distortion) {
+        px[0] = cam.fx * x + cam.cx;
+        px[1] = cam.fy * y + cam.cy;
+    } else {
+        const float r2 = x * x + y * y, r4 = r2 * r2, r6 = r4 * r2;
+        const float a1 = 2 * x * y, a2 = r2 + 2 * x * x, a3 = r2 + 2 * y * y;
+        const float cdist = 1 + cam.d[0] * r2 + cam.d[1] * r4 + cam.d[4] * r6;
+        const float xd = x * cdist + cam.d[2] * a1 + cam.d[3] * a2;
+        const float yd = y * cdist + cam.d[2] * a3 + cam.d[3] * a1;
+        px[0] = xd * cam.fx + cam.cx;
+        px[1] = yd * cam.fy + cam.cy;
+    }
+}
+__device__ __forceinline__ bool pj_in_frame(const tb_camera& cam, const float* px) {
+    if (!(fabsf(px[0]) < 2147483648.f) || !(fabsf(px[1]) < 2147483648.f)) return false; /* x86 cast -> INT_MIN */
+    const int u = (int)px[0], v = (int)px[1];
+    return u >= 0 && u < (int)((float)cam.width * 1.f) && v >= 0 && v < (int)((float)cam.height * 1.f);
+}
+
+__global__ void __launch_bounds__(256)
+k_project_frame(ProjPose P, tb_camera cam, const tb_keypoint* __restrict__ k2, const tb_mappoint* __restrict__ mp2, int n2,
+                const float* __restrict__ sf, int nlevels, float nratio, ProjQuery* __restrict__ q, int* __restrict__ bad_octave) {
+    const int i2 = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i2 >= n2) return;
+    ProjQuery o = {0.f, 0.f, -1.f, 0, 0};
+    const tb_mappoint mp = mp2[i2];
+    if (!mp.bad) {
+        float Pc[3], uv[2];
+        pj_se3_map(P, mp.pos, Pc);
+        const float invzc = 1.0f / Pc[2];
+        if (!(invzc < 0)) {
+            pj_world2cam(cam, Pc, uv);
+            if (pj_in_frame(cam, uv)) {
+                const int oct = k2[i2].octave;
+                if (oct < 0 || oct >= nlevels) *bad_octave = 1; /* benign race: every writer stores 1 */
+                else { o.u = uv[0]; o.v = uv[1]; o.r = nratio * sf[oct]; o.minL = oct - 1; o.maxL = oct + 1; }
+            }
+        }
+    }
+    q[i2] = o;
+}
+
+__global__ void __launch_bounds__(256)
+k_project_map(ProjPose P, tb_camera cam, const tb_mappoint* __restrict__ mps, int nmp, float sf0, float nratio,
+              ProjQuery* __restrict__ q) {
+    const int im = blockIdx.x * blockDim.x + threadIdx.x;
+    if (im >= nmp) return;
+    ProjQuery o = {0.f, 0.f, -1.f, 0, 0};
+    const tb_mappoint mp = mps[im];
+    if (!mp.bad) {
+        float Pc[3], uv[2], Ow[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) { /* Frame::SetPose: mOw = -Rcw^T tcw */
+            const float c0 = -P.T[i] * P.T[3], c1 = -P.T[4 + i] * P.T[7], c2 = -P.T[8 + i] * P.T[11];
+            Ow[i] = c0 + (c1 + c2);
+        }
+        pj_se3_map(P, mp.pos, Pc);
+        if (!(Pc[2] < 0.0f)) {
+            pj_world2cam(cam, Pc, uv);
+            if (pj_in_frame(cam, uv)) {
+                const float PO[3] = {mp.pos[0] - Ow[0], mp.pos[1] - Ow[1], mp.pos[2] - Ow[2]};
+                const float dist3 = sqrtf(PO[0] * PO[0] + (PO[1] * PO[1] + PO[2] * PO[2]));
+                if (!(dist3 < mp.min_dist || dist3 > mp.max_dist)) {
+                    const float viewCos = (PO[0] * mp.normal[0] + (PO[1] * mp.normal[1] + PO[2] * mp.normal[2])) / dist3;
+                    if (!(viewCos < 0.5f)) {
+                        float r = 4.f;
+                        if ((double)viewCos > 0.998) r = 2.5f;
+                        if ((double)nratio != 1.0) r *= nratio;
+                        o.u = uv[0]; o.v = uv[1]; o.r = r * sf0; o.minL = -1; o.maxL = 0;
+                    }
+                }
+            }
+        }
+    }
+    q[im] = o;
+}
+
+/* best[6 q]: bestDist, bestDist2, bestIdx, bestLevel, bestLevel2, candidates in the window */
+__global__ void __launch_bounds__(256)
+k_window_q(const ProjQuery* __restrict__ q, const uint8_t* __restrict__ qd, int nq, const tb_keypoint* __restrict__ k1,
+           const uint8_t* __restrict__ d1, const uint8_t* __restrict__ taken1, const int32_t* __restrict__ cellStart,
+           const int32_t* __restrict__ cellItems, float widthInv, float heightInv, int32_t* __restrict__ best) {
+    const int GRID_ROWS = 36, GRID_COLS = 120;
+    const int iq = blockIdx.x * blockDim.x + threadIdx.x;
+    if (iq >= nq) return;
+    int bestDist = 256, bestDist2 = 256, bestIdx = -1, bestLevel = -1, bestLevel2 = -1, ncand = 0;
+    const ProjQuery w = q[iq];
+    if (w.r >= 0.f) {
+        const float x = w.u, y = w.v, r = w.r;
+        const int nMinCellX = max(0, (int)floorf((x - r) * widthInv));
+        const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf((x + r) * widthInv));
+        const int nMinCellY = max(0, (int)floorf((y - r) * heightInv));
+        const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf((y + r) * heightInv));
+        if (nMinCellX < GRID_COLS && nMaxCellX >= 0 && nMinCellY < GRID_ROWS && nMaxCellY >= 0) {
+            const bool bCheckLevels = (w.minL > 0) || (w.maxL >= 0);
+            const unsigned long long* a = reinterpret_cast<const unsigned long long*>(qd) + (size_t)iq * 4;
+            Desc256 da;
+            da.w[0] = a[0]; da.w[1] = a[1]; da.w[2] = a[2]; da.w[3] = a[3];
+            for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+                for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+                    const int c = ix * GRID_ROWS + iy;
+                    for (int s = cellStart[c]; s < cellStart[c + 1]; s++) {
+                        const int j = cellItems[s];
+                        const tb_keypoint kp = k1[j];
+                        if (bCheckLevels) {
+                            if (kp.octave < w.minL) continue;
+                            if (w.maxL >= 0 && kp.octave > w.maxL) continue;
+                        }
+                        if (!(fabsf(kp.x - x) < r && fabsf(kp.y - y) < r)) continue;
+                        ncand++;
+                        if (taken1[j]) continue;
+                        const int dist = bf_dist(da, reinterpret_cast<const unsigned long long*>(d1) + (size_t)j * 4);
+                        if (dist < bestDist) {
+                            bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = kp.octave; bestIdx = j;
+                        } else if (dist < bestDist2) {
+                            bestLevel2 = kp.octave; bestDist2 = dist;
+                        }
+                    }
+                }
+        }
+    }
+    int32_t* o = best + (size_t)iq * 6;
+    o[0] = bestDist; o[1] = bestDist2; o[2] = bestIdx; o[3] = bestLevel; o[4] = bestLevel2; o[5] = ncand;
+}
+
+int tbk_projection_search(tb_ctx* ctx, int map_overload, const float Tcw[16], const tb_camera* cam, const tb_keypoint* d_k2,
+                          const tb_mappoint* d_mp, const uint8_t* d_mpdesc, int nq, const float* d_sf, int nlevels, float sf0,
+                          float nratio, const tb_keypoint* d_k1, const uint8_t* d_d1, const uint8_t* d_taken1,
+                          const int32_t* d_cellStart, const int32_t* d_cellItems, float widthInv, float heightInv,
+                          void* d_queries, int32_t* d_best, int* d_flag) {
+    if (nq <= 0) return TB_OK;
+    ProjPose P;
+    for (int i = 0; i < 16; i++) P.T[i] = Tcw[i];
+    ProjQuery* q = (ProjQuery*)d_queries;
+    tb_prof_begin(ctx, "k_project");
+    if (map_overload)
+        hipLaunchKernelGGL(k_project_map, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, P, *cam, d_mp, nq, sf0, nratio, q);
+    else
+        hipLaunchKernelGGL(k_project_frame, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, P, *cam, d_k2, d_mp, nq, d_sf,
+                           nlevels, nratio, q, d_flag);
+    tb_prof_end(ctx);
+    TB_HIP(ctx, hipGetLastError());
+    tb_prof_begin(ctx, "k_window_q");
+    hipLaunchKernelGGL(k_window_q, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, q, d_mpdesc, nq, d_k1, d_d1, d_taken1,
+                       d_cellStart, d_cellItems, widthInv, heightInv, d_best);
+    tb_prof_end(ctx);
+    TB_HIP(ctx, hipGetLastError());
+    return TB_OK;
+}

@@ -915,6 +915,159 @@ int tb_search_by_violence(tb_ctx* ctx, const tb_keypoint* k1, const uint8_t* d1,
     return TB_OK;
 }
 
+/* ---- Matcher::searchByProjection, both overloads (matcher.cpp:406-617) */
+namespace {
+struct ProjHost {
+    std::vector<int32_t> best;
+    int bad_octave = 0;
+};
+/* upload F1 (keys, descriptors, taken flags, lookup grid) and the map points, run projection + window search */
+int projection_run(tb_ctx* ctx, int map_overload, const float Tcw1[16], const tb_camera* cam1, int img1_w, int img1_h,
+                   const tb_keypoint* k1, const uint8_t* d1, const uint8_t* taken1, int n1, const tb_keypoint* k2,
+                   const tb_mappoint* mps, const uint8_t* mp_desc, int nq, const float* sf, int nlevels, float nratio,
+                   ProjHost& H) {
+    const int GRID_ROWS = 36, GRID_COLS = 120;
+    const float heightInv = (float)GRID_COLS / (float)img1_w; /* swapped in the reference (Frame.cpp:30-31); kept */
+    const float widthInv = (float)GRID_ROWS / (float)img1_h;
+    std::vector<int32_t> cellOf((size_t)std::max(n1, 1)), start((size_t)GRID_COLS * GRID_ROWS + 1, 0), items((size_t)std::max(n1, 1));
+    for (int i = 0; i < n1; i++) {
+        const int posX = (int)roundf(k1[i].x * widthInv), posY = (int)roundf(k1[i].y * heightInv);
+        cellOf[i] = (posX < 0 || posX >= GRID_COLS || posY < 0 || posY >= GRID_ROWS) ? -1 : posX * GRID_ROWS + posY;
+        if (cellOf[i] >= 0) start[cellOf[i] + 1]++;
+    }
+    for (size_t c = 0; c < (size_t)GRID_COLS * GRID_ROWS; c++) start[c + 1] += start[c];
+    {
+        std::vector<int32_t> fill(start.begin(), start.end() - 1);
+        for (int i = 0; i < n1; i++)
+            if (cellOf[i] >= 0) items[fill[cellOf[i]]++] = i;
+    }
+    const size_t m1 = (size_t)std::max(n1, 1), mq = (size_t)nq;
+    /* slot 7 holds the small arrays back to back (16-byte aligned pieces) */
+    auto al = [](size_t x) { return (x + 15) & ~(size_t)15; };
+    const size_t oMp = 0, oTaken = al(oMp + mq * sizeof(tb_mappoint)), oSf = al(oTaken + m1), oQ = al(oSf + (size_t)nlevels * 4),
+                 oFlag = al(oQ + mq * 20), misc = oFlag + 16;
+    void *dd1, *dmd, *dk1, *dk2, *dst, *dit, *dbest, *dmisc;
+    int rc;
+    if ((rc = tb_scratch(ctx, 0, m1 * 32, &dd1))) return rc;
+    if ((rc = tb_scratch(ctx, 1, mq * 32, &dmd))) return rc;
+    if ((rc = tb_scratch(ctx, 2, m1 * sizeof(tb_keypoint), &dk1))) return rc;
+    if ((rc = tb_scratch(ctx, 3, mq * sizeof(tb_keypoint), &dk2))) return rc;
+    if ((rc = tb_scratch(ctx, 4, start.size() * 4, &dst))) return rc;
+    if ((rc = tb_scratch(ctx, 5, items.size() * 4, &dit))) return rc;
+    if ((rc = tb_scratch(ctx, 6, mq * 24, &dbest))) return rc;
+    if ((rc = tb_scratch(ctx, 7, misc, &dmisc))) return rc;
+    char* mb = (char*)dmisc;
+    hipStream_t s = ctx->stream;
+    std::vector<uint8_t> taken(m1, 0);
+    if (taken1) std::copy(taken1, taken1 + n1, taken.begin());
+    if (n1 > 0) {
+        TB_HIP(ctx, hipMemcpyAsync(dd1, d1, (size_t)n1 * 32, hipMemcpyHostToDevice, s));
+        TB_HIP(ctx, hipMemcpyAsync(dk1, k1, (size_t)n1 * sizeof(tb_keypoint), hipMemcpyHostToDevice, s));
+    }
+    TB_HIP(ctx, hipMemcpyAsync(mb + oTaken, taken.data(), m1, hipMemcpyHostToDevice, s));
+    TB_HIP(ctx, hipMemcpyAsync(dmd, mp_desc, mq * 32, hipMemcpyHostToDevice, s));
+    TB_HIP(ctx, hipMemcpyAsync(mb + oMp, mps, mq * sizeof(tb_mappoint), hipMemcpyHostToDevice, s));
+    if (k2) TB_HIP(ctx, hipMemcpyAsync(dk2, k2, mq * sizeof(tb_keypoint), hipMemcpyHostToDevice, s));
+    TB_HIP(ctx, hipMemcpyAsync(mb + oSf, sf, (size_t)nlevels * 4, hipMemcpyHostToDevice, s));
+    TB_HIP(ctx, hipMemsetAsync(mb + oFlag, 0, 16, s));
+    TB_HIP(ctx, hipMemcpyAsync(dst, start.data(), start.size() * 4, hipMemcpyHostToDevice, s));
+    TB_HIP(ctx, hipMemcpyAsync(dit, items.data(), items.size() * 4, hipMemcpyHostToDevice, s));
+    TB_HIP(ctx, hipStreamSynchronize(s)); /* the host vectors above go out of use */
+    rc = tbk_projection_search(ctx, map_overload, Tcw1, cam1, (const tb_keypoint*)dk2, (const tb_mappoint*)(mb + oMp),
+                               (const uint8_t*)dmd, nq, (const float*)(mb + oSf), nlevels, sf[0], nratio, (const tb_keypoint*)dk1,
+                               (const uint8_t*)dd1, (const uint8_t*)(mb + oTaken), (const int32_t*)dst, (const int32_t*)dit, widthInv,
+                               heightInv, mb + oQ, (int32_t*)dbest, (int*)(mb + oFlag));
+    if (rc) return rc;
+    H.best.resize(mq * 6);
+    TB_HIP(ctx, hipMemcpyAsync(H.best.data(), dbest, mq * 24, hipMemcpyDeviceToHost, s));
+    TB_HIP(ctx, hipMemcpyAsync(&H.bad_octave, mb + oFlag, sizeof(int), hipMemcpyDeviceToHost, s));
+    TB_HIP(ctx, hipStreamSynchronize(s));
+    return TB_OK;
+}
+}  // namespace
+
+int tb_search_by_projection(tb_ctx* ctx, const float Tcw1[16], const tb_camera* cam1, int img1_width, int img1_height,
+                            const tb_keypoint* k1, const uint8_t* d1, const uint8_t* taken1, int n1, const tb_keypoint* k2,
+                            const tb_mappoint* mp2, const uint8_t* mp2_desc, int n2, const float* scale_factors, int nlevels,
+                            float nratio, int th_high, int histo_len, int check_orientation, tb_match* out, int cap, int* count) {
+    if (!ctx || !count || !Tcw1 || !cam1 || n1 < 0 || n2 < 0 || histo_len < 1 || nlevels < 1 || !scale_factors || img1_width < 1 ||
+        img1_height < 1)
+        return TB_EINVAL;
+    *count = 0;
+    if (n2 == 0) return TB_OK;
+    if ((n1 && (!k1 || !d1)) || !k2 || !mp2 || !mp2_desc) return TB_EINVAL;
+    ProjHost H;
+    int rc = projection_run(ctx, 0, Tcw1, cam1, img1_width, img1_height, k1, d1, taken1, n1, k2, mp2, mp2_desc, n2, scale_factors,
+                            nlevels, nratio, H);
+    if (rc) return rc;
+    if (H.bad_octave) return tb_fail(ctx, TB_EINVAL, "searchByProjection: a key octave is outside the %d scale factors", nlevels);
+    /* acceptance + rotation histogram, matcher.cpp:483-530 (bookkeeping over <= n2 survivors) */
+    std::vector<tb_match> matches;
+    std::vector<std::vector<int>> rotHist((size_t)histo_len);
+    const float factor = 1.0f / (float)histo_len;
+    for (int i2 = 0; i2 < n2; i2++) {
+        const int bestDist = H.best[6 * (size_t)i2], bestIdx1 = H.best[6 * (size_t)i2 + 2];
+        if (H.best[6 * (size_t)i2 + 5] == 0 || bestIdx1 < 0) continue;
+        if (bestDist <= th_high) {
+            tb_match m = {bestIdx1, i2, -1, (float)bestDist};
+            matches.push_back(m);
+            if (check_orientation) {
+                float rot = k2[i2].angle - k1[bestIdx1].angle;
+                if (rot < 0.0) rot += 360.0f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == histo_len) bin = 0;
+                if (bin < 0 || bin >= histo_len) return tb_fail(ctx, TB_EUNSUPPORTED, "rotation bin %d outside histogram (reference asserts)", bin);
+                rotHist[bin].push_back((int)matches.size() - 1);
+            }
+        }
+    }
+    std::vector<tb_match> good;
+    if (check_orientation) {
+        std::vector<int> sizes((size_t)histo_len);
+        for (int i = 0; i < histo_len; i++) sizes[i] = (int)rotHist[i].size();
+        int ind[3] = {-1, -1, -1};
+        tb_three_maxima(sizes.data(), histo_len, &ind[0], &ind[1], &ind[2]);
+        for (int i = 0; i < histo_len; i++)
+            if (i == ind[0] || i == ind[1] || i == ind[2])
+                for (int item : rotHist[i]) good.push_back(matches[item]);
+    } else {
+        good.swap(matches);
+    }
+    *count = (int)good.size();
+    if ((int)good.size() > cap) return tb_fail(ctx, TB_ECAPACITY, "matches: %d, capacity %d", (int)good.size(), cap);
+    if (out) std::copy(good.begin(), good.end(), out);
+    return TB_OK;
+}
+
+int tb_search_by_projection_map(tb_ctx* ctx, const float Tcw1[16], const tb_camera* cam1, int img1_width, int img1_height,
+                                const tb_keypoint* k1, const uint8_t* d1, const uint8_t* taken1, int n1, const tb_mappoint* mps,
+                                const uint8_t* mp_desc, int nmp, const float* scale_factors, int nlevels, float nratio, float radio,
+                                int th_high, tb_match* out, int cap, int* count) {
+    if (!ctx || !count || !Tcw1 || !cam1 || n1 < 0 || nmp < 0 || nlevels < 1 || !scale_factors || img1_width < 1 || img1_height < 1)
+        return TB_EINVAL;
+    *count = 0;
+    if (nmp == 0) return TB_OK;
+    if ((n1 && (!k1 || !d1)) || !mps || !mp_desc) return TB_EINVAL;
+    ProjHost H;
+    int rc = projection_run(ctx, 1, Tcw1, cam1, img1_width, img1_height, k1, d1, taken1, n1, nullptr, mps, mp_desc, nmp,
+                            scale_factors, nlevels, nratio, H);
+    if (rc) return rc;
+    std::vector<tb_match> matches;
+    for (int im = 0; im < nmp; im++) { /* ratio test, matcher.cpp:606-613 */
+        const int32_t* b = &H.best[6 * (size_t)im];
+        if (b[5] == 0 || b[2] < 0) continue;
+        if (b[0] <= th_high) {
+            if (b[3] == b[4] && (float)b[0] > radio * (float)b[1]) continue;
+            tb_match m = {b[2], im, -1, (float)b[0]};
+            matches.push_back(m);
+        }
+    }
+    *count = (int)matches.size();
+    if ((int)matches.size() > cap) return tb_fail(ctx, TB_ECAPACITY, "matches: %d, capacity %d", (int)matches.size(), cap);
+    if (out) std::copy(matches.begin(), matches.end(), out);
+    return TB_OK;
+}
+
 /* ------------------------------------------------------------------ pose optimisation / local BA */
 int tb_pose_opt_batch_dev(tb_ctx* ctx, int nproblems, const double K[4], const float* Tcw_in, const tb_obs* obs,
                           const int32_t* counts, int obs_pitch, uint8_t* outlier, float* Tcw_out, int32_t* n_inliers,

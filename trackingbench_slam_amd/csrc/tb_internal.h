@@ -140,6 +140,12 @@ int tbk_window_match(tb_ctx* ctx, const tb_keypoint* d_k1, const uint8_t* d_d1, 
                      const uint8_t* d_d2, int n2, const int32_t* d_cellStart, const int32_t* d_cellItems,
                      float widthInv, float heightInv, int min_level, int max_level, float r,
                      int32_t* d_best /* n1 x 4: bestDist, bestDist2, bestIdx, #candidates */);
+/* searchByProjection: project nq map points into F1 and search F1's lookup grid; best[6 nq] */
+int tbk_projection_search(tb_ctx* ctx, int map_overload, const float Tcw[16], const tb_camera* cam, const tb_keypoint* d_k2,
+                          const tb_mappoint* d_mp, const uint8_t* d_mpdesc, int nq, const float* d_sf, int nlevels, float sf0,
+                          float nratio, const tb_keypoint* d_k1, const uint8_t* d_d1, const uint8_t* d_taken1,
+                          const int32_t* d_cellStart, const int32_t* d_cellItems, float widthInv, float heightInv,
+                          void* d_queries, int32_t* d_best, int* d_flag);
 int tbk_pose_batch(tb_ctx* ctx, int nproblems, const double K[4], const float* Tcw_in, const tb_obs* obs,
                    const int32_t* counts, int obs_pitch, uint8_t* outlier, float* Tcw_out, int32_t* n_inliers,
                    double* stats, double* d_err);

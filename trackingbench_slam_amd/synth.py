@@ -184,3 +184,77 @@ def ba_problem(seed, nkf, npt, K, obs_per_pt=5, noise_px=0.5, pose_noise=0.02, p
     pts_init = X + pt_noise * st.uniform(npt * 3, -1, 1).reshape(npt, 3)
     return (poses.astype(np.float32), poses_init.astype(np.float32), X.astype(np.float32),
             pts_init.astype(np.float32), obs)
+
+
+def projection_case(seed, n1=1500, nmp=1200, width=1241, height=376, nlevels=8, scale=0.8, K=(718.856, 718.856, 607.1928, 185.2157),
+                    distortion=None):
+    """Inputs of the projection matchers: a current frame F1 (pose, keys, descriptors, taken
+    flags) and nmp map points with reference-frame keys F2 aligned to them. About 70 % of the map points project
+    into F1 next to one of its keys (descriptor = that key's with a few flipped bits, octave within one level, angle
+    rotated by a common offset), the rest are behind the camera, outside the image, bad, or unmatched.
+    Returns a dict of arrays in the C-ABI layouts (capi.KEYPOINT / MAPPOINT / CAMERA)."""
+    from . import capi
+    st = Stream(0x9207EC7 + int(seed))
+    fx, fy, cx, cy = K
+    cam = np.zeros(1, capi.CAMERA)
+    cam["fx"], cam["fy"], cam["cx"], cam["cy"], cam["width"], cam["height"] = fx, fy, cx, cy, width, height
+    if distortion is not None:
+        cam["has_distortion"] = 1
+        cam["d"][0] = np.asarray(distortion, np.float32)
+    a = 0.03
+    T = np.eye(4)
+    T[:3, :3] = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    T[:3, 3] = [0.3, -0.05, 0.2]
+    T = T.astype(np.float32)
+    sf = np.ones(nlevels, np.float32)
+    for i in range(1, nlevels):
+        sf[i] = sf[i - 1] * np.float32(scale)
+    # F1 keys
+    k1 = np.zeros(n1, capi.KEYPOINT)
+    k1["x"] = st.uniform(n1, 4, width - 4).astype(np.float32)
+    k1["y"] = st.uniform(n1, 4, height - 4).astype(np.float32)
+    k1["octave"] = st.randint(n1, 0, nlevels)
+    k1["angle"] = st.uniform(n1, 0, 360).astype(np.float32)
+    k1["size"] = 31.0
+    d1 = (st.u64(n1 * 4).view(np.uint8)).reshape(n1, 32).copy()
+    taken1 = (st.uniform(n1) < 0.1).astype(np.uint8)
+    # map points: back-project a key of F1 (or a random pixel) at a random depth, world = Twc * Pc
+    R, t = T[:3, :3].astype(np.float64), T[:3, 3].astype(np.float64)
+    src = st.randint(nmp, 0, n1)
+    kind = st.uniform(nmp)                      # < .7 near a key, < .8 random pixel, < .9 behind, else outside
+    depth = st.uniform(nmp, 4.0, 40.0)
+    px = np.where(kind < 0.7, k1["x"][src] + st.uniform(nmp, -2.5, 2.5), st.uniform(nmp, 0, width))
+    py = np.where(kind < 0.7, k1["y"][src] + st.uniform(nmp, -2.5, 2.5), st.uniform(nmp, 0, height))
+    px = np.where(kind >= 0.9, px + 3 * width, px)
+    depth = np.where((kind >= 0.8) & (kind < 0.9), -depth, depth)
+    Pc = np.stack([(px - cx) / fx * depth, (py - cy) / fy * depth, depth], 1)
+    Pw = (Pc - t) @ R                           # R^T (Pc - t)
+    Ow = -R.T @ t
+    mp = np.zeros(nmp, capi.MAPPOINT)
+    mp["pos"] = Pw.astype(np.float32)
+    n = Ow[None, :] - Pw
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    n = -n                                      # IsInFrustum: viewCos = (P - Ow) . normal / dist
+    tilt = st.uniform(nmp * 3, -0.5, 0.5).reshape(nmp, 3) * (st.uniform(nmp) < 0.3)[:, None]
+    n = n + tilt
+    n /= np.linalg.norm(n, axis=1, keepdims=True)
+    mp["normal"] = n.astype(np.float32)
+    dist = np.linalg.norm(Pw - Ow[None, :], axis=1)
+    mp["min_dist"] = (dist * np.where(st.uniform(nmp) < 0.9, 0.6, 1.2)).astype(np.float32)
+    mp["max_dist"] = (dist * np.where(st.uniform(nmp) < 0.9, 1.7, 0.9)).astype(np.float32)
+    mp["bad"] = (st.uniform(nmp) < 0.08).astype(np.int32)
+    flips = st.randint(nmp * 12, 0, 256).reshape(nmp, 12)
+    nflip = st.randint(nmp, 0, 13)
+    mpd = np.where((kind < 0.7)[:, None], d1[src], (st.u64(nmp * 4).view(np.uint8)).reshape(nmp, 32)).copy()
+    for i in range(nmp):
+        for b in flips[i, :nflip[i]]:
+            mpd[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    k2 = np.zeros(nmp, capi.KEYPOINT)
+    k2["x"] = st.uniform(nmp, 0, width).astype(np.float32)
+    k2["y"] = st.uniform(nmp, 0, height).astype(np.float32)
+    k2["octave"] = np.clip(k1["octave"][src] + st.randint(nmp, -1, 2), 0, nlevels - 1)
+    rot = np.where(st.uniform(nmp) < 0.8, 25.0, st.uniform(nmp, 0, 360))
+    k2["angle"] = ((k1["angle"][src] + rot + st.uniform(nmp, -3, 3)) % 360.0).astype(np.float32)
+    k2["size"] = 31.0
+    return dict(Tcw=T, cam=cam, width=width, height=height, k1=k1, d1=d1, taken1=taken1, k2=k2, mp=mp, mp_desc=mpd, sf=sf)
+
