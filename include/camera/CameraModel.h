@@ -1,6 +1,7 @@
 /* Header shim: the slice of TRACKING_BENCH::PinholeCamera the hot path touches (reference
- * include/camera/CameraModel.h:46-89): intrinsics and pinhole projection. Distortion / remap are out of
- * scope (host glue on OpenCV calib3d). */
+ * include/camera/CameraModel.h:12-89): intrinsics, pinhole projection, IsInFrame. Distortion / remap are out
+ * of scope for the shim classes (host glue on OpenCV calib3d); the C ABI's tb_camera
+ * carries the radial-tangential coefficients for callers that have them. */
 #ifndef TRACKING_BENCH_CAMERAMODEL_H
 #define TRACKING_BENCH_CAMERAMODEL_H
 #include "../tb_compat/deps.h"
@@ -20,6 +21,14 @@ namespace TRACKING_BENCH
         virtual Eigen::Vector2f World2Cam(const Eigen::Vector3f& xyz_c) const = 0;
         inline int Width() const {return mnWidth;}
         inline int Height() const {return mnHeight;}
+        // reference CameraModel.h:33-39
+        inline bool IsInFrame(const Eigen::Vector2i& obs, int boundary = 0, float scale = 1) const
+        {
+            if(obs[0] >= boundary && obs[0] < (int)((float)Width()  * scale) - boundary &&
+               obs[1] >= boundary && obs[1] < (int)((float)Height() * scale) - boundary)
+                return true;
+            return false;
+        }
     };
 
     class PinholeCamera:public CameraModel

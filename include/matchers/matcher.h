@@ -1,7 +1,7 @@
 /* Header shim: the hot-path slice of TRACKING_BENCH::Matcher with the reference's signatures
- * (reference include/matchers/matcher.h:18-62,149-150) on the C ABI (tb_search_by_bf,
- * tb_search_by_violence). Projection / BoW / NN(LSH) / optical-flow / direct-alignment matchers are out
- * of scope (SURVEY.md sections 2 and 8f). */
+ * (reference include/matchers/matcher.h:18-80,149-150) on the C ABI (tb_search_by_bf,
+ * tb_search_by_violence, tb_search_by_projection, tb_search_by_projection_map). BoW / NN(LSH) /
+ * optical-flow / direct-alignment matchers are out of scope (SURVEY.md sections 2 and 8f). */
 #ifndef TRACKING_BENCH_MATCHER_H
 #define TRACKING_BENCH_MATCHER_H
 #include <memory>
@@ -11,6 +11,7 @@
 namespace TRACKING_BENCH
 {
     class Frame;
+    class Map;
 
     class Matcher
     {
@@ -48,6 +49,22 @@ namespace TRACKING_BENCH
                 int max_level = 1,
                 float search_r = 10,
                 bool MapPointOnly = false);
+
+        // Projection (reference :64-80)
+        void setProjectionParam(int low, int high, int histo_length, bool check, float ratio)
+        {
+            TH_LOW = low;
+            TH_HIGH = high;
+            HISTO_LENGTH = histo_length;
+            checkOrientation=check;
+            nRatio=ratio;
+        }
+        std::vector<cv::DMatch> searchByProjection(
+                const std::shared_ptr<Frame>& F1,
+                const std::shared_ptr<Frame>& F2);
+        std::vector<cv::DMatch> searchByProjection(
+                const std::shared_ptr<Map>& map,
+                const std::shared_ptr<Frame>& F1, float r);
 
         static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b);
         static void ComputeThreeMaxima(std::vector<int>* histo, const int L, int &ind1, int &ind2, int &ind3);

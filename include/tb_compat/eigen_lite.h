@@ -37,6 +37,7 @@ typedef Matrix<float, 4, 4> Matrix4f;
 typedef Matrix<float, 3, 3> Matrix3f;
 typedef Matrix<float, 3, 1> Vector3f;
 typedef Matrix<float, 2, 1> Vector2f;
+typedef Matrix<int, 2, 1> Vector2i;
 typedef Matrix<double, 3, 1> Vector3d;
 
 }  // namespace Eigen

@@ -22,10 +22,42 @@ namespace TRACKING_BENCH
     {
     public:
         explicit MapPoint(const Eigen::Vector3f& Pos) : mWorldPos(Pos) {}
+        // shim-only constructor: position + descriptor (the reference's takes Map / Frame / Feature handles,
+        // MapPoint.h:22-24; map bookkeeping is out of scope)
+        MapPoint(const Eigen::Vector3f& Pos, cv::Mat des) : mWorldPos(Pos), mDescriptor(std::move(des)) {}
         void SetWorldPos(const Eigen::Vector3f& pos) { mWorldPos = pos; }
         Eigen::Vector3f GetWorldPos() { return mWorldPos; }
+        // what the projection matchers read (reference MapPoint.h:30,37,44-45,55,60-61)
+        Eigen::Vector3f GetNormal() { return mNormalVector; }
+        int Observations() { return nObs; }
+        void SetBadFlag() { mbBad = true; }
+        bool isBad() { return mbBad; }
+        cv::Mat GetDescriptor() { return mDescriptor; }
+        float GetMinDistanceInvariance() { return 1; }      // constants in the reference (MapPoint.cpp:207-217)
+        float GetMaxDistanceInvariance() { return 1000; }
+        // shim-only setters for the state the reference derives in AddObservation / UpdateNormalAndDepth
+        void SetObservations(int n) { nObs = n; }
+        void SetNormal(const Eigen::Vector3f& normal) { mNormalVector = normal; }
     private:
         Eigen::Vector3f mWorldPos;
+        Eigen::Vector3f mNormalVector = Eigen::Vector3f::Zero();
+        cv::Mat mDescriptor;
+        int nObs = 0;
+        bool mbBad = false;
+    };
+
+    // Map: only the container the projection matcher walks (reference Map.h:13-42). The reference keeps the points in
+    // a std::set ordered by pointer value, so its GetAllMapPoints() order -- and with it DMatch::trainIdx -- changes
+    // from run to run; here it is insertion order.
+    class Map
+    {
+    public:
+        void AddMapPoint(const std::shared_ptr<MapPoint>& pMP) { mvpMapPoints.push_back(pMP); }
+        std::vector<std::shared_ptr<MapPoint>> GetAllMapPoints() { return mvpMapPoints; }
+        long unsigned int MapPointsInMap() { return mvpMapPoints.size(); }
+        void clear() { mvpMapPoints.clear(); }
+    private:
+        std::vector<std::shared_ptr<MapPoint>> mvpMapPoints;
     };
 
     class Feature

@@ -1,8 +1,11 @@
 // The reference's test/test_matcher.cpp flow (:17-70) on the header shims, with the reference's own in-tree
 // images instead of the author's EuRoC paths, plus searchByViolence (:70-72, commented out there) and
-// LocalBA::PoseOptimization on synthetic map points (test/test_vo.cpp:305-355 recipe). Instead of imshow it
+// LocalBA::PoseOptimization on synthetic map points (test/test_vo.cpp:305-355 recipe) and both searchByProjection
+// overloads (matcher.cpp:406-617) on map points back-projected from frame 1. Instead of imshow it
 // dumps every result to a binary file that tests/test_gpu_shim.py compares with the CPU oracle.
+#include <cmath>
 #include <cstdio>
+#include <cstring>
 #include <cstdlib>
 #include <fstream>
 #include <iostream>
@@ -15,6 +18,7 @@
 #include "mapping/LocalBA.h"
 #include "matchers/matcher.h"
 #include "types/Frame.h"
+#include "tb_types.h"
 
 using namespace TRACKING_BENCH;
 
@@ -81,6 +85,53 @@ int main(int argc, char** argv)
     std::vector<uint8_t> outl(n);
     for (int i = 0; i < n; i++) outl[i] = frame1_ptr->GetOutlier(i) ? 1 : 0;
 
+    // projection matchers (reference matcher.cpp:406-617): give frame 2's keys map points that project next to
+    // frame-1 keys (back-projected through the optimised pose), mark some frame-1 points as already observed
+    const Eigen::Matrix4f Twc = frame1_ptr->GetPoseInverse();
+    const int n2p = std::min<int>((int)keypoints2.size(), 600), n1all = (int)keypoints1.size();
+    std::vector<tb_mappoint> mp_rec((size_t)n2p);
+    std::vector<uint8_t> mp_desc((size_t)n2p * 32);
+    auto map_ptr = std::make_shared<Map>();
+    for (int i = 0; i < n && i < n1all; i += 5) frame1_ptr->GetMapPoint(i)->SetObservations(1);
+    for (int i2 = 0; i2 < n2p; i2++)
+    {
+        const int j = (i2 * 7) % n1all;
+        const float depth = 5.f + (float)(i2 % 30), x = frame1_ptr->GetKey(j)->kp.pt.x + (float)(i2 % 5) - 2.f, y = frame1_ptr->GetKey(j)->kp.pt.y + (float)(i2 % 3) - 1.f;
+        Eigen::Vector3f Pc; Pc[0] = (x - 607.1928f) / 718.856f * depth; Pc[1] = (y - 185.2157f) / 718.856f * depth; Pc[2] = depth;
+        Eigen::Vector3f Pw;
+        for (int a = 0; a < 3; a++) Pw[a] = Twc(a, 0) * Pc[0] + Twc(a, 1) * Pc[1] + Twc(a, 2) * Pc[2] + Twc(a, 3);
+        cv::Mat des(1, 32, CV_8UC1);
+        std::memcpy(des.ptr(0), descriptors1.ptr(j), 32);
+        des.ptr(0)[i2 % 32] ^= (uint8_t)(i2 & 0x7); // a few flipped bits
+        auto mp = std::make_shared<MapPoint>(Pw, des);
+        Eigen::Vector3f nrm; for (int a = 0; a < 3; a++) nrm[a] = Pw[a] - Twc(a, 3);
+        const float nn = std::sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
+        for (int a = 0; a < 3; a++) nrm[a] /= nn;
+        if (i2 % 4 == 1) nrm[0] = -nrm[0]; // some points face away
+        mp->SetNormal(nrm);
+        if (i2 % 11 == 3) mp->SetBadFlag();
+        if (i2 % 13 != 5) frame2_ptr->AddMapPoint(mp, i2); // some keys keep no map point
+        map_ptr->AddMapPoint(mp);
+        std::memset(&mp_rec[i2], 0, sizeof(tb_mappoint));
+        for (int a = 0; a < 3; a++) { mp_rec[i2].pos[a] = Pw[a]; mp_rec[i2].normal[a] = nrm[a]; }
+        mp_rec[i2].min_dist = mp->GetMinDistanceInvariance(); mp_rec[i2].max_dist = mp->GetMaxDistanceInvariance();
+        mp_rec[i2].bad = mp->isBad() ? 1 : 0;
+        std::memcpy(mp_desc.data() + (size_t)i2 * 32, des.ptr(0), 32);
+    }
+    matcher_ptr->setProjectionParam(30, 100, 30, true, 8);
+    auto pmatches = matcher_ptr->searchByProjection(frame1_ptr, frame2_ptr);
+    matcher_ptr->setProjectionParam(30, 100, 30, true, 3);
+    auto mmatches = matcher_ptr->searchByProjection(map_ptr, frame1_ptr, 0.8f);
+    std::vector<tb_keypoint> k1now((size_t)n1all);
+    std::vector<uint8_t> taken1((size_t)n1all, 0), nomp2((size_t)n2p, 0);
+    for (int i = 0; i < n1all; i++)
+    {
+        std::memcpy(&k1now[i], &frame1_ptr->GetKey(i)->kp, sizeof(tb_keypoint));
+        auto p = frame1_ptr->GetMapPoint(i);
+        taken1[i] = (p && p->Observations() > 0) ? 1 : 0;
+    }
+    for (int i2 = 0; i2 < n2p; i2++) nomp2[i2] = frame2_ptr->GetMapPoint(i2) ? 0 : 1;
+
     std::ofstream o(argv[4], std::ios::binary);
     put(o, keypoints1.data(), keypoints1.size()); put(o, descriptors1.data, (size_t)descriptors1.rows * 32);
     put(o, keypoints2.data(), keypoints2.size()); put(o, descriptors2.data, (size_t)descriptors2.rows * 32);
@@ -89,7 +140,11 @@ int main(int argc, char** argv)
     put(o, fast_kps.data(), fast_kps.size());
     float Tf[16]; for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) Tf[i * 4 + j] = T(i, j);
     put(o, Tf, 16); put(o, outl.data(), outl.size()); put(o, &inliers, 1);
+    put(o, k1now.data(), k1now.size()); put(o, taken1.data(), taken1.size()); put(o, nomp2.data(), nomp2.size());
+    put(o, mp_rec.data(), mp_rec.size()); put(o, mp_desc.data(), mp_desc.size());
+    put(o, pmatches.data(), pmatches.size()); put(o, mmatches.data(), mmatches.size());
     std::cout << "kps " << keypoints1.size() << "/" << keypoints2.size() << " added " << added.size() << " bf " << matches.size()
-              << " violence " << vmatches.size() << " fast " << fast_kps.size() << " pose inliers " << inliers << std::endl;
+              << " violence " << vmatches.size() << " fast " << fast_kps.size() << " pose inliers " << inliers
+              << " projection " << pmatches.size() << " map projection " << mmatches.size() << std::endl;
     return 0;
 }

@@ -47,9 +47,10 @@ def test_reference_style_driver_on_shims(golden):
         log = subprocess.check_output([EXE, os.path.join(GOLDEN, "kitti00_left_1241x376.pgm"),
                                        os.path.join(GOLDEN, "kitti00_right_1241x376.pgm"), ob, out], timeout=300).decode()
         assert "kps" in log
-        (k1, d1, k2, d2, ka, da, bf, vio, fg, T, outl, ninl) = _read_blocks(
+        (k1, d1, k2, d2, ka, da, bf, vio, fg, T, outl, ninl, k1now, taken1, nomp2, mp, mpd, pm, mm) = _read_blocks(
             out, [capi.KEYPOINT, np.uint8, capi.KEYPOINT, np.uint8, capi.KEYPOINT, np.uint8, capi.MATCH, capi.MATCH,
-                  capi.KEYPOINT, np.float32, np.uint8, np.int32])
+                  capi.KEYPOINT, np.float32, np.uint8, np.int32, capi.KEYPOINT, np.uint8, np.uint8, capi.MAPPOINT, np.uint8,
+                  capi.MATCH, capi.MATCH])
     assert np.array_equal(k1, golden["c5_kps_left"]) and np.array_equal(d1.reshape(-1, 32), golden["c5_desc_left"])
     assert np.array_equal(k2, golden["c5_kps_right"]) and np.array_equal(d2.reshape(-1, 32), golden["c5_desc_right"])
     assert np.array_equal(ka, golden["c5_addpoints_kps_left"]) and np.array_equal(da.reshape(-1, 32), golden["c5_addpoints_desc_left"])
@@ -61,6 +62,16 @@ def test_reference_style_driver_on_shims(golden):
     no, To, oo, _ = oracle.pose_opt(K, np.eye(4, dtype=np.float32), obs2)
     assert int(ninl[0]) == no and np.array_equal(outl, oo)
     assert np.allclose(T.reshape(4, 4), To, rtol=1e-6, atol=1e-6)
+    # projection matchers through the class API == oracle on the same inputs (frame-2 keys without a map point
+    # reach the C ABI as bad records)
+    cam = oracle.camera(718.856, 718.856, 607.1928, 185.2157, 1241, 376)
+    sf = oracle.scale_factors(5, 0.8)[0]
+    mp2 = mp.copy(); mp2["bad"] |= nomp2.astype(np.int32)
+    n2p = len(mp)
+    po = oracle.search_by_projection(T, cam, 1241, 376, k1now, d1.reshape(-1, 32), taken1, k2[:n2p], mp2, mpd.reshape(-1, 32), sf, 8.0)
+    assert len(po) > 50 and np.array_equal(pm, po)
+    mo = oracle.search_by_projection_map(T, cam, 1241, 376, k1now, d1.reshape(-1, 32), taken1, mp, mpd.reshape(-1, 32), sf, 3.0, 0.8)
+    assert len(mo) > 5 and np.array_equal(mm, mo)
 
 
 def test_shim_library_exports_reference_classes():

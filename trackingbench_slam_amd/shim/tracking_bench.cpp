@@ -234,6 +234,85 @@ namespace TRACKING_BENCH
         return out;
     }
 
+    /* the projection matchers (reference matcher.cpp:406-617) on tb_search_by_projection[_map] */
+    static void frame_projection_inputs(const std::shared_ptr<Frame>& F1, float Tcw[16], tb_camera& cam, std::vector<tb_keypoint>& k1,
+                                        std::vector<uint8_t>& d1, std::vector<uint8_t>& taken1)
+    {
+        const Eigen::Matrix4f T = F1->GetPose();
+        for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) Tcw[i * 4 + j] = T(i, j);
+        auto pin = std::dynamic_pointer_cast<PinholeCamera>(F1->GetCameraModel());
+        if (!pin) throw std::invalid_argument("Matcher::searchByProjection: F1 needs a PinholeCamera");
+        std::memset(&cam, 0, sizeof cam);
+        cam.fx = pin->fx(); cam.fy = pin->fy(); cam.cx = pin->cx(); cam.cy = pin->cy();
+        cam.width = pin->Width(); cam.height = pin->Height();
+        frame_keys(F1, k1);
+        frame_desc(F1, d1);
+        taken1.assign(k1.size(), 0);
+        for (size_t i = 0; i < k1.size(); i++)
+        {
+            auto p = F1->GetMapPoint(i);
+            if (p && p->Observations() > 0) taken1[i] = 1;
+        }
+    }
+    static void mappoint_record(const std::shared_ptr<MapPoint>& p, tb_mappoint& r, uint8_t* desc)
+    {
+        std::memset(&r, 0, sizeof r);
+        std::memset(desc, 0, 32);
+        if (!p || p->isBad()) { r.bad = 1; return; }
+        const Eigen::Vector3f X = p->GetWorldPos(), n = p->GetNormal();
+        for (int i = 0; i < 3; i++) { r.pos[i] = X[i]; r.normal[i] = n[i]; }
+        r.min_dist = p->GetMinDistanceInvariance();
+        r.max_dist = p->GetMaxDistanceInvariance();
+        cv::Mat d = p->GetDescriptor();
+        if (d.rows > 0) std::memcpy(desc, d.ptr(0), 32);
+    }
+
+    std::vector<cv::DMatch> Matcher::searchByProjection(const std::shared_ptr<Frame>& F1, const std::shared_ptr<Frame>& F2)
+    {
+        float Tcw[16];
+        tb_camera cam;
+        std::vector<tb_keypoint> k1, k2;
+        std::vector<uint8_t> d1, taken1;
+        frame_projection_inputs(F1, Tcw, cam, k1, d1, taken1);
+        frame_keys(F2, k2);
+        std::vector<tb_mappoint> mp(std::max<size_t>(k2.size(), 1));
+        std::vector<uint8_t> md(std::max<size_t>(k2.size(), 1) * 32);
+        for (size_t i = 0; i < k2.size(); i++) mappoint_record(F2->GetMapPoint(i), mp[i], md.data() + i * 32);
+        const std::vector<float> sf = F1->GetScaleFactors();
+        cv::Mat img1 = F1->GetImage();
+        std::vector<cv::DMatch> out(std::max<size_t>(k2.size(), 1));
+        int n = 0;
+        check(tb_search_by_projection(shim_ctx(), Tcw, &cam, img1.cols, img1.rows, k1.data(), d1.data(), taken1.data(), (int)k1.size(),
+                                      k2.data(), mp.data(), md.data(), (int)k2.size(), sf.data(), (int)sf.size(), nRatio, TH_HIGH,
+                                      HISTO_LENGTH, checkOrientation ? 1 : 0, reinterpret_cast<tb_match*>(out.data()), (int)out.size(), &n),
+              "Matcher::searchByProjection");
+        out.resize(n);
+        return out;
+    }
+
+    std::vector<cv::DMatch> Matcher::searchByProjection(const std::shared_ptr<Map>& map, const std::shared_ptr<Frame>& F1, float radio)
+    {
+        float Tcw[16];
+        tb_camera cam;
+        std::vector<tb_keypoint> k1;
+        std::vector<uint8_t> d1, taken1;
+        frame_projection_inputs(F1, Tcw, cam, k1, d1, taken1);
+        const std::vector<std::shared_ptr<MapPoint>> pts = map->GetAllMapPoints();
+        std::vector<tb_mappoint> mp(std::max<size_t>(pts.size(), 1));
+        std::vector<uint8_t> md(std::max<size_t>(pts.size(), 1) * 32);
+        for (size_t i = 0; i < pts.size(); i++) mappoint_record(pts[i], mp[i], md.data() + i * 32);
+        const std::vector<float> sf = F1->GetScaleFactors();
+        cv::Mat img1 = F1->GetImage();
+        std::vector<cv::DMatch> out(std::max<size_t>(pts.size(), 1));
+        int n = 0;
+        check(tb_search_by_projection_map(shim_ctx(), Tcw, &cam, img1.cols, img1.rows, k1.data(), d1.data(), taken1.data(), (int)k1.size(),
+                                          mp.data(), md.data(), (int)pts.size(), sf.data(), (int)sf.size(), nRatio, radio, TH_HIGH,
+                                          reinterpret_cast<tb_match*>(out.data()), (int)out.size(), &n),
+              "Matcher::searchByProjection(map)");
+        out.resize(n);
+        return out;
+    }
+
     int Matcher::DescriptorDistance(const cv::Mat& a, const cv::Mat& b) { return tb_descriptor_distance(a.ptr(0), b.ptr(0)); }
 
     void Matcher::ComputeThreeMaxima(std::vector<int>* histo, const int L, int& ind1, int& ind2, int& ind3)
