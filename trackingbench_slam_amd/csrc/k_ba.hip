@@ -36,7 +36,8 @@
 struct BaState {
     double lambda, ni, currentChi, chi0, scale_p, rho;
     int iter, qmax, status, need_lin, cur, ok2, done_iters, err;
-    int sing, max_rows, pad1, pad2; /* max_rows: most Hpl rows (6 per free-keyframe edge) any BA_CP-point Schur chunk has;
+    int sing, max_rows, hq_fresh, pad2; /* max_rows: most Hpl rows (6 per free-keyframe edge) any BA_CP-point Schur chunk has;
+                                          hq_fresh: the point pass of this trial already wrote the (inverse, bl) records;
                                           sing: a point block was singular in this trial (solve fails, as in the CPU solver) */
 };
 
@@ -184,7 +185,7 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
     if (tid == 0) {
         st->lambda = 0; st->ni = 2; st->currentChi = 0; st->chi0 = 0; st->scale_p = 0; st->rho = 0;
         st->iter = 0; st->qmax = 0; st->status = (d.iters > 0 && nobs > 0) ? 0 : 1; st->need_lin = 1; st->cur = 0; st->ok2 = 1;
-        st->done_iters = 0; st->err = 0; st->sing = 0;
+        st->done_iters = 0; st->err = 0; st->sing = 0; st->hq_fresh = 0;
     }
     __syncthreads();
     for (int e = tid; e < nobs; e += BA_T) {
@@ -217,10 +218,22 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
     if (tid == 0 && st->err) st->status = 1;
 }
 
+/* (inverse, bl) record of one point for this trial's lambda: the 6 unique entries of (Hll + lambda I)^-1 (ba_inv3's
+ * result is symmetric bit for bit) followed by bl, or zeros for a singular block */
+__device__ __forceinline__ void ba_write_hq(double* q, const double* Hll, const double* bl, double lambda, BaState* st) {
+    double inv[9];
+    const bool ok = ba_inv3(Hll, lambda, inv);
+    if (!ok) st->sing = 1; /* benign race: every writer stores 1 */
+    q[0] = ok ? inv[0] : 0.0; q[1] = ok ? inv[1] : 0.0; q[2] = ok ? inv[2] : 0.0;
+    q[3] = ok ? inv[4] : 0.0; q[4] = ok ? inv[5] : 0.0; q[5] = ok ? inv[8] : 0.0;
+#pragma unroll
+    for (int c = 0; c < 3; c++) q[6 + c] = ok ? bl[c] : 0.0;
+}
+
 /* ---- A: point pass */
 __global__ void __launch_bounds__(BA_T)
 k_ba_points(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw, const int* __restrict__ iw,
-            const BaState* __restrict__ states) {
+            BaState* __restrict__ states) {
     __shared__ double red[4];
     __shared__ double sT[TB_MAX_LEVELS * 7 * 8];
     const int w = blockIdx.y, tid = threadIdx.x;
@@ -283,6 +296,7 @@ k_ba_points(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
         }
         for (int a = 0; a < 6; a++) D[d.oHll + (size_t)p * 6 + a] = Hll[a];
         for (int a = 0; a < 3; a++) D[d.oBl + (size_t)p * 3 + a] = bl[a];
+        if (st.iter > 0) ba_write_hq(D + d.oHq + (size_t)p * 9, Hll, bl, st.lambda, states + w); /* lambda of this trial is final */
         maxd = fmax(fabs(Hll[0]), fmax(fabs(Hll[3]), fabs(Hll[5])));
     }
     const double s = ba_block_sum1(chi, red);
@@ -379,6 +393,7 @@ k_ba_reduce(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, BaSta
         for (int b = 0; b < d.nblkP; b++) { chi += D[d.oPartP + (size_t)b * 4]; mL = fmax(mL, D[d.oPartP + (size_t)b * 4 + 1]); }
         st->currentChi = chi;
         if (st->iter == 0) { st->chi0 = chi; st->lambda = 1e-5 * fmax(mH, mL); st->ni = 2; }
+        st->hq_fresh = st->iter > 0 ? 1 : 0; /* the point pass ran with this trial's final lambda */
         st->need_lin = 0;
     }
 }
@@ -390,18 +405,14 @@ __global__ void __launch_bounds__(BA_T)
 k_ba_hinv(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) {
     const int w = blockIdx.y, p = blockIdx.x * BA_T + threadIdx.x;
     const BaState st = states[w];
-    if (st.status || p >= d.npt) return;
+    if (st.status || st.hq_fresh || p >= d.npt) return; /* hq_fresh: k_ba_points wrote the records for this lambda */
     double* D = dw + (size_t)w * d.wstride;
-    double ph[6], inv[9];
+    double ph[6], pb[3];
 #pragma unroll
     for (int i = 0; i < 6; i++) ph[i] = D[d.oHll + (size_t)p * 6 + i];
-    const bool ok = ba_inv3(ph, st.lambda, inv);
-    if (!ok) states[w].sing = 1; /* benign race: every writer stores 1 */
-    double* q = D + d.oHq + (size_t)p * 9;
-    q[0] = ok ? inv[0] : 0.0; q[1] = ok ? inv[1] : 0.0; q[2] = ok ? inv[2] : 0.0;
-    q[3] = ok ? inv[4] : 0.0; q[4] = ok ? inv[5] : 0.0; q[5] = ok ? inv[8] : 0.0;
 #pragma unroll
-    for (int c = 0; c < 3; c++) q[6 + c] = ok ? D[d.oBl + (size_t)p * 3 + c] : 0.0;
+    for (int i = 0; i < 3; i++) pb[i] = D[d.oBl + (size_t)p * 3 + i];
+    ba_write_hq(D + d.oHq + (size_t)p * 9, ph, pb, st.lambda, states + w);
 }
 
 /* broadcast of one lane's double through the scalar unit (lane index wave-uniform) */
@@ -814,6 +825,7 @@ __global__ void k_ba_decide(BaDims d, const double* __restrict__ dw, BaState* __
     st->qmax++;
     st->rho = rho;
     st->sing = 0;
+    st->hq_fresh = 0;
     if (!(rho < 0 && st->qmax < 10)) { /* this LM iteration is over */
         st->done_iters++;
         const bool terminate = (st->qmax == 10 || rho == 0);
@@ -918,12 +930,14 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
     hipLaunchKernelGGL(k_ba_setup, dim3(nkf + 2, W), dim3(BA_T), 0, s, d, d_poses, d_pts, d_obs, d_counts, dw, iw, states);
     tb_prof_end(ctx);
     TB_HIP(ctx, hipGetLastError());
+    /* one still-running counter per round (zeroed once): no memset node between the rounds */
+    const int ring = 1000;
+    TB_HIP(ctx, hipMemsetAsync(running, 0, ring * sizeof(int), s));
     int host_running = 1, rounds = 0;
-    const int max_rounds = iters * 10 + 1;
+    const int max_rounds = std::min(iters * 10 + 1, 1000); /* ring size below */
     int batch = iters + 1;
     while (host_running > 0 && rounds < max_rounds) {
         for (int r = 0; r < batch && rounds < max_rounds; r++, rounds++) {
-            TB_HIP(ctx, hipMemsetAsync(running, 0, sizeof(int), s));
             tb_prof_begin(ctx, "k_ba_points");
             hipLaunchKernelGGL(k_ba_points, dim3(d.nblkP, W), dim3(BA_T), 0, s, d, d_obs, dw, iw, states);
             tb_prof_end(ctx);
@@ -955,12 +969,12 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
             hipLaunchKernelGGL(k_ba_update, dim3(d.nblkP, W), dim3(BA_T), 0, s, d, d_obs, dw, iw, states);
             tb_prof_end(ctx);
             tb_prof_begin(ctx, "k_ba_decide");
-            hipLaunchKernelGGL(k_ba_decide, dim3((W + 63) / 64), dim3(64), 0, s, d, dw, states, running);
+            hipLaunchKernelGGL(k_ba_decide, dim3((W + 63) / 64), dim3(64), 0, s, d, dw, states, running + rounds % ring);
             tb_prof_end(ctx);
             TB_HIP(ctx, hipGetLastError());
         }
         /* windows still running after the expected number of trials (rejected steps): one sync, then continue */
-        TB_HIP(ctx, hipMemcpyAsync(&host_running, running, sizeof(int), hipMemcpyDeviceToHost, s));
+        TB_HIP(ctx, hipMemcpyAsync(&host_running, running + (rounds - 1) % ring, sizeof(int), hipMemcpyDeviceToHost, s));
         TB_HIP(ctx, hipStreamSynchronize(s));
         batch = 4;
     }
