@@ -28,6 +28,7 @@
 #include "tb_se3.h"
 
 #define BA_T 256
+#define BA_SI 4               /* consecutive edges per thread in k_ba_setup's scans */
 #define BA_CP 4               /* points per Schur chunk (one wavefront each) */
 #define BA_LD (BA_CP * 3 + 1) /* LDS row stride (doubles) of the densified tiles */
 #define BA_KFCH 1024          /* edges per keyframe-pass chunk */
@@ -48,7 +49,7 @@ struct BaDims {
     /* per-window offsets, in doubles, into the double workspace */
     unsigned long long wstride, oT, oP, oErr, oWgt, oHpl, oHll, oBl, oHq, oHpp, oBp, oXp, oPartKF, oPartP, oPartS;
     /* per-window offsets, in ints, into the int workspace */
-    unsigned long long istride, oPtStart, oPtFree, oKfStart, oKfEdges, oScan, oFreeKP;
+    unsigned long long istride, oPtStart, oPtFree, oKfStart, oKfEdges, oFreeKP;
 };
 
 typedef double ba_d4 __attribute__((ext_vector_type(4)));
@@ -110,7 +111,8 @@ __device__ __forceinline__ double ba_block_max1(double v, double* red) {
  * block nkf + 1 numbers the free-keyframe edges compactly (Hpl rows, key list, ptFree). */
 __global__ void __launch_bounds__(BA_T)
 k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ pts, const tb_ba_obs* __restrict__ obsAll,
-           const int32_t* __restrict__ obsCounts, double* __restrict__ dw, int* __restrict__ iw, BaState* __restrict__ states) {
+           const int32_t* __restrict__ obsCounts, double* __restrict__ dw, int* __restrict__ iw, BaState* __restrict__ states,
+           int* __restrict__ errflag) {
     __shared__ int tmp[8];
     __shared__ int sflags[BA_T];
     __shared__ int srun;
@@ -120,6 +122,28 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
     double* D = dw + (size_t)w * d.wstride;
     int* I = iw + (size_t)w * d.istride;
     BaState* st = states + w;
+    {   /* input check, a slice of the edges per block (errflag[w] was zeroed before the launch; k_ba_points turns it
+         * into the window's status): indices in range, grouped by ascending point, and a point observed at most once
+         * per keyframe (the Schur tiles hold one Hpl block per (keyframe, point); within a sorted run the first
+         * repeat lies at most nkf edges after its earlier occurrence). The look-back loads are issued eight at a time
+         * without looking at them in between -- a compare-and-continue loop is one memory latency per step. */
+        const int nb = gridDim.x, per = (nobs + nb - 1) / nb;
+        bool bad = false;
+        for (int e = k * per + tid; e < min((k + 1) * per, nobs); e += BA_T) {
+            const tb_ba_obs o = obs[e];
+            if (o.kf < 0 || o.kf >= d.nkf || o.pt < 0 || o.pt >= d.npt || (e > 0 && o.pt < obs[e - 1].pt)) bad = true;
+            for (int b0 = 1; b0 <= d.nkf && b0 <= e; b0 += 8) {
+                int pk[8], pp[8];
+#pragma unroll
+                for (int i = 0; i < 8; i++) { const int ee = max(e - b0 - i, 0); pk[i] = obs[ee].kf; pp[i] = obs[ee].pt; }
+#pragma unroll
+                for (int i = 0; i < 8; i++)
+                    if (b0 + i <= d.nkf && b0 + i <= e && pp[i] == o.pt && pk[i] == o.kf) bad = true;
+                if (pp[7] != o.pt) break; /* left the point's run */
+            }
+        }
+        if (bad) errflag[w] = 1; /* benign race: every writer stores 1 */
+    }
     if (k < d.nkf) {
         int below = 0;
         for (int e = tid; e < nobs; e += BA_T) below += (obs[e].kf >= 0 && obs[e].kf < k) ? 1 : 0;
@@ -129,13 +153,18 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
         __syncthreads();
         const int base = tmp[0] + tmp[1] + tmp[2] + tmp[3];
         __syncthreads();
-        for (int e0 = 0; e0 < nobs; e0 += BA_T) {
-            const int e = e0 + tid;
-            const int f = (e < nobs && obs[e].kf == k) ? 1 : 0;
-            sflags[tid] = f;
+        for (int e0 = 0; e0 < nobs; e0 += BA_T * BA_SI) { /* BA_SI consecutive edges per thread, one block scan per slab */
+            const int eb = e0 + tid * BA_SI;
+            int f[BA_SI], cnt = 0;
+#pragma unroll
+            for (int i = 0; i < BA_SI; i++) { f[i] = (eb + i < nobs && obs[eb + i].kf == k) ? 1 : 0; cnt += f[i]; }
+            sflags[tid] = cnt;
             __syncthreads();
             const int total = tb_block_excl_scan(sflags, BA_T, tmp);
-            if (f) I[d.oKfEdges + base + srun + sflags[tid]] = e;
+            int pos = base + srun + sflags[tid];
+#pragma unroll
+            for (int i = 0; i < BA_SI; i++)
+                if (f[i]) I[d.oKfEdges + pos++] = eb + i;
             __syncthreads();
             if (tid == 0) srun += total;
             __syncthreads();
@@ -152,26 +181,29 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
          * freeKP[ce] = pt << 6 | free keyframe index; ptFree[p] = first compact edge of point p */
         if (tid == 0) srun = 0;
         __syncthreads();
-        for (int e0 = 0; e0 < nobs; e0 += BA_T) {
-            const int e = e0 + tid;
-            const int kf = (e < nobs) ? obs[e].kf : -1;
-            const int f = (kf >= d.nfixed) ? 1 : 0;
-            sflags[tid] = f;
+        for (int e0 = 0; e0 < nobs; e0 += BA_T * BA_SI) {
+            const int eb = e0 + tid * BA_SI;
+            int kf[BA_SI], cnt = 0;
+#pragma unroll
+            for (int i = 0; i < BA_SI; i++) { kf[i] = (eb + i < nobs) ? obs[eb + i].kf : -1; cnt += (kf[i] >= d.nfixed) ? 1 : 0; }
+            sflags[tid] = cnt;
             __syncthreads();
             const int total = tb_block_excl_scan(sflags, BA_T, tmp);
-            const int ce = srun + sflags[tid];
-            if (e < nobs) I[d.oScan + e] = ce;
-            if (f) I[d.oFreeKP + ce] = (int)(((unsigned)obs[e].pt << 6) | ((unsigned)(kf - d.nfixed) & 63u));
+            int ce = srun + sflags[tid];
+#pragma unroll
+            for (int i = 0; i < BA_SI; i++) {
+                if (eb + i < nobs) { /* points whose first edge is this one (observations are grouped by ascending point) */
+                    const int prev = (eb + i > 0) ? obs[eb + i - 1].pt : -1, cur = obs[eb + i].pt;
+                    for (int p = max(prev + 1, 0); p <= min(cur, d.npt); p++) I[d.oPtFree + p] = ce;
+                }
+                if (kf[i] >= d.nfixed) { I[d.oFreeKP + ce] = (int)(((unsigned)obs[eb + i].pt << 6) | ((unsigned)(kf[i] - d.nfixed) & 63u)); ce++; }
+            }
             __syncthreads();
             if (tid == 0) srun += total;
             __syncthreads();
         }
         const int nfreeE = srun;
-        for (int p = tid; p <= d.npt; p += BA_T) {
-            int lo = 0, hi = nobs;
-            while (lo < hi) { const int mid = (lo + hi) >> 1; if (obs[mid].pt < p) lo = mid + 1; else hi = mid; }
-            I[d.oPtFree + p] = (lo < nobs) ? I[d.oScan + lo] : nfreeE;
-        }
+        for (int p = max((nobs > 0 ? obs[nobs - 1].pt : -1) + 1, 0) + tid; p <= d.npt; p += BA_T) I[d.oPtFree + p] = nfreeE;
         __syncthreads();
         int mr = 0; /* most edge rows in a Schur chunk: picks how many the kernel keeps in registers per lane */
         for (int c = tid; c < d.nChunks; c += BA_T)
@@ -188,19 +220,11 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
         st->done_iters = 0; st->err = 0; st->sing = 0; st->hq_fresh = 0;
     }
     __syncthreads();
-    for (int e = tid; e < nobs; e += BA_T) {
-        const tb_ba_obs o = obs[e];
-        if (o.kf < 0 || o.kf >= d.nkf || o.pt < 0 || o.pt >= d.npt || (e > 0 && o.pt < obs[e - 1].pt)) st->err = 1;
-        /* a point is observed at most once per keyframe (the Schur tiles hold one Hpl block per (keyframe, point));
-         * the first repeat within a point's run lies at most nkf edges after its earlier occurrence */
-        for (int b = 1; b <= d.nkf && e - b >= 0 && obs[e - b].pt == o.pt; b++)
-            if (obs[e - b].kf == o.kf) st->err = 1;
+    for (int e = tid; e < nobs; e += BA_T) { /* ptStart[p] = first edge with pt >= p: the points whose first edge is e */
+        const int prev = (e > 0) ? obs[e - 1].pt : -1, cur = obs[e].pt;
+        for (int p = max(prev + 1, 0); p <= min(cur, d.npt); p++) I[d.oPtStart + p] = e;
     }
-    for (int p = tid; p <= d.npt; p += BA_T) { /* first edge with pt >= p */
-        int lo = 0, hi = nobs;
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (obs[mid].pt < p) lo = mid + 1; else hi = mid; }
-        I[d.oPtStart + p] = lo;
-    }
+    for (int p = max((nobs > 0 ? obs[nobs - 1].pt : -1) + 1, 0) + tid; p <= d.npt; p += BA_T) I[d.oPtStart + p] = nobs;
     for (int kk = tid; kk < d.nkf; kk += BA_T) {
         const float* T = poses + ((size_t)w * d.nkf + kk) * 16;
         double R[9], t[3];
@@ -214,8 +238,6 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
         D[d.oP + i] = v;
         D[d.oP + (size_t)d.npt * 3 + i] = v;
     }
-    __syncthreads();
-    if (tid == 0 && st->err) st->status = 1;
 }
 
 /* (inverse, bl) record of one point for this trial's lambda: the 6 unique entries of (Hll + lambda I)^-1 (ba_inv3's
@@ -233,10 +255,14 @@ __device__ __forceinline__ void ba_write_hq(double* q, const double* Hll, const 
 /* ---- A: point pass */
 __global__ void __launch_bounds__(BA_T)
 k_ba_points(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw, const int* __restrict__ iw,
-            BaState* __restrict__ states) {
+            BaState* __restrict__ states, const int* __restrict__ errflag) {
     __shared__ double red[4];
     __shared__ double sT[TB_MAX_LEVELS * 7 * 8];
     const int w = blockIdx.y, tid = threadIdx.x;
+    if (errflag[w]) { /* k_ba_setup rejected the window's observations: nothing may index with them */
+        if (blockIdx.x == 0 && tid == 0) { states[w].status = 1; states[w].err = 1; }
+        return;
+    }
     const BaState st = states[w];
     if (st.status || !st.need_lin) return;
     const tb_ba_obs* obs = obsAll + (size_t)w * d.obs_pitch;
@@ -895,7 +921,6 @@ static void ba_dims(BaDims& d, int W, const double K[4], int nkf, int nfixed, in
     d.oPtFree = itake(npt + 1);
     d.oKfStart = itake(nkf + 1);
     d.oKfEdges = itake(obs_pitch);
-    d.oScan = itake(obs_pitch + 1);
     d.oFreeKP = itake(obs_pitch);
     d.istride = io;
 }
@@ -904,7 +929,7 @@ size_t tbk_local_ba_work_bytes(int W, int nkf, int nfixed, int npt, int obs_pitc
     BaDims d;
     const double K[4] = {1, 1, 0, 0};
     ba_dims(d, W, K, nkf, nfixed, npt, obs_pitch, 1);
-    return (size_t)W * (d.wstride * sizeof(double) + d.istride * sizeof(int) + sizeof(BaState)) + 4096;
+    return (size_t)W * (d.wstride * sizeof(double) + d.istride * sizeof(int) + sizeof(BaState) + sizeof(int)) + 4096;
 }
 
 int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixed, float* d_poses, int npt, float* d_pts,
@@ -926,20 +951,22 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
     int* running = (int*)((char*)states + (size_t)W * sizeof(BaState));
     hipStream_t s = ctx->stream;
     const size_t lds = std::max<size_t>(4 * (size_t)BA_WAVE_LDS, 64 * 64) * sizeof(double);
+    /* behind the states: one still-running counter per round (no memset node between the rounds), then one
+     * rejected-input flag per window; zeroed together before the setup kernel */
+    const int ring = 1000;
+    int* errflag = running + ring;
+    TB_HIP(ctx, hipMemsetAsync(running, 0, (size_t)(ring + W) * sizeof(int), s));
     tb_prof_begin(ctx, "k_ba_setup");
-    hipLaunchKernelGGL(k_ba_setup, dim3(nkf + 2, W), dim3(BA_T), 0, s, d, d_poses, d_pts, d_obs, d_counts, dw, iw, states);
+    hipLaunchKernelGGL(k_ba_setup, dim3(nkf + 2, W), dim3(BA_T), 0, s, d, d_poses, d_pts, d_obs, d_counts, dw, iw, states, errflag);
     tb_prof_end(ctx);
     TB_HIP(ctx, hipGetLastError());
-    /* one still-running counter per round (zeroed once): no memset node between the rounds */
-    const int ring = 1000;
-    TB_HIP(ctx, hipMemsetAsync(running, 0, ring * sizeof(int), s));
     int host_running = 1, rounds = 0;
     const int max_rounds = std::min(iters * 10 + 1, 1000); /* ring size below */
     int batch = iters + 1;
     while (host_running > 0 && rounds < max_rounds) {
         for (int r = 0; r < batch && rounds < max_rounds; r++, rounds++) {
             tb_prof_begin(ctx, "k_ba_points");
-            hipLaunchKernelGGL(k_ba_points, dim3(d.nblkP, W), dim3(BA_T), 0, s, d, d_obs, dw, iw, states);
+            hipLaunchKernelGGL(k_ba_points, dim3(d.nblkP, W), dim3(BA_T), 0, s, d, d_obs, dw, iw, states, errflag);
             tb_prof_end(ctx);
             tb_prof_begin(ctx, "k_ba_kf");
             hipLaunchKernelGGL(k_ba_kf, dim3(std::min(BA_KFBLK, d.kfChunks), d.nfree, W), dim3(BA_T), 0, s, d, d_obs, dw, iw, states);
