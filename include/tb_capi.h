@@ -146,6 +146,28 @@ int tb_search_by_projection_map(tb_ctx* ctx, const float Tcw1[16], const tb_came
                                 const float* scale_factors, int nlevels, float nratio, float radio, int th_high,
                                 tb_match* out, int cap, int* count);
 
+/* SURVEY 8(f) row 3 -- Frame::AssignFeaturesToGrid (Frame.cpp:187-200, PosInGrid :257-265) for a batch of frames, on
+ * the device: frame f has counts[f] keys at keys + f*key_pitch; its 120x36 lookup grid comes back as CSR,
+ * cell_start + f*4321 (cell c = posX*36 + posY, last entry = total) and cell_items + f*key_pitch (key indices, inside a
+ * cell in insertion = index order). img_* = level-0 image size (grid factors, swapped as in Frame.cpp:30-31).
+ * Device pointers, asynchronous on the context's stream. */
+int tb_frame_grid_batch_dev(tb_ctx* ctx, int nframes, const tb_keypoint* keys, const int32_t* counts, int key_pitch,
+                            int img_width, int img_height, int32_t* cell_start, int32_t* cell_items);
+/* Batched, device-resident Matcher::searchByProjection(F1, F2) (matcher.cpp:406-531): pair p reads Tcw1 + 16p, F1's
+ * keys / descriptors / taken flags at stride pitch1 (n1[p] valid) with the lookup grid built by
+ * tb_frame_grid_batch_dev, F2's keys and key-aligned map points / descriptors at stride pitch2 (n2[p] valid); cam1 and
+ * scale_factors are host arrays shared by all pairs. Matches go to out + p*cap in the reference's order, their
+ * number to out_counts[p] (if it exceeds cap the list is truncated, the count is not); flags[p] != 0 reports what the
+ * host form returns as an error (1: a key octave outside the scale factors, 2: a rotation bin outside the histogram,
+ * where the reference asserts). Device pointers, asynchronous, no host synchronisation. histo_len <= 1024. */
+int tb_search_by_projection_batch_dev(tb_ctx* ctx, int npairs, const float* Tcw1, const tb_camera* cam1, int img1_width,
+                                      int img1_height, const tb_keypoint* k1, const uint8_t* d1, const uint8_t* taken1,
+                                      const int32_t* n1, int pitch1, const int32_t* cell_start, const int32_t* cell_items,
+                                      const tb_keypoint* k2, const tb_mappoint* mp2, const uint8_t* mp2_desc,
+                                      const int32_t* n2, int pitch2, const float* scale_factors, int nlevels, float nratio,
+                                      int th_high, int histo_len, int check_orientation, tb_match* out, int cap,
+                                      int32_t* out_counts, int32_t* flags);
+
 /* ---------------------------------------------------------------- pose optimisation / local BA
  * LocalBA::PoseOptimization, LocalBA.cpp:291-490. K = fx,fy,cx,cy. Tcw_in/out: row-major 4x4.
  * outlier: n in/out flags (Frame::GetOutlier/SetOutlier). *n_inliers = nInitialCorrespondences - nBad.

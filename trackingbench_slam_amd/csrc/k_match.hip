@@ -369,3 +369,253 @@ int tbk_projection_search(tb_ctx* ctx, int map_overload, const float Tcw[16], co
     TB_HIP(ctx, hipGetLastError());
     return TB_OK;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * SURVEY 8(f) row 3 -- Frame::AssignFeaturesToGrid (Frame.cpp:187-200, PosInGrid :257-265) on the device, and the
+ * batched, device-resident form of searchByProjection(F1, F2) on top of it (no host round trip: projection,
+ * window search, acceptance, rotation histogram and the ordered match list all stay in HBM).
+ *
+ * k_grid_build: one workgroup per frame. The 120x36 lookup grid as CSR: LDS histogram of the keys' cells, block
+ * scan, scatter, then every cell's (short) item list is put back into key-index order -- the order
+ * std::vector::push_back gives the reference, which decides ties in the matchers. */
+#define GRID_CELLS (120 * 36)
+__global__ void __launch_bounds__(256)
+k_grid_build(const tb_keypoint* __restrict__ keys, const int32_t* __restrict__ counts, int key_pitch, float widthInv,
+             float heightInv, int32_t* __restrict__ cellStart, int32_t* __restrict__ cellItems) {
+    __shared__ int hist[GRID_CELLS];
+    __shared__ int tmp[8];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const tb_keypoint* k = keys + (size_t)f * key_pitch;
+    const int n = min(counts[f], key_pitch);
+    int32_t* start = cellStart + (size_t)f * (GRID_CELLS + 1);
+    int32_t* items = cellItems + (size_t)f * key_pitch;
+    for (int c = tid; c < GRID_CELLS; c += 256) hist[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int posX = (int)roundf(k[i].x * widthInv), posY = (int)roundf(k[i].y * heightInv);
+        if (posX >= 0 && posX < 120 && posY >= 0 && posY < 36) atomicAdd(&hist[posX * 36 + posY], 1);
+    }
+    __syncthreads();
+    const int total = tb_block_excl_scan(hist, GRID_CELLS, tmp);
+    for (int c = tid; c < GRID_CELLS; c += 256) start[c] = hist[c];
+    if (tid == 0) start[GRID_CELLS] = total;
+    __syncthreads();
+    for (int i = tid; i < n; i += 256) {
+        const int posX = (int)roundf(k[i].x * widthInv), posY = (int)roundf(k[i].y * heightInv);
+        if (posX >= 0 && posX < 120 && posY >= 0 && posY < 36) items[atomicAdd(&hist[posX * 36 + posY], 1)] = i;
+    }
+    __syncthreads(); /* hist[c] is now the END of cell c; the global writes below read what this block wrote */
+    __threadfence_block();
+    for (int c = tid; c < GRID_CELLS; c += 256) { /* insertion sort of the cell's items by key index */
+        const int b = start[c], e = hist[c];
+        for (int i = b + 1; i < e; i++) {
+            const int v = items[i];
+            int j = i - 1;
+            while (j >= b && items[j] > v) { items[j + 1] = items[j]; j--; }
+            items[j + 1] = v;
+        }
+    }
+}
+
+struct ProjBatch {
+    const float* Tcw;                /* [npairs][16] */
+    tb_camera cam;
+    const tb_keypoint* k1; const uint8_t* d1; const uint8_t* taken1; const int32_t* n1; int pitch1;
+    const int32_t* cellStart; const int32_t* cellItems;
+    const tb_keypoint* k2; const tb_mappoint* mp2; const uint8_t* mp2d; const int32_t* n2; int pitch2;
+    float sf[TB_MAX_LEVELS * 2]; int nlevels;
+    float nratio, widthInv, heightInv;
+    int th_high, histo_len, check_orientation;
+    int32_t* best;                   /* [npairs][pitch2][6] */
+    tb_match* out; int cap; int32_t* out_counts; int32_t* flags; /* flags[p]: 1 = octave outside the table, 2 = bin outside the histogram */
+};
+
+/* projection + window search of one map point of pair blockIdx.y (k_project_frame + k_window_q fused) */
+__global__ void __launch_bounds__(256)
+k_proj_search_batch(ProjBatch B) {
+    const int p = blockIdx.y, i2 = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n2 = min(B.n2[p], B.pitch2);
+    if (i2 >= n2) return;
+    ProjPose P;
+#pragma unroll
+    for (int i = 0; i < 16; i++) P.T[i] = B.Tcw[(size_t)p * 16 + i];
+    const tb_mappoint mp = B.mp2[(size_t)p * B.pitch2 + i2];
+    int bestDist = 256, bestDist2 = 256, bestIdx = -1, bestLevel = -1, bestLevel2 = -1, ncand = 0;
+    bool search = false;
+    float x = 0, y = 0, r = 0;
+    int minL = 0, maxL = 0;
+    if (!mp.bad) {
+        float Pc[3], uv[2];
+        pj_se3_map(P, mp.pos, Pc);
+        const float invzc = 1.0f / Pc[2];
+        if (!(invzc < 0)) {
+            pj_world2cam(B.cam, Pc, uv);
+            if (pj_in_frame(B.cam, uv)) {
+                const int oct = B.k2[(size_t)p * B.pitch2 + i2].octave;
+                if (oct < 0 || oct >= B.nlevels) B.flags[p] = 1; /* benign race */
+                else { x = uv[0]; y = uv[1]; r = B.nratio * B.sf[oct]; minL = oct - 1; maxL = oct + 1; search = true; }
+            }
+        }
+    }
+    if (search) {
+        const int GRID_ROWS = 36, GRID_COLS = 120;
+        const int nMinCellX = max(0, (int)floorf((x - r) * B.widthInv));
+        const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf((x + r) * B.widthInv));
+        const int nMinCellY = max(0, (int)floorf((y - r) * B.heightInv));
+        const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf((y + r) * B.heightInv));
+        if (nMinCellX < GRID_COLS && nMaxCellX >= 0 && nMinCellY < GRID_ROWS && nMaxCellY >= 0) {
+            const bool bCheckLevels = (minL > 0) || (maxL >= 0);
+            const int32_t* cs = B.cellStart + (size_t)p * (GRID_CELLS + 1);
+            const int32_t* ci = B.cellItems + (size_t)p * B.pitch1;
+            const tb_keypoint* k1 = B.k1 + (size_t)p * B.pitch1;
+            const uint8_t* d1 = B.d1 + (size_t)p * B.pitch1 * 32;
+            const uint8_t* tk = B.taken1 + (size_t)p * B.pitch1;
+            const unsigned long long* a = reinterpret_cast<const unsigned long long*>(B.mp2d) + ((size_t)p * B.pitch2 + i2) * 4;
+            Desc256 da;
+            da.w[0] = a[0]; da.w[1] = a[1]; da.w[2] = a[2]; da.w[3] = a[3];
+            for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+                for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+                    const int c = ix * GRID_ROWS + iy;
+                    for (int s = cs[c]; s < cs[c + 1]; s++) {
+                        const int j = ci[s];
+                        const tb_keypoint kp = k1[j];
+                        if (bCheckLevels) {
+                            if (kp.octave < minL) continue;
+                            if (maxL >= 0 && kp.octave > maxL) continue;
+                        }
+                        if (!(fabsf(kp.x - x) < r && fabsf(kp.y - y) < r)) continue;
+                        ncand++;
+                        if (tk[j]) continue;
+                        const int dist = bf_dist(da, reinterpret_cast<const unsigned long long*>(d1) + (size_t)j * 4);
+                        if (dist < bestDist) {
+                            bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = kp.octave; bestIdx = j;
+                        } else if (dist < bestDist2) {
+                            bestLevel2 = kp.octave; bestDist2 = dist;
+                        }
+                    }
+                }
+        }
+    }
+    int32_t* o = B.best + ((size_t)p * B.pitch2 + i2) * 6;
+    o[0] = bestDist; o[1] = bestDist2; o[2] = bestIdx; o[3] = bestLevel; o[4] = bestLevel2; o[5] = ncand;
+}
+
+/* acceptance, rotation histogram, ComputeThreeMaxima and the ordered match list (matcher.cpp:483-530): one
+ * workgroup per pair. The reference's output order -- kept bins ascending, inside a bin the order of acceptance --
+ * is a stable partition: one ordered compaction pass per kept bin (at most three). */
+__global__ void __launch_bounds__(256)
+k_proj_accept_batch(ProjBatch B) {
+    __shared__ int hist[1024];
+    __shared__ int sflag[256];
+    __shared__ int tmp[8];
+    __shared__ int keep[3];
+    __shared__ int srun;
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int n2 = min(B.n2[p], B.pitch2);
+    const int32_t* best = B.best + (size_t)p * B.pitch2 * 6;
+    const tb_keypoint* k1 = B.k1 + (size_t)p * B.pitch1;
+    const tb_keypoint* k2 = B.k2 + (size_t)p * B.pitch2;
+    tb_match* out = B.out + (size_t)p * B.cap;
+    const float factor = 1.0f / (float)B.histo_len;
+    auto accepted = [&](int i2, int& bin) -> bool {
+        if (i2 >= n2) return false;
+        const int bd = best[6 * (size_t)i2], bi = best[6 * (size_t)i2 + 2];
+        if (best[6 * (size_t)i2 + 5] == 0 || bi < 0 || bd > B.th_high) return false;
+        bin = 0;
+        if (B.check_orientation) {
+            float rot = k2[i2].angle - k1[bi].angle;
+            if (rot < 0.0f) rot += 360.0f;
+            bin = (int)roundf(rot * factor);
+            if (bin == B.histo_len) bin = 0;
+            if (bin < 0 || bin >= B.histo_len) { B.flags[p] = 2; return false; } /* the reference asserts */
+        }
+        return true;
+    };
+    if (tid == 0) { keep[0] = B.check_orientation ? -1 : 0; keep[1] = keep[2] = -1; srun = 0; }
+    for (int b = tid; b < B.histo_len; b += 256) hist[b] = 0;
+    __syncthreads();
+    if (B.check_orientation) {
+        for (int i2 = tid; i2 < n2; i2 += 256) { int bin; if (accepted(i2, bin)) atomicAdd(&hist[bin], 1); }
+        __syncthreads();
+        if (tid == 0) { /* Matcher::ComputeThreeMaxima, matcher.cpp:810-851 */
+            int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+            for (int i = 0; i < B.histo_len; i++) {
+                const int s = hist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = i; }
+                else if (s > max3) { max3 = s; i3 = i; }
+            }
+            if ((float)max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
+            else if ((float)max3 < 0.1f * (float)max1) { i3 = -1; }
+            /* kept bins in ascending order */
+            int a = i1, b = i2, c = i3, t;
+            if (a < 0) a = 1 << 30; if (b < 0) b = 1 << 30; if (c < 0) c = 1 << 30;
+            if (a > b) { t = a; a = b; b = t; } if (b > c) { t = b; b = c; c = t; } if (a > b) { t = a; a = b; b = t; }
+            keep[0] = a < (1 << 30) ? a : -1; keep[1] = b < (1 << 30) ? b : -1; keep[2] = c < (1 << 30) ? c : -1;
+        }
+        __syncthreads();
+    }
+    for (int kb = 0; kb < 3; kb++) {
+        const int want = keep[kb];
+        if (want < 0) continue;
+        for (int e0 = 0; e0 < n2; e0 += 256) {
+            const int i2 = e0 + tid;
+            int bin = 0;
+            const int f = (accepted(i2, bin) && (!B.check_orientation || bin == want)) ? 1 : 0;
+            sflag[tid] = f;
+            __syncthreads();
+            const int total = tb_block_excl_scan(sflag, 256, tmp);
+            const int slot = srun + sflag[tid];
+            if (f && slot < B.cap) {
+                tb_match m;
+                m.queryIdx = best[6 * (size_t)i2 + 2]; m.trainIdx = i2; m.imgIdx = -1; m.distance = (float)best[6 * (size_t)i2];
+                out[slot] = m;
+            }
+            __syncthreads();
+            if (tid == 0) srun += total;
+            __syncthreads();
+        }
+    }
+    if (tid == 0) B.out_counts[p] = srun; /* may exceed cap: the list is truncated, the count is not */
+}
+
+int tbk_grid_build_batch(tb_ctx* ctx, int nframes, const tb_keypoint* d_keys, const int32_t* d_counts, int key_pitch, int img_w,
+                         int img_h, int32_t* d_cellStart, int32_t* d_cellItems) {
+    if (nframes <= 0) return TB_OK;
+    const float heightInv = 120.f / (float)img_w, widthInv = 36.f / (float)img_h; /* swapped in the reference; kept */
+    tb_prof_begin(ctx, "k_grid_build");
+    hipLaunchKernelGGL(k_grid_build, dim3(nframes), dim3(256), 0, ctx->stream, d_keys, d_counts, key_pitch, widthInv, heightInv,
+                       d_cellStart, d_cellItems);
+    tb_prof_end(ctx);
+    TB_HIP(ctx, hipGetLastError());
+    return TB_OK;
+}
+
+int tbk_projection_batch(tb_ctx* ctx, int npairs, const float* d_Tcw, const tb_camera* cam, int img_w, int img_h,
+                         const tb_keypoint* d_k1, const uint8_t* d_d1, const uint8_t* d_taken1, const int32_t* d_n1, int pitch1,
+                         const int32_t* d_cellStart, const int32_t* d_cellItems, const tb_keypoint* d_k2, const tb_mappoint* d_mp2,
+                         const uint8_t* d_mp2d, const int32_t* d_n2, int pitch2, const float* sf, int nlevels, float nratio,
+                         int th_high, int histo_len, int check_orientation, int32_t* d_best, tb_match* d_out, int cap,
+                         int32_t* d_out_counts, int32_t* d_flags) {
+    if (npairs <= 0 || pitch2 <= 0) return TB_OK;
+    ProjBatch B;
+    B.Tcw = d_Tcw; B.cam = *cam;
+    B.k1 = d_k1; B.d1 = d_d1; B.taken1 = d_taken1; B.n1 = d_n1; B.pitch1 = pitch1;
+    B.cellStart = d_cellStart; B.cellItems = d_cellItems;
+    B.k2 = d_k2; B.mp2 = d_mp2; B.mp2d = d_mp2d; B.n2 = d_n2; B.pitch2 = pitch2;
+    for (int i = 0; i < TB_MAX_LEVELS * 2; i++) B.sf[i] = i < nlevels ? sf[i] : 0.f;
+    B.nlevels = nlevels; B.nratio = nratio;
+    B.heightInv = 120.f / (float)img_w; B.widthInv = 36.f / (float)img_h;
+    B.th_high = th_high; B.histo_len = histo_len; B.check_orientation = check_orientation;
+    B.best = d_best; B.out = d_out; B.cap = cap; B.out_counts = d_out_counts; B.flags = d_flags;
+    TB_HIP(ctx, hipMemsetAsync(d_flags, 0, (size_t)npairs * sizeof(int32_t), ctx->stream));
+    tb_prof_begin(ctx, "k_proj_search");
+    hipLaunchKernelGGL(k_proj_search_batch, dim3((pitch2 + 255) / 256, npairs), dim3(256), 0, ctx->stream, B);
+    tb_prof_end(ctx);
+    TB_HIP(ctx, hipGetLastError());
+    tb_prof_begin(ctx, "k_proj_accept");
+    hipLaunchKernelGGL(k_proj_accept_batch, dim3(npairs), dim3(256), 0, ctx->stream, B);
+    tb_prof_end(ctx);
+    TB_HIP(ctx, hipGetLastError());
+    return TB_OK;
+}

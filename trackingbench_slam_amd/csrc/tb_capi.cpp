@@ -1068,6 +1068,34 @@ int tb_search_by_projection_map(tb_ctx* ctx, const float Tcw1[16], const tb_came
     return TB_OK;
 }
 
+/* ---- device-resident lookup grid + batched projection search */
+int tb_frame_grid_batch_dev(tb_ctx* ctx, int nframes, const tb_keypoint* keys, const int32_t* counts, int key_pitch, int img_width,
+                            int img_height, int32_t* cell_start, int32_t* cell_items) {
+    if (!ctx || nframes < 0 || key_pitch < 1 || img_width < 1 || img_height < 1 || (nframes && (!keys || !counts || !cell_start || !cell_items)))
+        return TB_EINVAL;
+    return tbk_grid_build_batch(ctx, nframes, keys, counts, key_pitch, img_width, img_height, cell_start, cell_items);
+}
+
+int tb_search_by_projection_batch_dev(tb_ctx* ctx, int npairs, const float* Tcw1, const tb_camera* cam1, int img1_width,
+                                      int img1_height, const tb_keypoint* k1, const uint8_t* d1, const uint8_t* taken1,
+                                      const int32_t* n1, int pitch1, const int32_t* cell_start, const int32_t* cell_items,
+                                      const tb_keypoint* k2, const tb_mappoint* mp2, const uint8_t* mp2_desc, const int32_t* n2,
+                                      int pitch2, const float* scale_factors, int nlevels, float nratio, int th_high, int histo_len,
+                                      int check_orientation, tb_match* out, int cap, int32_t* out_counts, int32_t* flags) {
+    if (!ctx || npairs < 0 || !cam1 || !scale_factors || nlevels < 1 || nlevels > TB_MAX_LEVELS * 2 || histo_len < 1 || histo_len > 1024 ||
+        pitch1 < 1 || pitch2 < 1 || cap < 0 || img1_width < 1 || img1_height < 1)
+        return TB_EINVAL;
+    if (npairs == 0) return TB_OK;
+    if (!Tcw1 || !k1 || !d1 || !taken1 || !n1 || !cell_start || !cell_items || !k2 || !mp2 || !mp2_desc || !n2 || !out || !out_counts || !flags)
+        return TB_EINVAL;
+    void* dbest;
+    int rc = tb_scratch(ctx, 6, (size_t)npairs * pitch2 * 6 * sizeof(int32_t), &dbest);
+    if (rc) return rc;
+    return tbk_projection_batch(ctx, npairs, Tcw1, cam1, img1_width, img1_height, k1, d1, taken1, n1, pitch1, cell_start, cell_items, k2, mp2,
+                                mp2_desc, n2, pitch2, scale_factors, nlevels, nratio, th_high, histo_len, check_orientation,
+                                (int32_t*)dbest, out, cap, out_counts, flags);
+}
+
 /* ------------------------------------------------------------------ pose optimisation / local BA */
 int tb_pose_opt_batch_dev(tb_ctx* ctx, int nproblems, const double K[4], const float* Tcw_in, const tb_obs* obs,
                           const int32_t* counts, int obs_pitch, uint8_t* outlier, float* Tcw_out, int32_t* n_inliers,

@@ -140,6 +140,15 @@ int tbk_window_match(tb_ctx* ctx, const tb_keypoint* d_k1, const uint8_t* d_d1, 
                      const uint8_t* d_d2, int n2, const int32_t* d_cellStart, const int32_t* d_cellItems,
                      float widthInv, float heightInv, int min_level, int max_level, float r,
                      int32_t* d_best /* n1 x 4: bestDist, bestDist2, bestIdx, #candidates */);
+/* device-resident lookup grids and the batched searchByProjection(F1, F2) on them */
+int tbk_grid_build_batch(tb_ctx* ctx, int nframes, const tb_keypoint* d_keys, const int32_t* d_counts, int key_pitch, int img_w,
+                         int img_h, int32_t* d_cellStart, int32_t* d_cellItems);
+int tbk_projection_batch(tb_ctx* ctx, int npairs, const float* d_Tcw, const tb_camera* cam, int img_w, int img_h,
+                         const tb_keypoint* d_k1, const uint8_t* d_d1, const uint8_t* d_taken1, const int32_t* d_n1, int pitch1,
+                         const int32_t* d_cellStart, const int32_t* d_cellItems, const tb_keypoint* d_k2, const tb_mappoint* d_mp2,
+                         const uint8_t* d_mp2d, const int32_t* d_n2, int pitch2, const float* sf, int nlevels, float nratio,
+                         int th_high, int histo_len, int check_orientation, int32_t* d_best, tb_match* d_out, int cap,
+                         int32_t* d_out_counts, int32_t* d_flags);
 /* searchByProjection: project nq map points into F1 and search F1's lookup grid; best[6 nq] */
 int tbk_projection_search(tb_ctx* ctx, int map_overload, const float Tcw[16], const tb_camera* cam, const tb_keypoint* d_k2,
                           const tb_mappoint* d_mp, const uint8_t* d_mpdesc, int nq, const float* d_sf, int nlevels, float sf0,
