@@ -124,7 +124,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--frames", type=int, default=128, help="stereo frames per GPU per step")
+    ap.add_argument("--frames", type=int, default=512, help="stereo frames per GPU per step")
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--levels", type=int, default=8)
@@ -138,7 +138,7 @@ def main():
     ap.add_argument("--no-ba", action="store_true", help="diagnostic only: drop the local-BA stage")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
-    ap.add_argument("--ba-split", type=int, default=2, help="partitions of the BA windows, one stream + host thread each")
+    ap.add_argument("--ba-split", type=int, default=3, help="partitions of the BA windows, one stream + host thread each")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic stereo pairs tiled over the batch")
     args = ap.parse_args()
 

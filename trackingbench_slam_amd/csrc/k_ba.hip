@@ -47,7 +47,7 @@ struct BaDims {
     int nblkP, kfChunks, G, nChunks;
     double fx, fy, cx, cy;
     /* per-window offsets, in doubles, into the double workspace */
-    unsigned long long wstride, oT, oP, oErr, oWgt, oHpl, oHll, oBl, oHq, oHpp, oBp, oXp, oPartKF, oPartP, oPartS;
+    unsigned long long wstride, oT, oP, oHpl, oHll, oBl, oHq, oHpp, oBp, oXp, oPartKF, oPartP, oPartS;
     /* per-window offsets, in ints, into the int workspace */
     unsigned long long istride, oPtStart, oPtFree, oKfStart, oKfEdges, oFreeKP;
 };
@@ -291,8 +291,6 @@ k_ba_points(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
             const double r1 = (c2 <= delta * delta) ? 1.0 : delta / sqrt(c2);
             const double ww = r1 * wgt;
             chi += ba_huber_rho0(c2, delta);
-            *(ba_d2*)__builtin_assume_aligned(D + d.oErr + 2 * (size_t)e, 16) = (ba_d2){e0, e1};
-            D[d.oWgt + e] = ww;
             po_to_R(Tk, R);
             const double x = pc[0], y = pc[1], z = pc[2];
             const double tm[6] = {d.fx, 0, -x / z * d.fx, 0, d.fy, -y / z * d.fy};
@@ -347,6 +345,7 @@ k_ba_kf(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw,
     const int beg = I[d.oKfStart + kf], end = I[d.oKfStart + kf + 1];
     const PoSE3 Tk = ba_load_se3(D + d.oT + ((size_t)st.cur * d.nkf + kf) * 7);
     const double* P = D + d.oP + (size_t)st.cur * d.npt * 3;
+    const double delta = (double)sqrtf(5.991f);
     /* BA_KFBLK blocks per keyframe walk its chunks; k_ba_reduce sums the occupied chunks in order */
     for (int chunk = blockIdx.x; chunk * BA_KFCH < end - beg; chunk += BA_KFBLK) {
         double acc[27];
@@ -363,12 +362,19 @@ k_ba_kf(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw,
 #pragma unroll
         for (int j = 0; j < BA_KFCH / BA_T; j++) {
             if (ee[j] < 0) continue;
-            const int e = ee[j], p = pp[j];
+            const tb_ba_obs o = obs[ee[j]];
+            const int p = pp[j];
             const double X[3] = {P[3 * p], P[3 * p + 1], P[3 * p + 2]};
             double pc[3], Jp[12];
             po_map(Tk, X, pc);
             ba_jac_pose(pc, d.fx, d.fy, Jp);
-            const double ww = D[d.oWgt + e], e0 = D[d.oErr + 2 * (size_t)e], e1 = D[d.oErr + 2 * (size_t)e + 1];
+            /* error and Huber weight exactly as the point pass computes them (same operands, same operations): cheaper
+             * than a 24-byte-per-edge round trip through HBM */
+            const double e0 = (double)o.u - (pc[0] / pc[2] * d.fx + d.cx);
+            const double e1 = (double)o.v - (pc[1] / pc[2] * d.fy + d.cy);
+            const double wgt = (double)o.inv_sigma2;
+            const double c2 = e0 * (wgt * e0) + e1 * (wgt * e1);
+            const double ww = ((c2 <= delta * delta) ? 1.0 : delta / sqrt(c2)) * wgt;
 #pragma unroll
             for (int a = 0; a < 6; a++) {
                 acc[21 + a] -= ww * (Jp[a] * e0 + Jp[6 + a] * e1);
@@ -902,8 +908,6 @@ static void ba_dims(BaDims& d, int W, const double K[4], int nkf, int nfixed, in
     auto take = [&](unsigned long long n) { unsigned long long r = o; o += (n + 1) & ~1ull; return r; };
     d.oT = take(2ull * nkf * 7);
     d.oP = take(2ull * npt * 3);
-    d.oErr = take(2ull * obs_pitch);
-    d.oWgt = take(obs_pitch);
     d.oHpl = take(18ull * obs_pitch);
     d.oHll = take(6ull * npt);
     d.oBl = take(3ull * npt);

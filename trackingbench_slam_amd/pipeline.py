@@ -21,7 +21,7 @@ KITTI_K = (718.856, 718.856, 607.1928, 185.2157)  # hard-coded in the reference,
 class TrackingPipeline:
     def __init__(self, width=1280, height=720, nlevels=8, scale=0.8, target=2000, init_th=80.0, min_th=30.0,
                  frames=16, bf_ratio=10.0, bf_min_th=30.0, device=0, with_ba=True, ba_kf=10, ba_pts=5000, ba_iters=10,
-                 seed=0, ba_split=2):
+                 seed=0, ba_split=3):
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
         self.F = int(frames)
