@@ -945,6 +945,7 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
         return tb_fail(ctx, TB_EUNSUPPORTED, "local BA: %d free keyframes (this build supports 1..10: one 64x64 Schur tile)", nfree);
     if (nkf > TB_MAX_LEVELS * 8) return tb_fail(ctx, TB_EUNSUPPORTED, "local BA: too many keyframes");
     if (npt > (1 << 25)) return tb_fail(ctx, TB_EUNSUPPORTED, "local BA: more than 2^25 points per window");
+    if (iters > 99) return tb_fail(ctx, TB_EUNSUPPORTED, "local BA: more than 99 LM iterations (one still-running counter per trial, 1000 of them)");
     BaDims d;
     ba_dims(d, W, K, nkf, nfixed, npt, obs_pitch, iters);
     if (tbk_local_ba_work_bytes(W, nkf, nfixed, npt, obs_pitch) > work_bytes) return tb_fail(ctx, TB_ENOMEM, "local BA workspace too small");
