@@ -468,8 +468,9 @@ __device__ __forceinline__ double ba_readlane(double v, int lane) {
  * cross-lane visibility needs no counter wait: a wavefront-scope fence only pins the compiler's ordering (a
  * workgroup-scope one would also drain vmcnt, i.e. the prefetched edge rows, on every phase change). */
 __device__ __forceinline__ void ba_wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
-#define BA_TRASH (2 * 64 * BA_LD + BA_CP * 9)  /* wave-relative offset of a 4-double sink for masked-out row items */
-#define BA_WAVE_LDS (BA_TRASH + 4)           /* doubles per wave */
+/* LDS of one wavefront, in doubles: Y and W tiles [16 R][BA_LD], the chunk's (inverse, bl) records, a 4-double sink */
+#define BA_TRASH_R(R) (2 * 16 * (R) * BA_LD + BA_CP * 9)
+#define BA_WAVE_LDS_R(R) (BA_TRASH_R(R) + 4)
 
 /* one prefetched Schur chunk: M edge rows per lane */
 template <int M>
@@ -484,7 +485,7 @@ struct BaPre {
 
 template <int R> /* R = 16-row tiles of the pose block: compile-time tile set (lower triangle), so the MFMA phase is
                      straight-line code with the accumulators pinned in registers */
-__global__ void __launch_bounds__(BA_T, 2)
+__global__ void __launch_bounds__(BA_T, R <= 3 ? 3 : 2)
 k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw, const int* __restrict__ iw,
            BaState* __restrict__ states) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
@@ -492,9 +493,10 @@ k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ 
     const BaState st = states[w];
     if (st.status) return;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    double* Yl = lds + (size_t)wave * BA_WAVE_LDS; /* [64][BA_LD]: Hpl * (Hll + lambda I)^-1 */
-    double* Wl = Yl + 64 * BA_LD;                  /* [64][BA_LD]: Hpl; row np holds bl */
-    double* Hi = Wl + 64 * BA_LD;                  /* [BA_CP][9] */
+    constexpr int ROWS = 16 * R, BA_TRASH = BA_TRASH_R(R), BA_WAVE_LDS = BA_WAVE_LDS_R(R);
+    double* Yl = lds + (size_t)wave * BA_WAVE_LDS; /* [ROWS][BA_LD]: Hpl * (Hll + lambda I)^-1 */
+    double* Wl = Yl + ROWS * BA_LD;                /* [ROWS][BA_LD]: Hpl */
+    double* Hi = Wl + ROWS * BA_LD;                /* [BA_CP][9] */
     double* D = dw + (size_t)w * d.wstride;
     const int* I = iw + (size_t)w * d.istride;
     ba_d4 acc[BA_MAXT][BA_MAXT];
@@ -502,11 +504,10 @@ k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ 
     for (int r = 0; r < BA_MAXT; r++)
 #pragma unroll
         for (int c = 0; c < BA_MAXT; c++) acc[r][c] = (ba_d4){0, 0, 0, 0};
-    for (int i = lane; i < 128 * BA_LD; i += 64) Yl[i] = 0;
+    for (int i = lane; i < 2 * ROWS * BA_LD; i += 64) Yl[i] = 0;
     ba_wave_lds_fence();
     const int stride = d.G * 4; /* waves per window */
-    constexpr bool TWO = R < 4; /* two register sets in flight; the 10-tile case has room for one */
-    const int pf = TWO ? 2 * stride : stride; /* chunk distance between a set's consecutive fills */
+    int pf = stride; /* chunk distance between a register set's consecutive fills (set by run(): 2 strides with two sets) */
     /* The edge rows (6 x 3 doubles per edge, one row per lane item) and the (inverse, bl) records of a chunk are
      * fetched TWO chunks ahead into one of two register sets: a set's loads are issued back to back right after its
      * previous contents were scattered, nothing looks at them until that set's next scatter, and the other set's
@@ -569,7 +570,7 @@ k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ 
                 if (j < MAXI) {
                     const int off = cpos[j];
                     double* yr = Yl + off;
-                    double* wr = Yl + ((off == BA_TRASH) ? BA_TRASH : off + 64 * BA_LD);
+                    double* wr = Yl + ((off == BA_TRASH) ? BA_TRASH : off + ROWS * BA_LD);
                     wr[0] = X.h0[j]; wr[1] = X.h1[j]; wr[2] = X.h2[j];
                     yr[0] = X.h0[j] * q[u][0] + X.h1[j] * q[u][1] + X.h2[j] * q[u][2];
                     yr[1] = X.h0[j] * q[u][1] + X.h1[j] * q[u][3] + X.h2[j] * q[u][4];
@@ -588,7 +589,7 @@ k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ 
 #pragma unroll
         for (int k = 0; k < BA_CP * 3; k++) {
             const double b = (k / 3 < p1 - p0) ? bl[k] : 0.0;
-            rhs = fma(Yl[lane * BA_LD + k], b, rhs);
+            rhs = fma(Yl[min(lane, ROWS - 1) * BA_LD + k], b, rhs); /* lanes >= ROWS: never read back */
         }
 #pragma unroll
         for (int kk = 0; kk < BA_CP * 3; kk += 4) {
@@ -609,7 +610,7 @@ k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ 
         /* clear what this chunk wrote (positions kept in registers) */
 #pragma unroll
         for (int j = 0; j < MAXI; j++) {
-            const int off = cpos[j], woff = (off == BA_TRASH) ? BA_TRASH : off + 64 * BA_LD;
+            const int off = cpos[j], woff = (off == BA_TRASH) ? BA_TRASH : off + ROWS * BA_LD;
             Yl[woff] = Yl[woff + 1] = Yl[woff + 2] = 0;
             Yl[off] = Yl[off + 1] = Yl[off + 2] = 0;
         }
@@ -617,6 +618,10 @@ k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ 
     };
     auto run = [&](auto mTag) {
         constexpr int M = decltype(mTag)::value;
+        /* two register sets in flight where the budget of three waves per SIMD (168 VGPRs; two waves for the 10-tile
+         * case) has room for them: up to two row items per lane */
+        constexpr bool TWO = R < 4 && M <= 2;
+        pf = TWO ? 2 * stride : stride;
         BaPre<M> A;
         int ch = g * 4 + wave;
         range(A, ch);
@@ -902,7 +907,7 @@ static void ba_dims(BaDims& d, int W, const double K[4], int nkf, int nfixed, in
     d.nblkP = (npt + BA_T - 1) / BA_T;
     d.kfChunks = (obs_pitch + BA_KFCH - 1) / BA_KFCH;
     d.nChunks = (npt + BA_CP - 1) / BA_CP;
-    d.G = std::min(std::max(512 / std::max(W, 1), 1), std::max((d.nChunks + 3) / 4, 1)); /* ~2 resident blocks per CU (register bound) */
+    d.G = std::min(std::max((d.np <= 48 ? 768 : 512) / std::max(W, 1), 1), std::max((d.nChunks + 3) / 4, 1)); /* 3 resident Schur blocks per CU (2 for the 10-tile case) */
     d.fx = K[0]; d.fy = K[1]; d.cx = K[2]; d.cy = K[3];
     unsigned long long o = 0;
     auto take = [&](unsigned long long n) { unsigned long long r = o; o += (n + 1) & ~1ull; return r; };
@@ -955,7 +960,8 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
     BaState* states = (BaState*)((char*)iw + (size_t)W * d.istride * sizeof(int));
     int* running = (int*)((char*)states + (size_t)W * sizeof(BaState));
     hipStream_t s = ctx->stream;
-    const size_t lds = std::max<size_t>(4 * (size_t)BA_WAVE_LDS, 64 * 64) * sizeof(double);
+    const int Rt = (d.np + 15) >> 4;
+    const size_t lds = std::max<size_t>(4 * (size_t)BA_WAVE_LDS_R(Rt), (size_t)16 * Rt * 64) * sizeof(double);
     /* behind the states: one still-running counter per round (no memset node between the rounds), then one
      * rejected-input flag per window; zeroed together before the setup kernel */
     const int ring = 1000;
