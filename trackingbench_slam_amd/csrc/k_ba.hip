@@ -28,7 +28,6 @@
 #include "tb_se3.h"
 
 #define BA_T 256
-#define BA_SI 4               /* consecutive edges per thread in k_ba_setup's scans */
 #define BA_CP 4               /* points per Schur chunk (one wavefront each) */
 #define BA_LD (BA_CP * 3 + 1) /* LDS row stride (doubles) of the densified tiles */
 #define BA_KFCH 1024          /* edges per keyframe-pass chunk */
@@ -104,6 +103,48 @@ __device__ __forceinline__ double ba_block_max1(double v, double* red) {
     return fmax(fmax(red[0], red[1]), fmax(red[2], red[3]));
 }
 
+/* Ordered compaction of the edges [0, n) that satisfy pred, by one 256-thread workgroup without a barrier per slab:
+ * every wavefront owns a contiguous quarter of the range; pass 1 counts (independent loads), one barrier gives each
+ * quarter its base rank, pass 2 ranks with ballots, four independent 64-edge groups per trip. visit(e, rank, hit) is
+ * called for EVERY edge with the number of hits before it. Returns the total number of hits. tmp: >= 8 ints of LDS. */
+template <class Pred, class Pred2, class Visit>
+__device__ __forceinline__ int ba_ordered_rank(int n, int* tmp, Pred pred, Pred2 pred2, int* total2, Visit visit) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = (((n + 3) >> 2) + 63) & ~63, lo = min(wave * q, n), hi = min(lo + q, n);
+    int cnt = 0, cnt2 = 0; /* pred2: a second class counted over the whole range in the same pass (total2) */
+    for (int e0 = lo; e0 < hi; e0 += 256) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int e = e0 + 64 * i + lane;
+            cnt += (e < hi && pred(e)) ? 1 : 0;
+            cnt2 += (e < hi && pred2(e)) ? 1 : 0;
+        }
+    }
+    cnt = tb_wave_sum(cnt);
+    cnt2 = tb_wave_sum(cnt2);
+    if (lane == 0) { tmp[wave] = cnt; tmp[4 + wave] = cnt2; }
+    __syncthreads();
+    int base = 0;
+    for (int v = 0; v < wave; v++) base += tmp[v];
+    const int total = tmp[0] + tmp[1] + tmp[2] + tmp[3];
+    *total2 = tmp[4] + tmp[5] + tmp[6] + tmp[7];
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int e0 = lo; e0 < hi; e0 += 256) {
+        bool f[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) { const int e = e0 + 64 * i + lane; f[i] = e < hi && pred(e); }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int e = e0 + 64 * i + lane;
+            const unsigned long long m = __ballot(f[i]);
+            if (e < hi) visit(e, base + __popcll(m & lt), f[i]);
+            base += __popcll(m);
+        }
+    }
+    __syncthreads(); /* tmp may be reused */
+    return total;
+}
+
 /* ---- setup: CSR by point (observations must be grouped by ascending point index) and by keyframe.
  * grid (nkf + 2, W): block k < nkf lists keyframe k's edges in ascending edge order (its base offset is
  * the count of edges with a smaller keyframe index, recounted per block so blocks stay independent);
@@ -114,8 +155,6 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
            const int32_t* __restrict__ obsCounts, double* __restrict__ dw, int* __restrict__ iw, BaState* __restrict__ states,
            int* __restrict__ errflag) {
     __shared__ int tmp[8];
-    __shared__ int sflags[BA_T];
-    __shared__ int srun;
     const int w = blockIdx.y, k = blockIdx.x, tid = threadIdx.x;
     const tb_ba_obs* obs = obsAll + (size_t)w * d.obs_pitch;
     const int nobs = min(obsCounts[w], d.obs_pitch);
@@ -145,33 +184,14 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
         if (bad) errflag[w] = 1; /* benign race: every writer stores 1 */
     }
     if (k < d.nkf) {
-        int below = 0;
-        for (int e = tid; e < nobs; e += BA_T) below += (obs[e].kf >= 0 && obs[e].kf < k) ? 1 : 0;
-        below = tb_wave_sum(below);
-        if ((tid & 63) == 0) tmp[tid >> 6] = below;
-        if (tid == 0) srun = 0;
-        __syncthreads();
-        const int base = tmp[0] + tmp[1] + tmp[2] + tmp[3];
-        __syncthreads();
-        for (int e0 = 0; e0 < nobs; e0 += BA_T * BA_SI) { /* BA_SI consecutive edges per thread, one block scan per slab */
-            const int eb = e0 + tid * BA_SI;
-            int f[BA_SI], cnt = 0;
-#pragma unroll
-            for (int i = 0; i < BA_SI; i++) { f[i] = (eb + i < nobs && obs[eb + i].kf == k) ? 1 : 0; cnt += f[i]; }
-            sflags[tid] = cnt;
-            __syncthreads();
-            const int total = tb_block_excl_scan(sflags, BA_T, tmp);
-            int pos = base + srun + sflags[tid];
-#pragma unroll
-            for (int i = 0; i < BA_SI; i++)
-                if (f[i]) I[d.oKfEdges + pos++] = eb + i;
-            __syncthreads();
-            if (tid == 0) srun += total;
-            __syncthreads();
-        }
+        /* keyframe k's edges in ascending edge order, placed behind the edges of the keyframes before it */
+        int base = 0;
+        const int mine = ba_ordered_rank(nobs, tmp, [&](int e) { return obs[e].kf == k; },
+                                         [&](int e) { const int kf = obs[e].kf; return kf >= 0 && kf < k; }, &base,
+                                         [&](int e, int rank, bool hit) { if (hit) I[d.oKfEdges + base + rank] = e; });
         if (tid == 0) {
             I[d.oKfStart + k] = base;
-            if (k == d.nkf - 1) I[d.oKfStart + d.nkf] = base + srun;
+            if (k == d.nkf - 1) I[d.oKfStart + d.nkf] = base + mine;
         }
         return;
     }
@@ -179,30 +199,14 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
         /* compact numbering of the free-keyframe edges (the only ones with an Hpl block): ce = rank among the free
          * edges in edge order, so a point's / a chunk's free edges are contiguous in Hpl and in the key list
          * freeKP[ce] = pt << 6 | free keyframe index; ptFree[p] = first compact edge of point p */
-        if (tid == 0) srun = 0;
-        __syncthreads();
-        for (int e0 = 0; e0 < nobs; e0 += BA_T * BA_SI) {
-            const int eb = e0 + tid * BA_SI;
-            int kf[BA_SI], cnt = 0;
-#pragma unroll
-            for (int i = 0; i < BA_SI; i++) { kf[i] = (eb + i < nobs) ? obs[eb + i].kf : -1; cnt += (kf[i] >= d.nfixed) ? 1 : 0; }
-            sflags[tid] = cnt;
-            __syncthreads();
-            const int total = tb_block_excl_scan(sflags, BA_T, tmp);
-            int ce = srun + sflags[tid];
-#pragma unroll
-            for (int i = 0; i < BA_SI; i++) {
-                if (eb + i < nobs) { /* points whose first edge is this one (observations are grouped by ascending point) */
-                    const int prev = (eb + i > 0) ? obs[eb + i - 1].pt : -1, cur = obs[eb + i].pt;
-                    for (int p = max(prev + 1, 0); p <= min(cur, d.npt); p++) I[d.oPtFree + p] = ce;
-                }
-                if (kf[i] >= d.nfixed) { I[d.oFreeKP + ce] = (int)(((unsigned)obs[eb + i].pt << 6) | ((unsigned)(kf[i] - d.nfixed) & 63u)); ce++; }
-            }
-            __syncthreads();
-            if (tid == 0) srun += total;
-            __syncthreads();
-        }
-        const int nfreeE = srun;
+        int unused = 0;
+        const int nfreeE = ba_ordered_rank(nobs, tmp, [&](int e) { return obs[e].kf >= d.nfixed; }, [](int) { return false; }, &unused,
+            [&](int e, int ce, bool hit) {
+                /* points whose first edge is this one (observations are grouped by ascending point) */
+                const int prev = (e > 0) ? obs[e - 1].pt : -1, cur = obs[e].pt;
+                for (int p = max(prev + 1, 0); p <= min(cur, d.npt); p++) I[d.oPtFree + p] = ce;
+                if (hit) I[d.oFreeKP + ce] = (int)(((unsigned)cur << 6) | ((unsigned)(obs[e].kf - d.nfixed) & 63u));
+            });
         for (int p = max((nobs > 0 ? obs[nobs - 1].pt : -1) + 1, 0) + tid; p <= d.npt; p += BA_T) I[d.oPtFree + p] = nfreeE;
         __syncthreads();
         int mr = 0; /* most edge rows in a Schur chunk: picks how many the kernel keeps in registers per lane */
