@@ -65,6 +65,31 @@ __device__ __forceinline__ double ba_huber_rho0(double c, double delta) {
     const double dsqr = delta * delta;
     return (c <= dsqr) ? c : 2 * sqrt(c) * delta - dsqr;
 }
+/* Linearisation of one observation at (Tk, X): Huber-weighted information ww, residual (e0, e1), the 2x3 point
+ * Jacobian Jl and camera-frame point pc (for ba_jac_pose). ONE definition for every kernel that needs Hpl =
+ * ww Jp^T Jl: the blocks are never stored, the point pass, the Schur kernel and the back-substitution each rebuild
+ * what they need from the 20-byte observation, and must agree bit for bit. */
+struct BaLin { double ww, e0, e1, c2; double pc[3]; double Jl[6]; };
+__device__ __forceinline__ void ba_linearize(const PoSE3& Tk, const double* X, float u, float v, float inv_sigma2, double fx,
+                                             double fy, double cx, double cy, double delta, BaLin& L) {
+    double R[9];
+    po_map(Tk, X, L.pc);
+    L.e0 = (double)u - (L.pc[0] / L.pc[2] * fx + cx);
+    L.e1 = (double)v - (L.pc[1] / L.pc[2] * fy + cy);
+    const double wgt = (double)inv_sigma2;
+    L.c2 = L.e0 * (wgt * L.e0) + L.e1 * (wgt * L.e1);
+    const double r1 = (L.c2 <= delta * delta) ? 1.0 : delta / sqrt(L.c2);
+    L.ww = r1 * wgt;
+    po_to_R(Tk, R);
+    const double x = L.pc[0], y = L.pc[1], z = L.pc[2];
+    const double tm[6] = {fx, 0, -x / z * fx, 0, fy, -y / z * fy};
+#pragma unroll
+    for (int a = 0; a < 2; a++)
+#pragma unroll
+        for (int c = 0; c < 3; c++)
+            L.Jl[a * 3 + c] = -1. / z * (tm[a * 3] * R[c] + tm[a * 3 + 1] * R[3 + c] + tm[a * 3 + 2] * R[6 + c]);
+}
+
 __device__ __forceinline__ bool ba_inv3(const double* H6, double lambda, double* I) {
     /* H6 = xx, xy, xz, yy, yz, zz of the symmetric Hll block */
     const double A0 = H6[0] + lambda, A1 = H6[1], A2 = H6[2], A4 = H6[3] + lambda, A5 = H6[4], A8 = H6[5] + lambda;
@@ -286,21 +311,13 @@ k_ba_points(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
         for (int e = I[d.oPtStart + p]; e < I[d.oPtStart + p + 1]; e++) {
             const tb_ba_obs o = obs[e];
             const PoSE3 Tk = ba_load_se3(sT + o.kf * 7);
-            double pc[3], R[9], Jp[12], Jl[6];
-            po_map(Tk, X, pc);
-            const double e0 = (double)o.u - (pc[0] / pc[2] * d.fx + d.cx);
-            const double e1 = (double)o.v - (pc[1] / pc[2] * d.fy + d.cy);
-            const double wgt = (double)o.inv_sigma2;
-            const double c2 = e0 * (wgt * e0) + e1 * (wgt * e1);
-            const double r1 = (c2 <= delta * delta) ? 1.0 : delta / sqrt(c2);
-            const double ww = r1 * wgt;
-            chi += ba_huber_rho0(c2, delta);
-            po_to_R(Tk, R);
-            const double x = pc[0], y = pc[1], z = pc[2];
-            const double tm[6] = {d.fx, 0, -x / z * d.fx, 0, d.fy, -y / z * d.fy};
-            for (int a = 0; a < 2; a++)
-                for (int c = 0; c < 3; c++)
-                    Jl[a * 3 + c] = -1. / z * (tm[a * 3] * R[c] + tm[a * 3 + 1] * R[3 + c] + tm[a * 3 + 2] * R[6 + c]);
+            BaLin L;
+            ba_linearize(Tk, X, o.u, o.v, o.inv_sigma2, d.fx, d.fy, d.cx, d.cy, delta, L);
+            const double ww = L.ww, e0 = L.e0, e1 = L.e1;
+            const double* Jl = L.Jl;
+            const double* pc = L.pc;
+            double Jp[12];
+            chi += ba_huber_rho0(L.c2, delta);
             for (int a = 0; a < 3; a++) bl[a] -= ww * (Jl[a] * e0 + Jl[3 + a] * e1);
             Hll[0] += ww * (Jl[0] * Jl[0] + Jl[3] * Jl[3]);
             Hll[1] += ww * (Jl[0] * Jl[1] + Jl[3] * Jl[4]);
@@ -781,6 +798,7 @@ k_ba_update(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
     __shared__ double red[4];
     __shared__ double sT[TB_MAX_LEVELS * 7 * 8];
     __shared__ double sx[64];
+    __shared__ double sTc[TB_MAX_LEVELS * 7 * 8];
     const int w = blockIdx.y, tid = threadIdx.x;
     const BaState st = states[w];
     if (st.status) return;
@@ -788,6 +806,7 @@ k_ba_update(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
     double* D = dw + (size_t)w * d.wstride;
     const int* I = iw + (size_t)w * d.istride;
     const double* Tn = D + d.oT + (size_t)(st.cur ^ 1) * d.nkf * 7;
+    for (int i = tid; i < d.nkf * 7; i += BA_T) sTc[i] = D[d.oT + (size_t)st.cur * d.nkf * 7 + i]; /* linearisation state */
     const double* P = D + d.oP + (size_t)st.cur * d.npt * 3;
     double* Pn = D + d.oP + (size_t)(st.cur ^ 1) * d.npt * 3;
     for (int i = tid; i < d.nkf * 7; i += BA_T) sT[i] = Tn[i];
@@ -804,12 +823,22 @@ k_ba_update(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
             /* k_ba_hinv's record: the damped inverse of this trial (all zero for a singular block: xl stays 0) */
             const double* q = D + d.oHq + (size_t)p * 9;
             const double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5];
-            for (int ce = I[d.oPtFree + p]; ce < I[d.oPtFree + p + 1]; ce++) {
-                const int kfree = I[d.oFreeKP + ce] & 63;
-                const double* H = D + d.oHpl + (size_t)ce * 18;
-                const double* xp = sx + 6 * kfree;
-                for (int c = 0; c < 3; c++)
-                    for (int a = 0; a < 6; a++) r[c] -= H[a * 3 + c] * xp[a];
+            /* r = bl - sum_k Hpl_k^T x_k with Hpl_k = ww Jp^T Jl rebuilt from the observation (a 144-byte block per edge
+             * would cost more to fetch than its ~150 flops): Hpl^T x = ww Jl^T (Jp x) */
+            const double Xc[3] = {P[3 * p], P[3 * p + 1], P[3 * p + 2]};
+            for (int e = I[d.oPtStart + p]; e < I[d.oPtStart + p + 1]; e++) {
+                const tb_ba_obs o = obs[e];
+                if (o.kf < d.nfixed) continue;
+                BaLin L;
+                double Jp[12];
+                ba_linearize(ba_load_se3(sTc + o.kf * 7), Xc, o.u, o.v, o.inv_sigma2, d.fx, d.fy, d.cx, d.cy, delta, L);
+                ba_jac_pose(L.pc, d.fx, d.fy, Jp);
+                const double* xp = sx + 6 * (o.kf - d.nfixed);
+                double s0 = 0, s1 = 0;
+#pragma unroll
+                for (int a = 0; a < 6; a++) { s0 += Jp[a] * xp[a]; s1 += Jp[6 + a] * xp[a]; }
+#pragma unroll
+                for (int c = 0; c < 3; c++) r[c] -= L.ww * (L.Jl[c] * s0 + L.Jl[3 + c] * s1);
             }
             xl[0] = q0 * r[0] + q1 * r[1] + q2 * r[2];
             xl[1] = q1 * r[0] + q3 * r[1] + q4 * r[2];
