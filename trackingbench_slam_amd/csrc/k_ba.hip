@@ -46,7 +46,7 @@ struct BaDims {
     int nblkP, kfChunks, G, nChunks;
     double fx, fy, cx, cy;
     /* per-window offsets, in doubles, into the double workspace */
-    unsigned long long wstride, oT, oP, oHpl, oHll, oBl, oHq, oHpp, oBp, oXp, oPartKF, oPartP, oPartS;
+    unsigned long long wstride, oT, oP, oHll, oBl, oHq, oHpp, oBp, oXp, oPartKF, oPartP, oPartS;
     /* per-window offsets, in ints, into the int workspace */
     unsigned long long istride, oPtStart, oPtFree, oKfStart, oKfEdges, oFreeKP;
 };
@@ -223,14 +223,20 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
     if (k == d.nkf + 1) {
         /* compact numbering of the free-keyframe edges (the only ones with an Hpl block): ce = rank among the free
          * edges in edge order, so a point's / a chunk's free edges are contiguous in Hpl and in the key list
-         * freeKP[ce] = pt << 6 | free keyframe index; ptFree[p] = first compact edge of point p */
+         * freeKP[ce] = {pt << 6 | free keyframe index, u, v, inv_sigma2}; ptFree[p] = first compact edge of point p */
         int unused = 0;
         const int nfreeE = ba_ordered_rank(nobs, tmp, [&](int e) { return obs[e].kf >= d.nfixed; }, [](int) { return false; }, &unused,
             [&](int e, int ce, bool hit) {
                 /* points whose first edge is this one (observations are grouped by ascending point) */
                 const int prev = (e > 0) ? obs[e - 1].pt : -1, cur = obs[e].pt;
                 for (int p = max(prev + 1, 0); p <= min(cur, d.npt); p++) I[d.oPtFree + p] = ce;
-                if (hit) I[d.oFreeKP + ce] = (int)(((unsigned)cur << 6) | ((unsigned)(obs[e].kf - d.nfixed) & 63u));
+                if (hit) { /* 16-byte record of the free-keyframe edge: key, pixel, information scale */
+                    const tb_ba_obs o = obs[e];
+                    int4 r;
+                    r.x = (int)(((unsigned)cur << 6) | ((unsigned)(o.kf - d.nfixed) & 63u));
+                    r.y = __float_as_int(o.u); r.z = __float_as_int(o.v); r.w = __float_as_int(o.inv_sigma2);
+                    *reinterpret_cast<int4*>(I + d.oFreeKP + 4 * (size_t)ce) = r;
+                }
             });
         for (int p = max((nobs > 0 ? obs[nobs - 1].pt : -1) + 1, 0) + tid; p <= d.npt; p += BA_T) I[d.oPtFree + p] = nfreeE;
         __syncthreads();
@@ -269,16 +275,32 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
     }
 }
 
-/* (inverse, bl) record of one point for this trial's lambda: the 6 unique entries of (Hll + lambda I)^-1 (ba_inv3's
- * result is symmetric bit for bit) followed by bl, or zeros for a singular block */
-__device__ __forceinline__ void ba_write_hq(double* q, const double* Hll, const double* bl, double lambda, BaState* st) {
-    double inv[9];
-    const bool ok = ba_inv3(Hll, lambda, inv);
+/* Point record of one trial (12 doubles): the damped point block A = Hll + lambda I enters the Schur complement and
+ * the back-substitution only through A^-1 = U U^T, U = C^-T upper triangular from the Cholesky factor A = C C^T:
+ *   S' = sum_l (Hpl U)(Hpl U)^T,   reduced rhs = sum_l (Hpl U)(U^T bl),   xl = U (U^T r)
+ * so the Schur kernel densifies ONE matrix Z = Hpl U instead of Hpl and Hpl A^-1. Layout: u00 u01 u02 u11 u12 u22,
+ * U^T bl (3), the point X at the linearisation state (3). A block that is not positive definite gives zeros and
+ * flags the trial (st->sing), like the failed inverse of the CPU solver. */
+__device__ __forceinline__ void ba_write_rec(double* q, const double* Hll, const double* bl, const double* X, double lambda,
+                                             BaState* st) {
+    const double a00 = Hll[0] + lambda, a10 = Hll[1], a20 = Hll[2], a11 = Hll[3] + lambda, a21 = Hll[4], a22 = Hll[5] + lambda;
+    bool ok = a00 > 0;
+    const double i00 = 1.0 / sqrt(ok ? a00 : 1.0), c10 = a10 * i00, c20 = a20 * i00;
+    const double d1 = a11 - c10 * c10;
+    ok = ok && d1 > 0;
+    const double i11 = 1.0 / sqrt(ok ? d1 : 1.0), c21 = (a21 - c20 * c10) * i11;
+    const double d2 = a22 - c20 * c20 - c21 * c21;
+    ok = ok && d2 > 0 && isfinite(d2);
+    const double i22 = 1.0 / sqrt(ok ? d2 : 1.0);
     if (!ok) st->sing = 1; /* benign race: every writer stores 1 */
-    q[0] = ok ? inv[0] : 0.0; q[1] = ok ? inv[1] : 0.0; q[2] = ok ? inv[2] : 0.0;
-    q[3] = ok ? inv[4] : 0.0; q[4] = ok ? inv[5] : 0.0; q[5] = ok ? inv[8] : 0.0;
-#pragma unroll
-    for (int c = 0; c < 3; c++) q[6 + c] = ok ? bl[c] : 0.0;
+    const double u00 = i00, u11 = i11, u22 = i22, u01 = -c10 * i00 * i11, u12 = -c21 * i11 * i22,
+                 u02 = -(c20 * i00 + c21 * u01) * i22;
+    q[0] = ok ? u00 : 0.0; q[1] = ok ? u01 : 0.0; q[2] = ok ? u02 : 0.0;
+    q[3] = ok ? u11 : 0.0; q[4] = ok ? u12 : 0.0; q[5] = ok ? u22 : 0.0;
+    q[6] = ok ? u00 * bl[0] : 0.0;
+    q[7] = ok ? u01 * bl[0] + u11 * bl[1] : 0.0;
+    q[8] = ok ? u02 * bl[0] + u12 * bl[1] + u22 * bl[2] : 0.0;
+    q[9] = X[0]; q[10] = X[1]; q[11] = X[2];
 }
 
 /* ---- A: point pass */
@@ -307,7 +329,6 @@ k_ba_points(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
     if (p < d.npt) {
         double Hll[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
         const double X[3] = {P[3 * p], P[3 * p + 1], P[3 * p + 2]};
-        int ce = I[d.oPtFree + p]; /* compact index of the point's next free-keyframe edge */
         for (int e = I[d.oPtStart + p]; e < I[d.oPtStart + p + 1]; e++) {
             const tb_ba_obs o = obs[e];
             const PoSE3 Tk = ba_load_se3(sT + o.kf * 7);
@@ -315,8 +336,6 @@ k_ba_points(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
             ba_linearize(Tk, X, o.u, o.v, o.inv_sigma2, d.fx, d.fy, d.cx, d.cy, delta, L);
             const double ww = L.ww, e0 = L.e0, e1 = L.e1;
             const double* Jl = L.Jl;
-            const double* pc = L.pc;
-            double Jp[12];
             chi += ba_huber_rho0(L.c2, delta);
             for (int a = 0; a < 3; a++) bl[a] -= ww * (Jl[a] * e0 + Jl[3 + a] * e1);
             Hll[0] += ww * (Jl[0] * Jl[0] + Jl[3] * Jl[3]);
@@ -325,23 +344,10 @@ k_ba_points(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
             Hll[3] += ww * (Jl[1] * Jl[1] + Jl[4] * Jl[4]);
             Hll[4] += ww * (Jl[1] * Jl[2] + Jl[4] * Jl[5]);
             Hll[5] += ww * (Jl[2] * Jl[2] + Jl[5] * Jl[5]);
-            if (o.kf >= d.nfixed) {
-                ba_jac_pose(pc, d.fx, d.fy, Jp);
-                /* one Hpl block = 144 B at a 16-byte aligned address: nine 16-byte stores per lane */
-                ba_d2* H = (ba_d2*)__builtin_assume_aligned(D + d.oHpl + (size_t)ce * 18, 16);
-                ce++;
-                double h[18];
-#pragma unroll
-                for (int a = 0; a < 6; a++)
-#pragma unroll
-                    for (int c = 0; c < 3; c++) h[a * 3 + c] = ww * (Jp[a] * Jl[c] + Jp[6 + a] * Jl[3 + c]);
-#pragma unroll
-                for (int i = 0; i < 9; i++) H[i] = (ba_d2){h[2 * i], h[2 * i + 1]};
-            }
         }
         for (int a = 0; a < 6; a++) D[d.oHll + (size_t)p * 6 + a] = Hll[a];
         for (int a = 0; a < 3; a++) D[d.oBl + (size_t)p * 3 + a] = bl[a];
-        if (st.iter > 0) ba_write_hq(D + d.oHq + (size_t)p * 9, Hll, bl, st.lambda, states + w); /* lambda of this trial is final */
+        if (st.iter > 0) ba_write_rec(D + d.oHq + (size_t)p * 12, Hll, bl, X, st.lambda, states + w); /* lambda of this trial is final */
         maxd = fmax(fabs(Hll[0]), fmax(fabs(Hll[3]), fabs(Hll[5])));
     }
     const double s = ba_block_sum1(chi, red);
@@ -460,12 +466,12 @@ k_ba_hinv(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) {
     const BaState st = states[w];
     if (st.status || st.hq_fresh || p >= d.npt) return; /* hq_fresh: k_ba_points wrote the records for this lambda */
     double* D = dw + (size_t)w * d.wstride;
-    double ph[6], pb[3];
+    double ph[6], pb[3], X[3];
 #pragma unroll
     for (int i = 0; i < 6; i++) ph[i] = D[d.oHll + (size_t)p * 6 + i];
 #pragma unroll
-    for (int i = 0; i < 3; i++) pb[i] = D[d.oBl + (size_t)p * 3 + i];
-    ba_write_hq(D + d.oHq + (size_t)p * 9, ph, pb, st.lambda, states + w);
+    for (int i = 0; i < 3; i++) { pb[i] = D[d.oBl + (size_t)p * 3 + i]; X[i] = D[d.oP + ((size_t)st.cur * d.npt + p) * 3 + i]; }
+    ba_write_rec(D + d.oHq + (size_t)p * 12, ph, pb, X, st.lambda, states + w);
 }
 
 /* broadcast of one lane's double through the scalar unit (lane index wave-uniform) */
@@ -475,205 +481,160 @@ __device__ __forceinline__ double ba_readlane(double v, int lane) {
     return __hiloint2double(hi, lo);
 }
 
-/* ---- D: Schur complement S' (np x np, lower triangle) and reduced rhs as an FP64 MFMA block GEMM.
- * Every WAVEFRONT works on its own 4-point chunks with private LDS tiles (no workgroup barrier in the
- * loop; three workgroups per CU keep three waves per SIMD so one wave's scatter overlaps another's MFMAs):
- *   (1) 4 lanes invert the damped 3x3 point blocks, (2) all lanes scatter the chunk's Hpl rows (6 x 3 per
- *   edge) into the dense tiles W and Y = Hpl * Hinv, bl goes to row np of W so the reduced rhs falls out of
- *   the same product, (3) 3 k-steps of v_mfma_f64_16x16x4 over the needed 16x16 tiles (row tile >= column
- *   tile, plus the column tile holding the rhs), (4) the touched entries are cleared again.
- * The loads of the wave's next chunk are issued before the MFMA phase (software pipeline). The four waves'
- * accumulators are summed through LDS in wave order; one partial tile per workgroup goes to k_ba_solve. */
+/* ---- D: Schur complement S' (np x np, lower triangle) and reduced rhs as an FP64 MFMA block product.
+ * Nothing per edge is stored between the passes: S' = sum_l Z_l Z_l^T with Z_l = Hpl_l U_l (6 nfree x 3), where U_l
+ * comes from the point record (A_l^-1 = U_l U_l^T) and every Hpl block = ww Jp^T Jl is rebuilt from the 16-byte
+ * free-edge record and the linearisation state -- ~250 FP64 vector operations per edge, hidden behind the matrix
+ * pipe, against 144 bytes of HBM traffic per edge and pass when the blocks were stored.
+ * Every WAVEFRONT works on its own 4-point chunks with a private LDS tile (no workgroup barrier in the loop):
+ *   lane = one free-keyframe edge of the chunk (at most 4 nfree <= 40): linearise, Z rows into the dense tile
+ *   Z[6 kfree + a][3 pl + c]; 3 k-steps of v_mfma_f64_16x16x4 over the lower-triangle 16x16 tiles with both operands
+ *   read from that one tile; reduced rhs = sum_l Z_l (U_l^T bl_l) as 12 FMAs per lane (lane = row); the touched
+ *   entries are cleared again. Records are prefetched two chunks ahead into one of two register sets; the fetch
+ *   path is unconditional (clamped indices, chunks past the end fetch the last one and stage nothing), so the
+ *   number of loads in flight is the same on every path and the compiler waits with vmcnt(N).
+ * The four waves' accumulators are summed through LDS in wave order; one partial per workgroup goes to k_ba_solve. */
 #define BA_MAXT 4 /* 16-row tiles per side (np <= 60) */
-/* The Schur tiles are private to one wavefront and the LDS executes a wavefront's instructions in issue order, so
+/* The Schur tile is private to one wavefront and the LDS executes a wavefront's instructions in issue order, so
  * cross-lane visibility needs no counter wait: a wavefront-scope fence only pins the compiler's ordering (a
- * workgroup-scope one would also drain vmcnt, i.e. the prefetched edge rows, on every phase change). */
+ * workgroup-scope one would also drain vmcnt, i.e. the prefetched records, on every phase change). */
 __device__ __forceinline__ void ba_wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
-/* LDS of one wavefront, in doubles: Y and W tiles [16 R][BA_LD], the chunk's (inverse, bl) records, a 4-double sink */
-#define BA_TRASH_R(R) (2 * 16 * (R) * BA_LD + BA_CP * 9)
+/* LDS of one wavefront, in doubles: the Z tile [16 R][BA_LD], the chunk's BA_CP point records, a 4-double sink */
+#define BA_REC 12
+#define BA_TRASH_R(R) (16 * (R) * BA_LD + BA_CP * BA_REC)
 #define BA_WAVE_LDS_R(R) (BA_TRASH_R(R) + 4)
 
-/* one prefetched Schur chunk: M edge rows per lane */
-template <int M>
+/* one prefetched Schur chunk */
 struct BaPre {
-    static constexpr int N = M;
-    int key[M];     /* pt << 6 | free keyframe index, -1 = no item */
-    double h0[M], h1[M], h2[M];
-    double hq;      /* lane < 9 * BA_CP: one double of the chunk's (inverse, bl) records */
-    int e0, e1;     /* compact edge range of the chunk held */
+    int key;        /* lane < edges of the chunk: pt << 6 | free keyframe index, else -1 */
+    float u, v, w;  /* pixel, information scale */
+    double rq;      /* lane < BA_CP * BA_REC: one double of the chunk's point records */
     int ne0, ne1;   /* compact edge range of the chunk this set fetches next */
 };
 
 template <int R> /* R = 16-row tiles of the pose block: compile-time tile set (lower triangle), so the MFMA phase is
                      straight-line code with the accumulators pinned in registers */
-__global__ void __launch_bounds__(BA_T, R <= 3 ? 3 : 2)
+__global__ void __launch_bounds__(BA_T, 2)
 k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw, const int* __restrict__ iw,
            BaState* __restrict__ states) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ double sTf[10 * 7]; /* free keyframes at the linearisation state */
     const int w = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
     const BaState st = states[w];
     if (st.status) return;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    constexpr int ROWS = 16 * R, BA_TRASH = BA_TRASH_R(R), BA_WAVE_LDS = BA_WAVE_LDS_R(R);
-    double* Yl = lds + (size_t)wave * BA_WAVE_LDS; /* [ROWS][BA_LD]: Hpl * (Hll + lambda I)^-1 */
-    double* Wl = Yl + ROWS * BA_LD;                /* [ROWS][BA_LD]: Hpl */
-    double* Hi = Wl + ROWS * BA_LD;                /* [BA_CP][9] */
+    constexpr int ROWS = 16 * R, BA_WAVE_LDS = BA_WAVE_LDS_R(R);
+    double* Zl = lds + (size_t)wave * BA_WAVE_LDS; /* [ROWS][BA_LD]: Hpl U */
+    double* Hi = Zl + ROWS * BA_LD;                /* [BA_CP][BA_REC] */
     double* D = dw + (size_t)w * d.wstride;
     const int* I = iw + (size_t)w * d.istride;
+    for (int i = tid; i < d.nfree * 7; i += BA_T) sTf[i] = D[d.oT + ((size_t)st.cur * d.nkf + d.nfixed) * 7 + i];
     ba_d4 acc[BA_MAXT][BA_MAXT];
 #pragma unroll
     for (int r = 0; r < BA_MAXT; r++)
 #pragma unroll
         for (int c = 0; c < BA_MAXT; c++) acc[r][c] = (ba_d4){0, 0, 0, 0};
-    for (int i = lane; i < 2 * ROWS * BA_LD; i += 64) Yl[i] = 0;
-    ba_wave_lds_fence();
-    const int stride = d.G * 4; /* waves per window */
-    int pf = stride; /* chunk distance between a register set's consecutive fills (set by run(): 2 strides with two sets) */
-    /* The edge rows (6 x 3 doubles per edge, one row per lane item) and the (inverse, bl) records of a chunk are
-     * fetched TWO chunks ahead into one of two register sets: a set's loads are issued back to back right after its
-     * previous contents were scattered, nothing looks at them until that set's next scatter, and the other set's
-     * whole chunk (scatter + MFMA phase) lies in between -- enough to cover an HBM miss under load.
-     * Everything on the fetch path is unconditional (clamped indices, a sink for dead items, the tail re-fetches the
-     * last chunk): the number of loads in flight is then the same on every path and the compiler can wait for one
-     * set with vmcnt(N) while the other stays in flight; any data-dependent branch or loop with loads in between
-     * degrades that to vmcnt(0). */
+    for (int i = lane; i < ROWS * BA_LD; i += 64) Zl[i] = 0;
+    __syncthreads();
+    const double delta = (double)sqrtf(5.991f);
+    const int stride = d.G * 4, pf = 2 * stride; /* waves per window; chunk distance between a set's fills */
     const int lastCh = d.nChunks - 1, lastE = d.obs_pitch - 1;
-    const double* Hpl = D + d.oHpl;
     const double* Hq = D + d.oHq;
-    const int* KP = I + d.oFreeKP;
-    auto range = [&](auto& X, int c) {
+    const int4* KP = reinterpret_cast<const int4*>(I + d.oFreeKP);
+    auto range = [&](BaPre& X, int c) {
         c = min(c, lastCh);
         X.ne0 = I[d.oPtFree + c * BA_CP];
         X.ne1 = I[d.oPtFree + min(c * BA_CP + BA_CP, d.npt)];
     };
-    auto preload = [&](auto& X, int c) { /* X.ne0/ne1 = edge range of chunk min(c, lastCh) */
-        constexpr int MAXI = std::remove_reference_t<decltype(X)>::N;
-        const int p0 = min(c, lastCh) * BA_CP, ea = X.ne0, eb = X.ne1;
-        X.e0 = ea; X.e1 = eb;
-#pragma unroll
-        for (int j = 0; j < MAXI; j++) {
-            const int it = lane + j * 64;
-            const unsigned e = (unsigned)min(ea + it / 6, lastE), a = (unsigned)(it - (it / 6) * 6);
-            const int key = KP[e]; /* unsigned 32-bit indices: scalar base + vector offset addressing */
-            X.key[j] = (it < (eb - ea) * 6) ? key : -1;
-            const double* H = Hpl + (e * 18u + a * 3u);
-            X.h0[j] = H[0]; X.h1[j] = H[1]; X.h2[j] = H[2];
-        }
-        X.hq = Hq[min((unsigned)p0 * 9u + (unsigned)min(lane, BA_CP * 9 - 1), (unsigned)d.npt * 9u - 1u)];
+    auto preload = [&](BaPre& X, int c) { /* X.ne0/ne1 = compact edge range of chunk min(c, lastCh) */
+        const int p0 = min(c, lastCh) * BA_CP, ea = X.ne0, eb = (c <= lastCh) ? X.ne1 : ea; /* past the end: no items */
+        const int4 r = KP[(unsigned)min(ea + lane, lastE)]; /* unsigned 32-bit index: scalar base + vector offset */
+        X.key = (lane < eb - ea) ? r.x : -1;
+        X.u = __int_as_float(r.y); X.v = __int_as_float(r.z); X.w = __int_as_float(r.w);
+        X.rq = Hq[min((unsigned)p0 * BA_REC + (unsigned)min(lane, BA_CP * BA_REC - 1), (unsigned)d.npt * BA_REC - 1u)];
         range(X, c + pf);
     };
     const int kofs = lane >> 4, l15 = lane & 15;
-    double rhs = 0; /* lane = row: this wave's part of sum_l Y bl */
-    auto chunk = [&](auto& X, int c) {
-        constexpr int MAXI = std::remove_reference_t<decltype(X)>::N;
-        const int p0 = c * BA_CP, p1 = min(p0 + BA_CP, d.npt);
-        if (lane < BA_CP * 9) Hi[lane] = X.hq;
+    double rhs = 0; /* lane = row: this wave's part of sum_l Z (U^T bl) */
+    auto chunk = [&](BaPre& X, int c) {
+        const int p0 = c * BA_CP, np1 = min(p0 + BA_CP, d.npt) - p0;
+        Hi[min(lane, BA_CP * BA_REC)] = X.rq; /* lanes past the records write the sink behind them */
+        double blp[BA_CP * 3]; /* U^T bl of the chunk's points, wave-uniform (scalar registers) */
+#pragma unroll
+        for (int k = 0; k < BA_CP * 3; k++) {
+            const double b = ba_readlane(X.rq, (k / 3) * BA_REC + 6 + (k % 3));
+            blp[k] = (k / 3 < np1) ? b : 0.0;
+        }
         ba_wave_lds_fence();
-        /* branch-free scatter: row items of fixed keyframes (and the lanes past the chunk's end) go to a sink */
-        int cpos[MAXI];
+        /* this lane's edge: linearise at the stored state, one Z block (6 x 3) into the tile */
+        const bool live = X.key >= 0;
+        const int pl = live ? (X.key >> 6) - p0 : 0, kf = live ? (X.key & 63) : 0;
+        const int zoff = (6 * kf) * BA_LD + 3 * pl;
+        if (live) {
+            const double* q = Hi + pl * BA_REC;
+            const double u00 = q[0], u01 = q[1], u02 = q[2], u11 = q[3], u12 = q[4], u22 = q[5];
+            const double Xp[3] = {q[9], q[10], q[11]};
+            BaLin L;
+            double Jp[12];
+            ba_linearize(ba_load_se3(sTf + kf * 7), Xp, X.u, X.v, X.w, d.fx, d.fy, d.cx, d.cy, delta, L);
+            ba_jac_pose(L.pc, d.fx, d.fy, Jp);
 #pragma unroll
-        for (int jj = 0; jj < MAXI; jj += 2) { /* two items at a time: 12 inverse entries in flight per lane */
-            double q[2][6];
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const int j = jj + u;
-                if (j < MAXI) {
-                    const bool live = X.key[j] >= 0;
-                    const int it = lane + j * 64, a = it - (it / 6) * 6, pl = live ? (X.key[j] >> 6) - p0 : 0;
-                    cpos[j] = live ? (6 * (X.key[j] & 63) + a) * BA_LD + 3 * pl : BA_TRASH;
-#pragma unroll
-                    for (int i = 0; i < 6; i++) q[u][i] = Hi[pl * 9 + i];
-                }
-            }
-#pragma unroll
-            for (int u = 0; u < 2; u++) {
-                const int j = jj + u;
-                if (j < MAXI) {
-                    const int off = cpos[j];
-                    double* yr = Yl + off;
-                    double* wr = Yl + ((off == BA_TRASH) ? BA_TRASH : off + ROWS * BA_LD);
-                    wr[0] = X.h0[j]; wr[1] = X.h1[j]; wr[2] = X.h2[j];
-                    yr[0] = X.h0[j] * q[u][0] + X.h1[j] * q[u][1] + X.h2[j] * q[u][2];
-                    yr[1] = X.h0[j] * q[u][1] + X.h1[j] * q[u][3] + X.h2[j] * q[u][4];
-                    yr[2] = X.h0[j] * q[u][2] + X.h1[j] * q[u][4] + X.h2[j] * q[u][5];
-                }
+            for (int a = 0; a < 6; a++) {
+                const double h0 = L.ww * (Jp[a] * L.Jl[0] + Jp[6 + a] * L.Jl[3]);
+                const double h1 = L.ww * (Jp[a] * L.Jl[1] + Jp[6 + a] * L.Jl[4]);
+                const double h2 = L.ww * (Jp[a] * L.Jl[2] + Jp[6 + a] * L.Jl[5]);
+                double* z = Zl + zoff + a * BA_LD;
+                z[0] = h0 * u00;
+                z[1] = h0 * u01 + h1 * u11;
+                z[2] = h0 * u02 + h1 * u12 + h2 * u22;
             }
         }
         ba_wave_lds_fence();
         /* this set is free again: issue the loads of the chunk it holds next, before the MFMA phase */
-        double bl[BA_CP * 3]; /* the chunk's bl, broadcast from the record registers (wave-uniform) */
-#pragma unroll
-        for (int k = 0; k < BA_CP * 3; k++) bl[k] = ba_readlane(X.hq, (k / 3) * 9 + 6 + (k % 3));
         preload(X, c + pf);
-        /* reduced right-hand side on the vector ALU: lane = row of Y, 3 * BA_CP products per chunk (as a 17th column
+        /* reduced right-hand side on the vector ALU: lane = row of Z, 3 * BA_CP products per chunk (as a 17th column
          * of the block product it would cost R more MFMA tiles per k-step for one useful column) */
 #pragma unroll
-        for (int k = 0; k < BA_CP * 3; k++) {
-            const double b = (k / 3 < p1 - p0) ? bl[k] : 0.0;
-            rhs = fma(Yl[min(lane, ROWS - 1) * BA_LD + k], b, rhs); /* lanes >= ROWS: never read back */
-        }
+        for (int k = 0; k < BA_CP * 3; k++) rhs = fma(Zl[min(lane, ROWS - 1) * BA_LD + k], blp[k], rhs); /* lanes >= ROWS: never read back */
 #pragma unroll
         for (int kk = 0; kk < BA_CP * 3; kk += 4) {
-            double av[BA_MAXT], bv[BA_MAXT];
+            double av[BA_MAXT];
 #pragma unroll
-            for (int t = 0; t < BA_MAXT; t++) {
-                av[t] = (t < R) ? Yl[(16 * t + l15) * BA_LD + kk + kofs] : 0.0;
-                bv[t] = (t < R) ? Wl[(16 * t + l15) * BA_LD + kk + kofs] : 0.0;
-            }
+            for (int t = 0; t < BA_MAXT; t++) av[t] = (t < R) ? Zl[(16 * t + l15) * BA_LD + kk + kofs] : 0.0;
 #pragma unroll
             for (int r = 0; r < BA_MAXT; r++)
 #pragma unroll
                 for (int cc = 0; cc < BA_MAXT; cc++)
                     if (r < R && cc <= r)
-                        acc[r][cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[r], bv[cc], acc[r][cc], 0, 0, 0);
+                        acc[r][cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[r], av[cc], acc[r][cc], 0, 0, 0);
         }
         ba_wave_lds_fence();
-        /* clear what this chunk wrote (positions kept in registers) */
+        if (live) { /* clear what this lane wrote */
 #pragma unroll
-        for (int j = 0; j < MAXI; j++) {
-            const int off = cpos[j], woff = (off == BA_TRASH) ? BA_TRASH : off + ROWS * BA_LD;
-            Yl[woff] = Yl[woff + 1] = Yl[woff + 2] = 0;
-            Yl[off] = Yl[off + 1] = Yl[off + 2] = 0;
+            for (int a = 0; a < 6; a++) {
+                double* z = Zl + zoff + a * BA_LD;
+                z[0] = z[1] = z[2] = 0;
+            }
         }
         ba_wave_lds_fence();
     };
-    auto run = [&](auto mTag) {
-        constexpr int M = decltype(mTag)::value;
-        /* two register sets in flight where the budget of three waves per SIMD (168 VGPRs; two waves for the 10-tile
-         * case) has room for them: up to two row items per lane */
-        constexpr bool TWO = R < 4 && M <= 2;
-        pf = TWO ? 2 * stride : stride;
-        BaPre<M> A;
+    if (d.nChunks > 0) {
+        BaPre A, B;
         int ch = g * 4 + wave;
         range(A, ch);
-        if constexpr (TWO) {
-            BaPre<M> B;
-            range(B, ch + stride);
-            preload(A, ch);
-            preload(B, ch + stride);
-            for (; ch + stride < d.nChunks; ch += 2 * stride) {
-                chunk(A, ch);
-                chunk(B, ch + stride);
-            }
-            if (ch < d.nChunks) chunk(A, ch);
-        } else {
-            preload(A, ch);
-            for (; ch < d.nChunks; ch += stride) chunk(A, ch);
+        range(B, ch + stride);
+        preload(A, ch);
+        preload(B, ch + stride);
+        for (; ch + stride < d.nChunks; ch += 2 * stride) {
+            chunk(A, ch);
+            chunk(B, ch + stride);
         }
-    };
-    /* rows per lane held in registers: the smallest M with 64 M >= the window's longest chunk; M = R always
-     * suffices (BA_CP points seen at most once by every free keyframe: 24 nfree <= 64 R; k_ba_setup rejects repeats) */
-    if (d.nChunks > 0) {
-        const int mr = st.max_rows;
-        if (mr <= 64 || R == 1) run(std::integral_constant<int, 1>{});
-        else if (mr <= 128 || R == 2) run(std::integral_constant<int, (R >= 2 ? 2 : 1)>{});
-        else if (mr <= 192 || R == 3) run(std::integral_constant<int, (R >= 3 ? 3 : 1)>{});
-        else run(std::integral_constant<int, R>{});
+        if (ch < d.nChunks) chunk(A, ch);
     }
     __syncthreads();
     /* sum the four waves' accumulators through LDS in wave order (fixed shape), then one partial per block.
      * C/D map of v_mfma_f64_16x16x4: col = lane & 15, row = (lane >> 4) + 4 * reg */
-    double* sum = lds; /* 64 x 64, reuses the tile storage: every wave is past its last tile read */
+    double* sum = lds; /* 16 R x 64, reuses the tile storage: every wave is past its last tile read */
     for (int wv = 0; wv < 4; wv++) {
         if (wave == wv) {
 #pragma unroll
@@ -687,7 +648,7 @@ k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ 
                         }
             ba_wave_lds_fence();
             /* column np = reduced rhs (k_ba_solve reads it there); it may lie inside a diagonal tile, whose entries
-             * in that column are products with the all-zero row np of W: overwritten / added on top */
+             * in that column are products with an all-zero row of Z: overwritten / added on top */
             if (lane < d.np) sum[lane * 64 + d.np] = (wv == 0) ? rhs : sum[lane * 64 + d.np] + rhs;
         }
         __syncthreads();
@@ -820,9 +781,9 @@ k_ba_update(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
         const double bl[3] = {r[0], r[1], r[2]};
         double xl[3] = {0, 0, 0};
         if (st.ok2) {
-            /* k_ba_hinv's record: the damped inverse of this trial (all zero for a singular block: xl stays 0) */
-            const double* q = D + d.oHq + (size_t)p * 9;
-            const double q0 = q[0], q1 = q[1], q2 = q[2], q3 = q[3], q4 = q[4], q5 = q[5];
+            /* the point record of this trial: A^-1 = U U^T (all zero for a singular block: xl stays 0) */
+            const double* q = D + d.oHq + (size_t)p * 12;
+            const double u00 = q[0], u01 = q[1], u02 = q[2], u11 = q[3], u12 = q[4], u22 = q[5];
             /* r = bl - sum_k Hpl_k^T x_k with Hpl_k = ww Jp^T Jl rebuilt from the observation (a 144-byte block per edge
              * would cost more to fetch than its ~150 flops): Hpl^T x = ww Jl^T (Jp x) */
             const double Xc[3] = {P[3 * p], P[3 * p + 1], P[3 * p + 2]};
@@ -840,9 +801,10 @@ k_ba_update(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
 #pragma unroll
                 for (int c = 0; c < 3; c++) r[c] -= L.ww * (L.Jl[c] * s0 + L.Jl[3 + c] * s1);
             }
-            xl[0] = q0 * r[0] + q1 * r[1] + q2 * r[2];
-            xl[1] = q1 * r[0] + q3 * r[1] + q4 * r[2];
-            xl[2] = q2 * r[0] + q4 * r[1] + q5 * r[2];
+            const double t0 = u00 * r[0], t1 = u01 * r[0] + u11 * r[1], t2 = u02 * r[0] + u12 * r[1] + u22 * r[2]; /* U^T r */
+            xl[0] = u00 * t0 + u01 * t1 + u02 * t2;
+            xl[1] = u11 * t1 + u12 * t2;
+            xl[2] = u22 * t2;
         }
         double X[3];
         for (int a = 0; a < 3; a++) {
@@ -940,16 +902,15 @@ static void ba_dims(BaDims& d, int W, const double K[4], int nkf, int nfixed, in
     d.nblkP = (npt + BA_T - 1) / BA_T;
     d.kfChunks = (obs_pitch + BA_KFCH - 1) / BA_KFCH;
     d.nChunks = (npt + BA_CP - 1) / BA_CP;
-    d.G = std::min(std::max((d.np <= 48 ? 768 : 512) / std::max(W, 1), 1), std::max((d.nChunks + 3) / 4, 1)); /* 3 resident Schur blocks per CU (2 for the 10-tile case) */
+    d.G = std::min(std::max(768 / std::max(W, 1), 1), std::max((d.nChunks + 3) / 4, 1)); /* 3 resident Schur blocks per CU */
     d.fx = K[0]; d.fy = K[1]; d.cx = K[2]; d.cy = K[3];
     unsigned long long o = 0;
     auto take = [&](unsigned long long n) { unsigned long long r = o; o += (n + 1) & ~1ull; return r; };
     d.oT = take(2ull * nkf * 7);
     d.oP = take(2ull * npt * 3);
-    d.oHpl = take(18ull * obs_pitch);
     d.oHll = take(6ull * npt);
     d.oBl = take(3ull * npt);
-    d.oHq = take(9ull * npt);
+    d.oHq = take(12ull * npt);
     d.oHpp = take(36ull * std::max(d.nfree, 1));
     d.oBp = take(64);
     d.oXp = take(64);
@@ -963,7 +924,7 @@ static void ba_dims(BaDims& d, int W, const double K[4], int nkf, int nfixed, in
     d.oPtFree = itake(npt + 1);
     d.oKfStart = itake(nkf + 1);
     d.oKfEdges = itake(obs_pitch);
-    d.oFreeKP = itake(obs_pitch);
+    d.oFreeKP = itake(4ull * obs_pitch);
     d.istride = io;
 }
 
