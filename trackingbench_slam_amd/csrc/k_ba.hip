@@ -54,13 +54,6 @@ struct BaDims {
 typedef double ba_d4 __attribute__((ext_vector_type(4)));
 typedef double ba_d2 __attribute__((ext_vector_type(2)));
 
-__device__ __forceinline__ void ba_jac_pose(const double* pc, double fx, double fy, double* J) {
-    const double x = pc[0], y = pc[1], invz = 1.0 / pc[2], invz_2 = invz * invz;
-    J[0] = x * y * invz_2 * fx; J[1] = -(1 + (x * x * invz_2)) * fx; J[2] = y * invz * fx;
-    J[3] = -invz * fx; J[4] = 0; J[5] = x * invz_2 * fx;
-    J[6] = (1 + y * y * invz_2) * fy; J[7] = -x * y * invz_2 * fy; J[8] = -x * invz * fy;
-    J[9] = 0; J[10] = -invz * fy; J[11] = y * invz_2 * fy;
-}
 __device__ __forceinline__ double ba_huber_rho0(double c, double delta) {
     const double dsqr = delta * delta;
     return (c <= dsqr) ? c : 2 * sqrt(c) * delta - dsqr;
@@ -69,25 +62,39 @@ __device__ __forceinline__ double ba_huber_rho0(double c, double delta) {
  * Jacobian Jl and camera-frame point pc (for ba_jac_pose). ONE definition for every kernel that needs Hpl =
  * ww Jp^T Jl: the blocks are never stored, the point pass, the Schur kernel and the back-substitution each rebuild
  * what they need from the 20-byte observation, and must agree bit for bit. */
-struct BaLin { double ww, e0, e1, c2; double pc[3]; double Jl[6]; };
-__device__ __forceinline__ void ba_linearize(const PoSE3& Tk, const double* X, float u, float v, float inv_sigma2, double fx,
-                                             double fy, double cx, double cy, double delta, BaLin& L) {
-    double R[9];
+struct BaLin { double ww, e0, e1, c2, invz; double pc[3]; double Jl[6]; };
+/* residual and Huber-weighted information of one observation; one reciprocal per edge (an FP64 division is ~12
+ * instructions around a quarter-rate v_rcp_f64, and these run on the same FP64 units as the MFMAs) */
+__device__ __forceinline__ void ba_residual(const PoSE3& Tk, const double* X, float u, float v, float inv_sigma2, double fx,
+                                            double fy, double cx, double cy, double delta, BaLin& L) {
     po_map(Tk, X, L.pc);
-    L.e0 = (double)u - (L.pc[0] / L.pc[2] * fx + cx);
-    L.e1 = (double)v - (L.pc[1] / L.pc[2] * fy + cy);
+    L.invz = 1.0 / L.pc[2];
+    L.e0 = (double)u - (L.pc[0] * L.invz * fx + cx);
+    L.e1 = (double)v - (L.pc[1] * L.invz * fy + cy);
     const double wgt = (double)inv_sigma2;
     L.c2 = L.e0 * (wgt * L.e0) + L.e1 * (wgt * L.e1);
     const double r1 = (L.c2 <= delta * delta) ? 1.0 : delta / sqrt(L.c2);
     L.ww = r1 * wgt;
+}
+__device__ __forceinline__ void ba_linearize(const PoSE3& Tk, const double* X, float u, float v, float inv_sigma2, double fx,
+                                             double fy, double cx, double cy, double delta, BaLin& L) {
+    double R[9];
+    ba_residual(Tk, X, u, v, inv_sigma2, fx, fy, cx, cy, delta, L);
     po_to_R(Tk, R);
-    const double x = L.pc[0], y = L.pc[1], z = L.pc[2];
-    const double tm[6] = {fx, 0, -x / z * fx, 0, fy, -y / z * fy};
+    const double ax = -(L.pc[0] * L.invz) * fx, ay = -(L.pc[1] * L.invz) * fy, m = -L.invz;
 #pragma unroll
-    for (int a = 0; a < 2; a++)
-#pragma unroll
-        for (int c = 0; c < 3; c++)
-            L.Jl[a * 3 + c] = -1. / z * (tm[a * 3] * R[c] + tm[a * 3 + 1] * R[3 + c] + tm[a * 3 + 2] * R[6 + c]);
+    for (int c = 0; c < 3; c++) { /* Jl = -1/z [fx 0 -x/z fx; 0 fy -y/z fy] R */
+        L.Jl[c] = m * (fx * R[c] + ax * R[6 + c]);
+        L.Jl[3 + c] = m * (fy * R[3 + c] + ay * R[6 + c]);
+    }
+}
+/* d(projection)/d(pose increment), 2 x 6, rows at J[0..5] and J[6..11] (g2o EdgeSE3ProjectXYZ convention) */
+__device__ __forceinline__ void ba_jac_pose_iz(const double* pc, double invz, double fx, double fy, double* J) {
+    const double x = pc[0], y = pc[1], invz_2 = invz * invz;
+    J[0] = x * y * invz_2 * fx; J[1] = -(1 + (x * x * invz_2)) * fx; J[2] = y * invz * fx;
+    J[3] = -invz * fx; J[4] = 0; J[5] = x * invz_2 * fx;
+    J[6] = (1 + y * y * invz_2) * fy; J[7] = -x * y * invz_2 * fy; J[8] = -x * invz * fy;
+    J[9] = 0; J[10] = -invz * fy; J[11] = y * invz_2 * fy;
 }
 
 __device__ __forceinline__ bool ba_inv3(const double* H6, double lambda, double* I) {
@@ -392,16 +399,12 @@ k_ba_kf(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw,
             const tb_ba_obs o = obs[ee[j]];
             const int p = pp[j];
             const double X[3] = {P[3 * p], P[3 * p + 1], P[3 * p + 2]};
-            double pc[3], Jp[12];
-            po_map(Tk, X, pc);
-            ba_jac_pose(pc, d.fx, d.fy, Jp);
-            /* error and Huber weight exactly as the point pass computes them (same operands, same operations): cheaper
-             * than a 24-byte-per-edge round trip through HBM */
-            const double e0 = (double)o.u - (pc[0] / pc[2] * d.fx + d.cx);
-            const double e1 = (double)o.v - (pc[1] / pc[2] * d.fy + d.cy);
-            const double wgt = (double)o.inv_sigma2;
-            const double c2 = e0 * (wgt * e0) + e1 * (wgt * e1);
-            const double ww = ((c2 <= delta * delta) ? 1.0 : delta / sqrt(c2)) * wgt;
+            double Jp[12];
+            BaLin L; /* residual and Huber weight exactly as the point pass computes them (same helper): cheaper than a
+                        24-byte-per-edge round trip through HBM */
+            ba_residual(Tk, X, o.u, o.v, o.inv_sigma2, d.fx, d.fy, d.cx, d.cy, delta, L);
+            ba_jac_pose_iz(L.pc, L.invz, d.fx, d.fy, Jp);
+            const double ww = L.ww, e0 = L.e0, e1 = L.e1;
 #pragma unroll
             for (int a = 0; a < 6; a++) {
                 acc[21 + a] -= ww * (Jp[a] * e0 + Jp[6 + a] * e1);
@@ -577,16 +580,22 @@ k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ 
             BaLin L;
             double Jp[12];
             ba_linearize(ba_load_se3(sTf + kf * 7), Xp, X.u, X.v, X.w, d.fx, d.fy, d.cx, d.cy, delta, L);
-            ba_jac_pose(L.pc, d.fx, d.fy, Jp);
+            ba_jac_pose_iz(L.pc, L.invz, d.fx, d.fy, Jp);
+            /* Z = Hpl U = (ww Jp)^T (Jl U): the 2 x 3 factor Jl U first, then 6 rows of two products each */
+            double JU[6];
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                JU[3 * r] = L.Jl[3 * r] * u00;
+                JU[3 * r + 1] = L.Jl[3 * r] * u01 + L.Jl[3 * r + 1] * u11;
+                JU[3 * r + 2] = L.Jl[3 * r] * u02 + L.Jl[3 * r + 1] * u12 + L.Jl[3 * r + 2] * u22;
+            }
 #pragma unroll
             for (int a = 0; a < 6; a++) {
-                const double h0 = L.ww * (Jp[a] * L.Jl[0] + Jp[6 + a] * L.Jl[3]);
-                const double h1 = L.ww * (Jp[a] * L.Jl[1] + Jp[6 + a] * L.Jl[4]);
-                const double h2 = L.ww * (Jp[a] * L.Jl[2] + Jp[6 + a] * L.Jl[5]);
+                const double p0w = L.ww * Jp[a], p1w = L.ww * Jp[6 + a];
                 double* z = Zl + zoff + a * BA_LD;
-                z[0] = h0 * u00;
-                z[1] = h0 * u01 + h1 * u11;
-                z[2] = h0 * u02 + h1 * u12 + h2 * u22;
+                z[0] = p0w * JU[0] + p1w * JU[3];
+                z[1] = p0w * JU[1] + p1w * JU[4];
+                z[2] = p0w * JU[2] + p1w * JU[5];
             }
         }
         ba_wave_lds_fence();
@@ -793,7 +802,7 @@ k_ba_update(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
                 BaLin L;
                 double Jp[12];
                 ba_linearize(ba_load_se3(sTc + o.kf * 7), Xc, o.u, o.v, o.inv_sigma2, d.fx, d.fy, d.cx, d.cy, delta, L);
-                ba_jac_pose(L.pc, d.fx, d.fy, Jp);
+                ba_jac_pose_iz(L.pc, L.invz, d.fx, d.fy, Jp);
                 const double* xp = sx + 6 * (o.kf - d.nfixed);
                 double s0 = 0, s1 = 0;
 #pragma unroll
@@ -814,12 +823,9 @@ k_ba_update(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
         }
         for (int e = I[d.oPtStart + p]; e < I[d.oPtStart + p + 1]; e++) {
             const tb_ba_obs o = obs[e];
-            double pc[3];
-            po_map(ba_load_se3(sT + o.kf * 7), X, pc);
-            const double e0 = (double)o.u - (pc[0] / pc[2] * d.fx + d.cx);
-            const double e1 = (double)o.v - (pc[1] / pc[2] * d.fy + d.cy);
-            const double wgt = (double)o.inv_sigma2;
-            chi += ba_huber_rho0(e0 * (wgt * e0) + e1 * (wgt * e1), delta);
+            BaLin L; /* the same residual arithmetic as the point pass: rho compares like with like */
+            ba_residual(ba_load_se3(sT + o.kf * 7), X, o.u, o.v, o.inv_sigma2, d.fx, d.fy, d.cx, d.cy, delta, L);
+            chi += ba_huber_rho0(L.c2, delta);
         }
     }
     const double s1 = ba_block_sum1(chi, red);
