@@ -65,9 +65,10 @@ __device__ __forceinline__ double ba_huber_rho0(double c, double delta) {
 struct BaLin { double ww, e0, e1, c2, invz; double pc[3]; double Jl[6]; };
 /* residual and Huber-weighted information of one observation; one reciprocal per edge (an FP64 division is ~12
  * instructions around a quarter-rate v_rcp_f64, and these run on the same FP64 units as the MFMAs) */
-__device__ __forceinline__ void ba_residual(const PoSE3& Tk, const double* X, float u, float v, float inv_sigma2, double fx,
+__device__ __forceinline__ void ba_residual(const double* Rt, const double* X, float u, float v, float inv_sigma2, double fx,
                                             double fy, double cx, double cy, double delta, BaLin& L) {
-    po_map(Tk, X, L.pc);
+#pragma unroll
+    for (int i = 0; i < 3; i++) L.pc[i] = ((Rt[3 * i] * X[0] + Rt[3 * i + 1] * X[1]) + Rt[3 * i + 2] * X[2]) + Rt[9 + i];
     L.invz = 1.0 / L.pc[2];
     L.e0 = (double)u - (L.pc[0] * L.invz * fx + cx);
     L.e1 = (double)v - (L.pc[1] * L.invz * fy + cy);
@@ -76,17 +77,23 @@ __device__ __forceinline__ void ba_residual(const PoSE3& Tk, const double* X, fl
     const double r1 = (L.c2 <= delta * delta) ? 1.0 : delta / sqrt(L.c2);
     L.ww = r1 * wgt;
 }
-__device__ __forceinline__ void ba_linearize(const PoSE3& Tk, const double* X, float u, float v, float inv_sigma2, double fx,
+__device__ __forceinline__ void ba_linearize(const double* Rt, const double* X, float u, float v, float inv_sigma2, double fx,
                                              double fy, double cx, double cy, double delta, BaLin& L) {
-    double R[9];
-    ba_residual(Tk, X, u, v, inv_sigma2, fx, fy, cx, cy, delta, L);
-    po_to_R(Tk, R);
+    ba_residual(Rt, X, u, v, inv_sigma2, fx, fy, cx, cy, delta, L);
     const double ax = -(L.pc[0] * L.invz) * fx, ay = -(L.pc[1] * L.invz) * fy, m = -L.invz;
 #pragma unroll
     for (int c = 0; c < 3; c++) { /* Jl = -1/z [fx 0 -x/z fx; 0 fy -y/z fy] R */
-        L.Jl[c] = m * (fx * R[c] + ax * R[6 + c]);
-        L.Jl[3 + c] = m * (fy * R[3 + c] + ay * R[6 + c]);
+        L.Jl[c] = m * (fx * Rt[c] + ax * Rt[6 + c]);
+        L.Jl[3 + c] = m * (fy * Rt[3 + c] + ay * Rt[6 + c]);
     }
+}
+/* keyframe pose as the passes use it: rotation matrix (row major) and translation, 12 doubles. Every kernel converts
+ * the stored unit quaternion once per workgroup instead of once per edge. */
+__device__ __forceinline__ void ba_pose_to_Rt(const double* T7, double* Rt) {
+    PoSE3 s;
+    s.qx = T7[0]; s.qy = T7[1]; s.qz = T7[2]; s.qw = T7[3]; s.tx = T7[4]; s.ty = T7[5]; s.tz = T7[6];
+    po_to_R(s, Rt);
+    Rt[9] = s.tx; Rt[10] = s.ty; Rt[11] = s.tz;
 }
 /* d(projection)/d(pose increment), 2 x 6, rows at J[0..5] and J[6..11] (g2o EdgeSE3ProjectXYZ convention) */
 __device__ __forceinline__ void ba_jac_pose_iz(const double* pc, double invz, double fx, double fy, double* J) {
@@ -315,7 +322,7 @@ __global__ void __launch_bounds__(BA_T)
 k_ba_points(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw, const int* __restrict__ iw,
             BaState* __restrict__ states, const int* __restrict__ errflag) {
     __shared__ double red[4];
-    __shared__ double sT[TB_MAX_LEVELS * 7 * 8];
+    __shared__ double sRt[TB_MAX_LEVELS * 8 * 12];
     const int w = blockIdx.y, tid = threadIdx.x;
     if (errflag[w]) { /* k_ba_setup rejected the window's observations: nothing may index with them */
         if (blockIdx.x == 0 && tid == 0) { states[w].status = 1; states[w].err = 1; }
@@ -328,7 +335,7 @@ k_ba_points(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
     const int* I = iw + (size_t)w * d.istride;
     const double* T = D + d.oT + (size_t)st.cur * d.nkf * 7;
     const double* P = D + d.oP + (size_t)st.cur * d.npt * 3;
-    for (int i = tid; i < d.nkf * 7; i += BA_T) sT[i] = T[i];
+    for (int k = tid; k < d.nkf; k += BA_T) ba_pose_to_Rt(T + k * 7, sRt + k * 12);
     __syncthreads();
     const double delta = (double)sqrtf(5.991f);
     const int p = blockIdx.x * BA_T + tid;
@@ -338,9 +345,8 @@ k_ba_points(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
         const double X[3] = {P[3 * p], P[3 * p + 1], P[3 * p + 2]};
         for (int e = I[d.oPtStart + p]; e < I[d.oPtStart + p + 1]; e++) {
             const tb_ba_obs o = obs[e];
-            const PoSE3 Tk = ba_load_se3(sT + o.kf * 7);
             BaLin L;
-            ba_linearize(Tk, X, o.u, o.v, o.inv_sigma2, d.fx, d.fy, d.cx, d.cy, delta, L);
+            ba_linearize(sRt + o.kf * 12, X, o.u, o.v, o.inv_sigma2, d.fx, d.fy, d.cx, d.cy, delta, L);
             const double ww = L.ww, e0 = L.e0, e1 = L.e1;
             const double* Jl = L.Jl;
             chi += ba_huber_rho0(L.c2, delta);
@@ -377,7 +383,8 @@ k_ba_kf(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw,
     double* D = dw + (size_t)w * d.wstride;
     const int* I = iw + (size_t)w * d.istride;
     const int beg = I[d.oKfStart + kf], end = I[d.oKfStart + kf + 1];
-    const PoSE3 Tk = ba_load_se3(D + d.oT + ((size_t)st.cur * d.nkf + kf) * 7);
+    double Tk[12];
+    ba_pose_to_Rt(D + d.oT + ((size_t)st.cur * d.nkf + kf) * 7, Tk);
     const double* P = D + d.oP + (size_t)st.cur * d.npt * 3;
     const double delta = (double)sqrtf(5.991f);
     /* BA_KFBLK blocks per keyframe walk its chunks; k_ba_reduce sums the occupied chunks in order */
@@ -521,7 +528,7 @@ __global__ void __launch_bounds__(BA_T, 2)
 k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw, const int* __restrict__ iw,
            BaState* __restrict__ states) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    __shared__ double sTf[10 * 7]; /* free keyframes at the linearisation state */
+    __shared__ double sRtf[10 * 12]; /* free keyframes at the linearisation state: R, t */
     const int w = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
     const BaState st = states[w];
     if (st.status) return;
@@ -531,7 +538,7 @@ k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ 
     double* Hi = Zl + ROWS * BA_LD;                /* [BA_CP][BA_REC] */
     double* D = dw + (size_t)w * d.wstride;
     const int* I = iw + (size_t)w * d.istride;
-    for (int i = tid; i < d.nfree * 7; i += BA_T) sTf[i] = D[d.oT + ((size_t)st.cur * d.nkf + d.nfixed) * 7 + i];
+    for (int k = tid; k < d.nfree; k += BA_T) ba_pose_to_Rt(D + d.oT + ((size_t)st.cur * d.nkf + d.nfixed + k) * 7, sRtf + k * 12);
     ba_d4 acc[BA_MAXT][BA_MAXT];
 #pragma unroll
     for (int r = 0; r < BA_MAXT; r++)
@@ -579,7 +586,7 @@ k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ 
             const double Xp[3] = {q[9], q[10], q[11]};
             BaLin L;
             double Jp[12];
-            ba_linearize(ba_load_se3(sTf + kf * 7), Xp, X.u, X.v, X.w, d.fx, d.fy, d.cx, d.cy, delta, L);
+            ba_linearize(sRtf + kf * 12, Xp, X.u, X.v, X.w, d.fx, d.fy, d.cx, d.cy, delta, L);
             ba_jac_pose_iz(L.pc, L.invz, d.fx, d.fy, Jp);
             /* Z = Hpl U = (ww Jp)^T (Jl U): the 2 x 3 factor Jl U first, then 6 rows of two products each */
             double JU[6];
@@ -766,9 +773,9 @@ __global__ void __launch_bounds__(BA_T)
 k_ba_update(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw, const int* __restrict__ iw,
             const BaState* __restrict__ states) {
     __shared__ double red[4];
-    __shared__ double sT[TB_MAX_LEVELS * 7 * 8];
+    __shared__ double sRt[TB_MAX_LEVELS * 8 * 12];  /* trial poses */
     __shared__ double sx[64];
-    __shared__ double sTc[TB_MAX_LEVELS * 7 * 8];
+    __shared__ double sRtc[TB_MAX_LEVELS * 8 * 12]; /* linearisation state */
     const int w = blockIdx.y, tid = threadIdx.x;
     const BaState st = states[w];
     if (st.status) return;
@@ -776,10 +783,10 @@ k_ba_update(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
     double* D = dw + (size_t)w * d.wstride;
     const int* I = iw + (size_t)w * d.istride;
     const double* Tn = D + d.oT + (size_t)(st.cur ^ 1) * d.nkf * 7;
-    for (int i = tid; i < d.nkf * 7; i += BA_T) sTc[i] = D[d.oT + (size_t)st.cur * d.nkf * 7 + i]; /* linearisation state */
+    for (int k = tid; k < d.nkf; k += BA_T) ba_pose_to_Rt(D + d.oT + ((size_t)st.cur * d.nkf + k) * 7, sRtc + k * 12);
     const double* P = D + d.oP + (size_t)st.cur * d.npt * 3;
     double* Pn = D + d.oP + (size_t)(st.cur ^ 1) * d.npt * 3;
-    for (int i = tid; i < d.nkf * 7; i += BA_T) sT[i] = Tn[i];
+    for (int k = tid; k < d.nkf; k += BA_T) ba_pose_to_Rt(Tn + k * 7, sRt + k * 12);
     for (int i = tid; i < d.np; i += BA_T) sx[i] = D[d.oXp + i];
     __syncthreads();
     const double delta = (double)sqrtf(5.991f);
@@ -801,7 +808,7 @@ k_ba_update(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
                 if (o.kf < d.nfixed) continue;
                 BaLin L;
                 double Jp[12];
-                ba_linearize(ba_load_se3(sTc + o.kf * 7), Xc, o.u, o.v, o.inv_sigma2, d.fx, d.fy, d.cx, d.cy, delta, L);
+                ba_linearize(sRtc + o.kf * 12, Xc, o.u, o.v, o.inv_sigma2, d.fx, d.fy, d.cx, d.cy, delta, L);
                 ba_jac_pose_iz(L.pc, L.invz, d.fx, d.fy, Jp);
                 const double* xp = sx + 6 * (o.kf - d.nfixed);
                 double s0 = 0, s1 = 0;
@@ -824,7 +831,7 @@ k_ba_update(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
         for (int e = I[d.oPtStart + p]; e < I[d.oPtStart + p + 1]; e++) {
             const tb_ba_obs o = obs[e];
             BaLin L; /* the same residual arithmetic as the point pass: rho compares like with like */
-            ba_residual(ba_load_se3(sT + o.kf * 7), X, o.u, o.v, o.inv_sigma2, d.fx, d.fy, d.cx, d.cy, delta, L);
+            ba_residual(sRt + o.kf * 12, X, o.u, o.v, o.inv_sigma2, d.fx, d.fy, d.cx, d.cy, delta, L);
             chi += ba_huber_rho0(L.c2, delta);
         }
     }
