@@ -62,15 +62,16 @@ def algorithmic_bytes(kernel, w, h, nlevels, scale, target, nimg, npairs):
 def schur_roofs(ba_pts, nwin, ba_kf, free_edges, nfixed=2):
     """k_ba_schur, ALGORITHMIC work of one launch (one LM trial of `nwin` windows), DESIGN.md 'Roofline accounting':
     flops = lower triangle of the np x np Schur block plus the reduced right-hand side, K = 3 densified columns per
-    point (the kernel executes more: 16x16 tiles pad the triangle); bytes = one 144 B Hpl block + 4 B key per
-    free-keyframe edge, one 72 B (inverse, bl) record per point, the per-workgroup partial blocks written."""
+    point (the kernel executes more: 16x16 tiles pad the triangle, and every Hpl block is rebuilt from its
+    observation instead of being fetched); bytes = one 16 B record per free-keyframe edge, one 96 B record per
+    point, the per-workgroup partial blocks written."""
     np_ = 6 * (ba_kf - nfixed)
     flops = 2.0 * (np_ * (np_ + 1) / 2 + np_) * 3 * ba_pts * nwin
     R = (np_ + 15) // 16
     nchunks = (ba_pts + 3) // 4
-    G = min(max(512 // max(nwin, 1), 1), max((nchunks + 3) // 4, 1))      # ba_dims() in k_ba.hip
+    G = min(max(1024 // max(nwin, 1), 1), max((nchunks + 3) // 4, 1))     # ba_dims() in k_ba.hip
     out = G * (R * (R + 1) // 2 * 256 + np_) * 8
-    nbytes = free_edges * (144 + 4) + nwin * (ba_pts * 72 + out)
+    nbytes = free_edges * 16 + nwin * (ba_pts * 96 + out)
     return flops, nbytes
 
 

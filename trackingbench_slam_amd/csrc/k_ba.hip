@@ -915,7 +915,7 @@ static void ba_dims(BaDims& d, int W, const double K[4], int nkf, int nfixed, in
     d.nblkP = (npt + BA_T - 1) / BA_T;
     d.kfChunks = (obs_pitch + BA_KFCH - 1) / BA_KFCH;
     d.nChunks = (npt + BA_CP - 1) / BA_CP;
-    d.G = std::min(std::max(768 / std::max(W, 1), 1), std::max((d.nChunks + 3) / 4, 1)); /* 3 resident Schur blocks per CU */
+    d.G = std::min(std::max(1024 / std::max(W, 1), 1), std::max((d.nChunks + 3) / 4, 1)); /* up to 4 resident Schur blocks per CU */
     d.fx = K[0]; d.fy = K[1]; d.cx = K[2]; d.cy = K[3];
     unsigned long long o = 0;
     auto take = [&](unsigned long long n) { unsigned long long r = o; o += (n + 1) & ~1ull; return r; };
