@@ -128,6 +128,18 @@ class TrackingPipeline:
             if self._step_done is not None:
                 st.wait_event(self._step_done)   # the previous step's consumers of the BA buffers are done
             futures.append(self._pool.submit(self._run_ba, ba, st))
+        self.extract_chain()
+        for fu in futures:
+            fu.result()
+        for _, st, _ in self.bas:
+            main.wait_stream(st)                 # the step is complete when every stream is
+        if self.bas:
+            self._step_done = torch.cuda.Event()
+            self._step_done.record(main)
+
+    def extract_chain(self):
+        """pyramid -> ORB -> searchByBF -> pose-opt -> track records of the resident batch, on the context's stream."""
+        F, ex, ctx, L = self.F, self.ex, self.ctx, capi.lib()
         ex.build_pyramid(2 * F)
         ex.orb(2 * F, self.target, self.init_th, self.min_th)
         pitch = self.kp_cap * 32
@@ -142,13 +154,6 @@ class TrackingPipeline:
                                           self.obs_pitch, C.c_void_p(self.outlier.data_ptr()), C.c_void_p(self.Tout.data_ptr()),
                                           C.c_void_p(self.n_inliers.data_ptr()), C.c_void_p(self.pose_stats.data_ptr())))
         ex.copy_results_dev(F, self.trk_kps.data_ptr(), self.trk_desc.data_ptr(), self.trk_counts.data_ptr(), self.kp_cap)
-        for fu in futures:
-            fu.result()
-        for _, st, _ in self.bas:
-            main.wait_stream(st)                 # the step is complete when every stream is
-        if self.bas:
-            self._step_done = torch.cuda.Event()
-            self._step_done.record(main)
 
     # ---- outputs (host copies, for tests)
     def frame_results(self, f):
