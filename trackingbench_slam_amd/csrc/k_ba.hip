@@ -7,20 +7,24 @@
  * 5.991); g2o-style Levenberg-Marquardt (tau = 1e-5, rho-based lambda update, <= 10 trials per
  * iteration) on the Schur-reduced pose system.  A batch of W equally sized windows runs together.
  *
- * MI355X mapping: an LM trial is a "round" of seven small kernels over all windows (no host round trips
- * inside a round; per-window LM state lives in HBM and every kernel skips finished windows):
- *   A point pass   (thread per point)  errors, Huber weights, Hll, bl, Hpl            -- only after an accepted step
- *   B keyframe pass(block per KF chunk) Hpp, bp as fixed-shape tree reductions          -- "
+ * MI355X mapping: an LM trial is a "round" of eight kernels over all windows (no host round trips inside a round;
+ * per-window LM state lives in HBM and every kernel skips finished windows). NOTHING PER EDGE IS STORED between the
+ * passes: every consumer rebuilds the linearisation of an edge (ba_linearize: ww, residual, Jl, Jp) from its
+ * 20-byte observation and the state -- ~150 FP64 operations against what used to be a 144-byte Hpl block per edge
+ * and pass through HBM.
+ *   A point pass    (thread per point)   chi2, Hll, bl; the point's record once lambda is final  -- after an accepted step
+ *   B keyframe pass (block per KF chunk) Hpp, bp as fixed-shape tree reductions                  -- "
  *   C reduce        chunk partials -> Hpp, bp, chi2, lambda_0
- *   D Schur         S' = sum_l (Hpl Hll^-1)(Hpl)^T as a dense block GEMM on the FP64 matrix cores
- *                   (v_mfma_f64_16x16x4): each workgroup densifies chunks of 32 points into two 64 x 96
- *                   LDS tiles (Y = Hpl Hll^-1, W = Hpl, plus bl as an extra row of W so the reduced right-hand
- *                   side falls out of the same product) and accumulates a 64 x 64 tile in registers
- *   E solve         S = Hpp + lambda I - S', Cholesky in LDS, pose update through the exp map
- *   F point update  back-substitution, trial errors
+ *   C2 records      (thread per point)   A = Hll + lambda I = C C^T, U = C^-T (A^-1 = U U^T), U^T bl, X -- when A could not
+ *   D Schur         S' = sum_l Z_l Z_l^T, Z_l = Hpl_l U_l, on the FP64 matrix cores (v_mfma_f64_16x16x4): every
+ *                   wavefront densifies its own 4-point chunks into a private LDS tile (lane = edge), both MFMA
+ *                   operands come from that tile; reduced rhs = sum_l Z_l (U_l^T bl_l) on the vector ALU
+ *   E solve         S = Hpp + lambda I - S', Cholesky in the registers of one wavefront, pose update through the exp map
+ *   F point update  back-substitution xl = U (U^T (bl - sum_k Hpl^T x_k)), trial chi2
  *   G decide        rho, accept / reject, lambda update, termination
  * Every cross-thread sum has a fixed shape (per-block trees + ordered partial sums), so results are
- * reproducible run to run.  Bound: FP64 MFMA for D (utilisation reported by bench.py), VALU/latency else.
+ * reproducible run to run.  Bound: the FP64 units (matrix + vector work, same datapath on CDNA4) for D, FP64
+ * VALU / latency for the rest; bench.py reports both roofs of D.
  */
 #include <type_traits>
 #include "tb_internal.h"
