@@ -168,6 +168,17 @@ int tb_search_by_projection_batch_dev(tb_ctx* ctx, int npairs, const float* Tcw1
                                       int th_high, int histo_len, int check_orientation, tb_match* out, int cap,
                                       int32_t* out_counts, int32_t* flags);
 
+/* Batched, device-resident Matcher::searchByViolence (matcher.cpp:299-395): pair p matches F1's keys (k1 / d1 at stride
+ * pitch1, n1[p] valid) against F2's (stride pitch2, n2[p] valid) through F2's lookup grid from
+ * tb_frame_grid_batch_dev (built over k2 with img2_*). Matches (queryIdx = F1 key, trainIdx = F2 key) go to
+ * out + p*cap in the reference's order, their number to out_counts[p] (truncated list, untruncated count);
+ * flags[p] = 2 reports a rotation bin outside the histogram (the reference asserts). Device pointers, asynchronous. */
+int tb_search_by_violence_batch_dev(tb_ctx* ctx, int npairs, const tb_keypoint* k1, const uint8_t* d1, const int32_t* n1,
+                                    int pitch1, const tb_keypoint* k2, const uint8_t* d2, const int32_t* n2, int pitch2,
+                                    const int32_t* cell_start2, const int32_t* cell_items2, int img2_width, int img2_height,
+                                    int min_level, int max_level, float radius, int th_low, float nratio, int histo_len,
+                                    int check_orientation, tb_match* out, int cap, int32_t* out_counts, int32_t* flags);
+
 /* ---------------------------------------------------------------- pose optimisation / local BA
  * LocalBA::PoseOptimization, LocalBA.cpp:291-490. K = fx,fy,cx,cy. Tcw_in/out: row-major 4x4.
  * outlier: n in/out flags (Frame::GetOutlier/SetOutlier). *n_inliers = nInitialCorrespondences - nBad.

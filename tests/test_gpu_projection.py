@@ -118,3 +118,70 @@ def test_projection_batch_device_resident(ctx):
     c = cases[0]
     _same(bp.matches(0), oracle.search_by_projection(c["Tcw"], c["cam"], c["width"], c["height"], c["k1"], c["d1"], c["taken1"],
                                                      c["k2"], c["mp"], c["mp_desc"], c["sf"], 8.0))
+
+
+def _violence_case(seed, n1, n2, width=1241, height=376):
+    """Two key sets for the window matcher: F2 = a shifted, re-angled, partly re-described copy of F1 plus clutter."""
+    st = synth.Stream(0x51013 + seed)
+    k1 = np.zeros(n1, capi.KEYPOINT)
+    k1["x"] = st.uniform(n1, 4, width - 4).astype(np.float32); k1["y"] = st.uniform(n1, 4, height - 4).astype(np.float32)
+    k1["octave"] = st.randint(n1, 0, 3); k1["angle"] = st.uniform(n1, 0, 360).astype(np.float32)
+    d1 = st.u64(n1 * 4).view(np.uint8).reshape(n1, 32).copy()
+    src = st.randint(n2, 0, max(n1, 1))
+    near = st.uniform(n2) < 0.7
+    k2 = np.zeros(n2, capi.KEYPOINT)
+    if n1:
+        k2["x"] = np.where(near, k1["x"][src] + st.uniform(n2, -6, 6), st.uniform(n2, 0, width)).astype(np.float32)
+        k2["y"] = np.where(near, k1["y"][src] + st.uniform(n2, -6, 6), st.uniform(n2, 0, height)).astype(np.float32)
+        k2["octave"] = np.clip(k1["octave"][src] + st.randint(n2, -1, 2), 0, 7)
+        rot = np.where(st.uniform(n2) < 0.8, 40.0, st.uniform(n2, 0, 360))
+        k2["angle"] = ((k1["angle"][src] - rot + st.uniform(n2, -3, 3)) % 360.0).astype(np.float32)
+        d2 = np.where(near[:, None], d1[src], st.u64(n2 * 4).view(np.uint8).reshape(n2, 32)).copy()
+    else:
+        d2 = st.u64(n2 * 4).view(np.uint8).reshape(n2, 32).copy()
+    flips = st.randint(n2 * 10, 0, 256).reshape(n2, 10)
+    nflip = st.randint(n2, 0, 11)
+    for i in range(n2):
+        for b in flips[i, :nflip[i]]:
+            d2[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    return k1, d1, k2, d2
+
+
+def test_violence_batch_device_resident(ctx):
+    """searchByViolence for a batch of frame pairs on device-built lookup grids == oracle == host entry point."""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", 0)
+    W, H = 1241, 376
+    cases = [_violence_case(i, n1, n2) for i, (n1, n2) in enumerate([(2000, 2000), (1200, 1900), (300, 50), (1, 700), (500, 0)])]
+    P = len(cases)
+    p1 = max(len(c[0]) for c in cases); p2 = max(max(len(c[2]) for c in cases), 1)
+    k1 = np.zeros((P, p1), capi.KEYPOINT); d1 = np.zeros((P, p1, 32), np.uint8)
+    k2 = np.zeros((P, p2), capi.KEYPOINT); d2 = np.zeros((P, p2, 32), np.uint8)
+    n1 = np.zeros(P, np.int32); n2 = np.zeros(P, np.int32)
+    for i, (a, b, c, d) in enumerate(cases):
+        k1[i, :len(a)] = a; d1[i, :len(a)] = b; k2[i, :len(c)] = c; d2[i, :len(c)] = d
+        n1[i], n2[i] = len(a), len(c)
+
+    def up(a):
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(dev)
+    tk1, td1, tk2, td2 = up(k1), up(d1), up(k2), up(d2)
+    tn1, tn2 = torch.from_numpy(n1).to(dev), torch.from_numpy(n2).to(dev)
+    cs = torch.zeros((P, 120 * 36 + 1), dtype=torch.int32, device=dev); ci = torch.zeros((P, p2), dtype=torch.int32, device=dev)
+    out = torch.zeros((P, p1, 4), dtype=torch.int32, device=dev); oc = torch.zeros(P, dtype=torch.int32, device=dev)
+    fl = torch.zeros(P, dtype=torch.int32, device=dev)
+    L = capi.lib()
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    ctx.check(L.tb_frame_grid_batch_dev(ctx._h, P, vp(tk2), vp(tn2), p2, W, H, vp(cs), vp(ci)))
+    for check, rad, ratio in ((True, 20.0, 0.9), (False, 8.0, 0.7)):
+        ctx.check(L.tb_search_by_violence_batch_dev(ctx._h, P, vp(tk1), vp(td1), vp(tn1), p1, vp(tk2), vp(td2), vp(tn2), p2, vp(cs), vp(ci),
+                                                    W, H, 0, 5, C.c_float(rad), 60, C.c_float(ratio), 30, int(check), vp(out), p1, vp(oc),
+                                                    vp(fl)))
+        torch.cuda.synchronize()
+        assert int(fl.abs().sum().item()) == 0
+        for p, (a, b, c, d) in enumerate(cases):
+            mo = oracle.search_by_violence(a, b, c, d, W, H, 0, 5, rad, 60, ratio, 30, check)
+            n = int(oc[p].item())
+            _same(out[p, :n].cpu().numpy().view(capi.MATCH).reshape(-1), mo)
+            _same(ctx.search_by_violence(a, b, c, d, W, H, 0, 5, rad, 60, ratio, 30, check), mo)
+        assert int(oc.sum().item()) > 500

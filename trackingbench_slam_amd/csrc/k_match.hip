@@ -619,3 +619,164 @@ int tbk_projection_batch(tb_ctx* ctx, int npairs, const float* d_Tcw, const tb_c
     TB_HIP(ctx, hipGetLastError());
     return TB_OK;
 }
+
+/* ------------------------------------------------------------------------------------------------
+ * Batched, device-resident Matcher::searchByViolence (matcher.cpp:299-395) on the device-built lookup grids: pair =
+ * blockIdx.y; window search per F1 key (k_window's body), then acceptance (th_low, nratio), rotation histogram,
+ * ComputeThreeMaxima and the reference's output order, one workgroup per pair. */
+struct VioBatch {
+    const tb_keypoint* k1; const uint8_t* d1; const int32_t* n1; int pitch1;
+    const tb_keypoint* k2; const uint8_t* d2; const int32_t* n2; int pitch2;
+    const int32_t* cellStart; const int32_t* cellItems; /* grids of the F2 frames */
+    float widthInv, heightInv, r, nratio;
+    int min_level, max_level, th_low, histo_len, check_orientation;
+    int32_t* best;            /* [npairs][pitch1][4]: bestDist, bestDist2, bestIdx, candidates */
+    tb_match* out; int cap; int32_t* out_counts; int32_t* flags;
+};
+
+__global__ void __launch_bounds__(256)
+k_window_batch(VioBatch B) {
+    const int GRID_ROWS = 36, GRID_COLS = 120;
+    const int p = blockIdx.y, i1 = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n1 = min(B.n1[p], B.pitch1);
+    if (i1 >= n1) return;
+    const tb_keypoint* k1 = B.k1 + (size_t)p * B.pitch1;
+    const tb_keypoint* k2 = B.k2 + (size_t)p * B.pitch2;
+    const uint8_t* d2 = B.d2 + (size_t)p * B.pitch2 * 32;
+    const int32_t* cs = B.cellStart + (size_t)p * (GRID_CELLS + 1);
+    const int32_t* ci = B.cellItems + (size_t)p * B.pitch2;
+    int bestDist = 0x7fffffff, bestDist2 = 0x7fffffff, bestIdx = -1, ncand = 0;
+    const float x = k1[i1].x, y = k1[i1].y, r = B.r;
+    const int nMinCellX = max(0, (int)floorf((x - r) * B.widthInv));
+    const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf((x + r) * B.widthInv));
+    const int nMinCellY = max(0, (int)floorf((y - r) * B.heightInv));
+    const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf((y + r) * B.heightInv));
+    if (nMinCellX < GRID_COLS && nMaxCellX >= 0 && nMinCellY < GRID_ROWS && nMaxCellY >= 0) {
+        const bool bCheckLevels = (B.min_level > 0) || (B.max_level >= 0);
+        const unsigned long long* a = reinterpret_cast<const unsigned long long*>(B.d1) + ((size_t)p * B.pitch1 + i1) * 4;
+        Desc256 da;
+        da.w[0] = a[0]; da.w[1] = a[1]; da.w[2] = a[2]; da.w[3] = a[3];
+        for (int ix = nMinCellX; ix <= nMaxCellX; ix++)
+            for (int iy = nMinCellY; iy <= nMaxCellY; iy++) {
+                const int c = ix * GRID_ROWS + iy;
+                for (int s = cs[c]; s < cs[c + 1]; s++) {
+                    const int j = ci[s];
+                    const tb_keypoint kp = k2[j];
+                    if (bCheckLevels) {
+                        if (kp.octave < B.min_level) continue;
+                        if (B.max_level >= 0 && kp.octave > B.max_level) continue;
+                    }
+                    if (!(fabsf(kp.x - x) < r && fabsf(kp.y - y) < r)) continue;
+                    ncand++;
+                    const int dist = bf_dist(da, reinterpret_cast<const unsigned long long*>(d2) + (size_t)j * 4);
+                    if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx = j; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+            }
+    }
+    int32_t* o = B.best + ((size_t)p * B.pitch1 + i1) * 4;
+    o[0] = bestDist; o[1] = bestDist2; o[2] = bestIdx; o[3] = ncand;
+}
+
+__global__ void __launch_bounds__(256)
+k_violence_accept_batch(VioBatch B) {
+    __shared__ int hist[1024];
+    __shared__ int sflag[256];
+    __shared__ int tmp[8];
+    __shared__ int keep[3];
+    __shared__ int srun;
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int n1 = min(B.n1[p], B.pitch1);
+    const int32_t* best = B.best + (size_t)p * B.pitch1 * 4;
+    const tb_keypoint* k1 = B.k1 + (size_t)p * B.pitch1;
+    const tb_keypoint* k2 = B.k2 + (size_t)p * B.pitch2;
+    tb_match* out = B.out + (size_t)p * B.cap;
+    const float factor = 1.f / (float)B.histo_len;
+    auto accepted = [&](int i1, int& bin) -> bool { /* matcher.cpp:352-377 */
+        if (i1 >= n1) return false;
+        const int bd = best[4 * (size_t)i1], bd2 = best[4 * (size_t)i1 + 1], bi = best[4 * (size_t)i1 + 2];
+        if (best[4 * (size_t)i1 + 3] == 0) return false;
+        if (!(bd <= B.th_low && (float)bd < (float)bd2 * B.nratio)) return false;
+        bin = 0;
+        if (B.check_orientation) {
+            float rot = k1[i1].angle - k2[bi].angle;
+            if (rot < 0) rot += 360.f;
+            bin = (int)roundf(rot * factor);
+            if (bin == B.histo_len) bin = 0;
+            if (bin < 0 || bin >= B.histo_len) { B.flags[p] = 2; return false; } /* the reference asserts */
+        }
+        return true;
+    };
+    if (tid == 0) { keep[0] = B.check_orientation ? -1 : 0; keep[1] = keep[2] = -1; srun = 0; }
+    for (int b = tid; b < B.histo_len; b += 256) hist[b] = 0;
+    __syncthreads();
+    if (B.check_orientation) {
+        for (int i1 = tid; i1 < n1; i1 += 256) { int bin; if (accepted(i1, bin)) atomicAdd(&hist[bin], 1); }
+        __syncthreads();
+        if (tid == 0) { /* Matcher::ComputeThreeMaxima, matcher.cpp:810-851 */
+            int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+            for (int i = 0; i < B.histo_len; i++) {
+                const int s = hist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = i; }
+                else if (s > max3) { max3 = s; i3 = i; }
+            }
+            if ((float)max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
+            else if ((float)max3 < 0.1f * (float)max1) { i3 = -1; }
+            int a = i1 < 0 ? (1 << 30) : i1, b = i2 < 0 ? (1 << 30) : i2, c = i3 < 0 ? (1 << 30) : i3, t;
+            if (a > b) { t = a; a = b; b = t; }
+            if (b > c) { t = b; b = c; c = t; }
+            if (a > b) { t = a; a = b; b = t; }
+            keep[0] = a < (1 << 30) ? a : -1; keep[1] = b < (1 << 30) ? b : -1; keep[2] = c < (1 << 30) ? c : -1;
+        }
+        __syncthreads();
+    }
+    for (int kb = 0; kb < 3; kb++) {
+        const int want = keep[kb];
+        if (want < 0) continue;
+        for (int e0 = 0; e0 < n1; e0 += 256) {
+            const int i1 = e0 + tid;
+            int bin = 0;
+            const int f = (accepted(i1, bin) && (!B.check_orientation || bin == want)) ? 1 : 0;
+            sflag[tid] = f;
+            __syncthreads();
+            const int total = tb_block_excl_scan(sflag, 256, tmp);
+            const int slot = srun + sflag[tid];
+            if (f && slot < B.cap) {
+                tb_match m;
+                m.queryIdx = i1; m.trainIdx = best[4 * (size_t)i1 + 2]; m.imgIdx = -1; m.distance = (float)best[4 * (size_t)i1];
+                out[slot] = m;
+            }
+            __syncthreads();
+            if (tid == 0) srun += total;
+            __syncthreads();
+        }
+    }
+    if (tid == 0) B.out_counts[p] = srun;
+}
+
+int tbk_violence_batch(tb_ctx* ctx, int npairs, const tb_keypoint* d_k1, const uint8_t* d_d1, const int32_t* d_n1, int pitch1,
+                       const tb_keypoint* d_k2, const uint8_t* d_d2, const int32_t* d_n2, int pitch2, const int32_t* d_cellStart,
+                       const int32_t* d_cellItems, int img2_w, int img2_h, int min_level, int max_level, float radius, int th_low,
+                       float nratio, int histo_len, int check_orientation, int32_t* d_best, tb_match* d_out, int cap,
+                       int32_t* d_out_counts, int32_t* d_flags) {
+    if (npairs <= 0 || pitch1 <= 0) return TB_OK;
+    VioBatch B;
+    B.k1 = d_k1; B.d1 = d_d1; B.n1 = d_n1; B.pitch1 = pitch1;
+    B.k2 = d_k2; B.d2 = d_d2; B.n2 = d_n2; B.pitch2 = pitch2;
+    B.cellStart = d_cellStart; B.cellItems = d_cellItems;
+    B.heightInv = 120.f / (float)img2_w; B.widthInv = 36.f / (float)img2_h; /* swapped in the reference; kept */
+    B.r = radius; B.nratio = nratio; B.min_level = min_level; B.max_level = max_level;
+    B.th_low = th_low; B.histo_len = histo_len; B.check_orientation = check_orientation;
+    B.best = d_best; B.out = d_out; B.cap = cap; B.out_counts = d_out_counts; B.flags = d_flags;
+    TB_HIP(ctx, hipMemsetAsync(d_flags, 0, (size_t)npairs * sizeof(int32_t), ctx->stream));
+    tb_prof_begin(ctx, "k_window_batch");
+    hipLaunchKernelGGL(k_window_batch, dim3((pitch1 + 255) / 256, npairs), dim3(256), 0, ctx->stream, B);
+    tb_prof_end(ctx);
+    TB_HIP(ctx, hipGetLastError());
+    tb_prof_begin(ctx, "k_violence_accept");
+    hipLaunchKernelGGL(k_violence_accept_batch, dim3(npairs), dim3(256), 0, ctx->stream, B);
+    tb_prof_end(ctx);
+    TB_HIP(ctx, hipGetLastError());
+    return TB_OK;
+}

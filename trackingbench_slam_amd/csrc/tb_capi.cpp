@@ -1096,6 +1096,23 @@ int tb_search_by_projection_batch_dev(tb_ctx* ctx, int npairs, const float* Tcw1
                                 (int32_t*)dbest, out, cap, out_counts, flags);
 }
 
+int tb_search_by_violence_batch_dev(tb_ctx* ctx, int npairs, const tb_keypoint* k1, const uint8_t* d1, const int32_t* n1, int pitch1,
+                                    const tb_keypoint* k2, const uint8_t* d2, const int32_t* n2, int pitch2,
+                                    const int32_t* cell_start2, const int32_t* cell_items2, int img2_width, int img2_height,
+                                    int min_level, int max_level, float radius, int th_low, float nratio, int histo_len,
+                                    int check_orientation, tb_match* out, int cap, int32_t* out_counts, int32_t* flags) {
+    if (!ctx || npairs < 0 || histo_len < 1 || histo_len > 1024 || pitch1 < 1 || pitch2 < 1 || cap < 0 || img2_width < 1 || img2_height < 1)
+        return TB_EINVAL;
+    if (npairs == 0) return TB_OK;
+    if (!k1 || !d1 || !n1 || !k2 || !d2 || !n2 || !cell_start2 || !cell_items2 || !out || !out_counts || !flags) return TB_EINVAL;
+    void* dbest;
+    int rc = tb_scratch(ctx, 6, (size_t)npairs * pitch1 * 4 * sizeof(int32_t), &dbest);
+    if (rc) return rc;
+    return tbk_violence_batch(ctx, npairs, k1, d1, n1, pitch1, k2, d2, n2, pitch2, cell_start2, cell_items2, img2_width, img2_height,
+                              min_level, max_level, radius, th_low, nratio, histo_len, check_orientation, (int32_t*)dbest, out, cap,
+                              out_counts, flags);
+}
+
 /* ------------------------------------------------------------------ pose optimisation / local BA */
 int tb_pose_opt_batch_dev(tb_ctx* ctx, int nproblems, const double K[4], const float* Tcw_in, const tb_obs* obs,
                           const int32_t* counts, int obs_pitch, uint8_t* outlier, float* Tcw_out, int32_t* n_inliers,

@@ -140,6 +140,11 @@ int tbk_window_match(tb_ctx* ctx, const tb_keypoint* d_k1, const uint8_t* d_d1, 
                      const uint8_t* d_d2, int n2, const int32_t* d_cellStart, const int32_t* d_cellItems,
                      float widthInv, float heightInv, int min_level, int max_level, float r,
                      int32_t* d_best /* n1 x 4: bestDist, bestDist2, bestIdx, #candidates */);
+int tbk_violence_batch(tb_ctx* ctx, int npairs, const tb_keypoint* d_k1, const uint8_t* d_d1, const int32_t* d_n1, int pitch1,
+                       const tb_keypoint* d_k2, const uint8_t* d_d2, const int32_t* d_n2, int pitch2, const int32_t* d_cellStart,
+                       const int32_t* d_cellItems, int img2_w, int img2_h, int min_level, int max_level, float radius, int th_low,
+                       float nratio, int histo_len, int check_orientation, int32_t* d_best, tb_match* d_out, int cap,
+                       int32_t* d_out_counts, int32_t* d_flags);
 /* device-resident lookup grids and the batched searchByProjection(F1, F2) on them */
 int tbk_grid_build_batch(tb_ctx* ctx, int nframes, const tb_keypoint* d_keys, const int32_t* d_counts, int key_pitch, int img_w,
                          int img_h, int32_t* d_cellStart, int32_t* d_cellItems);
