@@ -90,3 +90,34 @@ def test_local_ba_rejects_bad_input(ctx):
         P2 = np.tile(np.eye(4, dtype=np.float32), (14, 1, 1))
         ctx.local_ba(K, P2, 2, Xi, obs, 5)
     assert e.value.code == capi.TB_EUNSUPPORTED
+
+
+def test_local_ba_unobserved_points_and_empty_window(ctx):
+    """Points without any observation keep their position (their block is lambda I, their gradient zero); a window without
+    observations is left untouched. Both next to ordinary windows in one batch."""
+    Pt, Pi, Xt, Xi, obs = synth.ba_problem(21, 5, 60, K)
+    o2 = obs[(obs["pt"] != 3) & (obs["pt"] != 7) & (obs["pt"] != 59)]
+    io, Po, Xo, so = oracle.local_ba(K, Pi, 2, Xi, o2, 5)
+    ig, Pg, Xg, sg = ctx.local_ba(K, Pi, 2, Xi, o2, 5)
+    _close(Pg, Po)
+    _close(Xg, Xo)
+    assert np.array_equal(Xg[[3, 7, 59]], Xi[[3, 7, 59]])
+    # only fixed keyframes observe a point: no Schur contribution, but it still moves
+    o3 = obs[~((obs["pt"] == 5) & (obs["kf"] >= 2))]
+    io, Po, Xo, so = oracle.local_ba(K, Pi, 2, Xi, o3, 5)
+    ig, Pg, Xg, sg = ctx.local_ba(K, Pi, 2, Xi, o3, 5)
+    _close(Pg, Po)
+    _close(Xg, Xo)
+    import torch
+    from trackingbench_slam_amd.ba import BatchedLocalBA
+    ba = BatchedLocalBA(ctx, 3, nkf=6, npt=200, iters=6, seed=9, device=torch.device("cuda", 0), distinct=3)
+    ba.counts[1] = 0                      # the middle window has no observations
+    ba.run()
+    torch.cuda.synchronize()
+    # (poses pass through the solver's unit quaternion and back: equal to rounding, not bit for bit)
+    assert torch.allclose(ba.poses[1], ba.poses0[1], rtol=0, atol=1e-6) and torch.equal(ba.pts[1], ba.pts0[1])
+    for w in (0, 2):
+        n = int(ba.host["counts"][w])
+        io, Po, Xo, so = oracle.local_ba(K, ba.host["poses"][w], 2, ba.host["pts"][w], ba.host["obs"][w, :n], 6)
+        _close(ba.poses[w].cpu().numpy().reshape(-1, 4, 4), Po)
+        _close(ba.pts[w].cpu().numpy(), Xo)
