@@ -52,6 +52,7 @@ k_resize(PlanGeom g, uint8_t* __restrict__ slab, const ResizeX* __restrict__ rx,
  * lane stay in registers across the tile's rows, and the 16 taps of every output group come from LDS instead
  * of 16 scattered global byte loads. Requires 4-byte aligned source rows; tile footprint given by the launcher. */
 #define RS_ROWS 8
+#define RS_MAXR 14 /* source rows of a tile kept in registers while they are fetched (8 destination rows at scale >= 0.73) */
 
 __global__ void __launch_bounds__(64)
 k_resize_lds(PlanGeom g, uint8_t* __restrict__ slab, const ResizeX* __restrict__ rx, const ResizeY* __restrict__ ry,
@@ -68,10 +69,27 @@ k_resize_lds(PlanGeom g, uint8_t* __restrict__ slab, const ResizeX* __restrict__
     const int ndw = ((sxb - sxa) >> 2) + 1;
     const int sya = ry[dy0].sy0, syb = ry[dy1].sy1;
     const int nrows = syb - sya + 1;
-    for (int r = 0; r < nrows; r++) {
-        const uint8_t* S = src + (size_t)(sya + r) * sstride + sxa;
-        for (int dd = lane; dd < ndw; dd += 64)
-            *reinterpret_cast<uint32_t*>(rows + r * rowBytes + 4 * dd) = *reinterpret_cast<const uint32_t*>(S + 4 * dd);
+    if (nrows <= RS_MAXR && ndw <= 128) {
+        /* every source dword of the tile in flight at once (a load -> LDS store loop per row is one memory latency per
+         * row and wave), then the LDS stores */
+        uint32_t v[RS_MAXR][2];
+        const uint8_t* S = src + (size_t)sya * sstride + sxa + 4 * lane;
+#pragma unroll
+        for (int r = 0; r < RS_MAXR; r++) {
+            v[r][0] = (r < nrows && lane < ndw) ? *reinterpret_cast<const uint32_t*>(S + (size_t)r * sstride) : 0u;
+            v[r][1] = (r < nrows && lane + 64 < ndw) ? *reinterpret_cast<const uint32_t*>(S + (size_t)r * sstride + 256) : 0u;
+        }
+#pragma unroll
+        for (int r = 0; r < RS_MAXR; r++) {
+            if (r < nrows && lane < ndw) *reinterpret_cast<uint32_t*>(rows + r * rowBytes + 4 * lane) = v[r][0];
+            if (r < nrows && lane + 64 < ndw) *reinterpret_cast<uint32_t*>(rows + r * rowBytes + 4 * lane + 256) = v[r][1];
+        }
+    } else {
+        for (int r = 0; r < nrows; r++) {
+            const uint8_t* S = src + (size_t)(sya + r) * sstride + sxa;
+            for (int dd = lane; dd < ndw; dd += 64)
+                *reinterpret_cast<uint32_t*>(rows + r * rowBytes + 4 * dd) = *reinterpret_cast<const uint32_t*>(S + 4 * dd);
+        }
     }
     __syncthreads();
     const int dx0 = X0 + 4 * lane;
