@@ -347,8 +347,11 @@ k_ba_points(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
     if (p < d.npt) {
         double Hll[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
         const double X[3] = {P[3 * p], P[3 * p + 1], P[3 * p + 2]};
-        for (int e = I[d.oPtStart + p]; e < I[d.oPtStart + p + 1]; e++) {
-            const tb_ba_obs o = obs[e];
+        const int eBeg = I[d.oPtStart + p], eEnd = I[d.oPtStart + p + 1];
+        tb_ba_obs on = obs[min(eBeg, d.obs_pitch - 1)]; /* the next observation is in flight while this one is linearised */
+        for (int e = eBeg; e < eEnd; e++) {
+            const tb_ba_obs o = on;
+            on = obs[min(e + 1, d.obs_pitch - 1)];
             BaLin L;
             ba_linearize(sRt + o.kf * 12, X, o.u, o.v, o.inv_sigma2, d.fx, d.fy, d.cx, d.cy, delta, L);
             const double ww = L.ww, e0 = L.e0, e1 = L.e1;
@@ -396,20 +399,28 @@ k_ba_kf(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw,
         double acc[27];
 #pragma unroll
         for (int i = 0; i < 27; i++) acc[i] = 0;
-        int ee[BA_KFCH / BA_T], pp[BA_KFCH / BA_T];
+        /* three rounds of independent loads (edge ids, observations, points), each round in flight together: a
+         * load-use-load chain per edge would be three memory latencies per edge */
+        int ee[BA_KFCH / BA_T];
+        tb_ba_obs oo[BA_KFCH / BA_T];
+        double XX[BA_KFCH / BA_T][3];
 #pragma unroll
         for (int j = 0; j < BA_KFCH / BA_T; j++) {
             const int idx = beg + chunk * BA_KFCH + j * BA_T + tid;
             ee[j] = (idx < end) ? I[d.oKfEdges + idx] : -1;
         }
 #pragma unroll
-        for (int j = 0; j < BA_KFCH / BA_T; j++) pp[j] = (ee[j] >= 0) ? obs[ee[j]].pt : 0;
+        for (int j = 0; j < BA_KFCH / BA_T; j++) oo[j] = obs[max(ee[j], 0)];
+#pragma unroll
+        for (int j = 0; j < BA_KFCH / BA_T; j++) {
+            const int p = min(max(oo[j].pt, 0), d.npt - 1);
+            XX[j][0] = P[3 * p]; XX[j][1] = P[3 * p + 1]; XX[j][2] = P[3 * p + 2];
+        }
 #pragma unroll
         for (int j = 0; j < BA_KFCH / BA_T; j++) {
             if (ee[j] < 0) continue;
-            const tb_ba_obs o = obs[ee[j]];
-            const int p = pp[j];
-            const double X[3] = {P[3 * p], P[3 * p + 1], P[3 * p + 2]};
+            const tb_ba_obs o = oo[j];
+            const double* X = XX[j];
             double Jp[12];
             BaLin L; /* residual and Huber weight exactly as the point pass computes them (same helper): cheaper than a
                         24-byte-per-edge round trip through HBM */
@@ -800,6 +811,7 @@ k_ba_update(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
         double r[3] = {D[d.oBl + (size_t)p * 3], D[d.oBl + (size_t)p * 3 + 1], D[d.oBl + (size_t)p * 3 + 2]};
         const double bl[3] = {r[0], r[1], r[2]};
         double xl[3] = {0, 0, 0};
+        const int eBeg = I[d.oPtStart + p], eEnd = I[d.oPtStart + p + 1];
         if (st.ok2) {
             /* the point record of this trial: A^-1 = U U^T (all zero for a singular block: xl stays 0) */
             const double* q = D + d.oHq + (size_t)p * 12;
@@ -807,8 +819,10 @@ k_ba_update(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
             /* r = bl - sum_k Hpl_k^T x_k with Hpl_k = ww Jp^T Jl rebuilt from the observation (a 144-byte block per edge
              * would cost more to fetch than its ~150 flops): Hpl^T x = ww Jl^T (Jp x) */
             const double Xc[3] = {P[3 * p], P[3 * p + 1], P[3 * p + 2]};
-            for (int e = I[d.oPtStart + p]; e < I[d.oPtStart + p + 1]; e++) {
-                const tb_ba_obs o = obs[e];
+            tb_ba_obs on = obs[min(eBeg, d.obs_pitch - 1)]; /* next observation in flight while this one is processed */
+            for (int e = eBeg; e < eEnd; e++) {
+                const tb_ba_obs o = on;
+                on = obs[min(e + 1, d.obs_pitch - 1)];
                 if (o.kf < d.nfixed) continue;
                 BaLin L;
                 double Jp[12];
@@ -832,8 +846,10 @@ k_ba_update(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
             Pn[3 * p + a] = X[a];
             sc += xl[a] * (st.lambda * xl[a] + bl[a]);
         }
-        for (int e = I[d.oPtStart + p]; e < I[d.oPtStart + p + 1]; e++) {
-            const tb_ba_obs o = obs[e];
+        tb_ba_obs on2 = obs[min(eBeg, d.obs_pitch - 1)];
+        for (int e = eBeg; e < eEnd; e++) {
+            const tb_ba_obs o = on2;
+            on2 = obs[min(e + 1, d.obs_pitch - 1)];
             BaLin L; /* the same residual arithmetic as the point pass: rho compares like with like */
             ba_residual(sRt + o.kf * 12, X, o.u, o.v, o.inv_sigma2, d.fx, d.fy, d.cx, d.cy, delta, L);
             chi += ba_huber_rho0(L.c2, delta);
