@@ -221,7 +221,7 @@ def main():
         kern_ms = {k: round(v[1] / args.steps, 4) for k, v in sorted(prof.items())}
         if name == "k_ba_schur":
             # one launch = one LM trial of one partition of the windows; both roofs are reported, `bound` is the
-            # nearer one (the kernel streams every Hpl block once per trial AND multiplies it on the FP64 matrix cores)
+            # nearer one (the kernel rebuilds every Hpl block from its 16-byte record AND multiplies it on the FP64 matrix cores)
             nwin = pipe.bas[0][0].W
             free_edges = sum(b.free_edges for b, _, _ in pipe.bas) / max(len(pipe.bas), 1)
             fl, nb = schur_roofs(args.ba_pts, nwin, args.ba_kf, free_edges)

@@ -26,7 +26,7 @@ class BatchedLocalBA:
             poses[w] = Pi.reshape(nkf, 16)
             pts[w] = Xi
         self.host = dict(obs=obs, counts=cnt, poses=poses, pts=pts)
-        # edges with a free keyframe carry an Hpl block (bench.py's roofline accounting)
+        # edges with a free keyframe enter the Schur complement (bench.py's roofline accounting)
         self.free_edges = int(sum(int((obs[w, :cnt[w]]["kf"] >= nfixed).sum()) for w in range(self.W)))
         self.edges = int(cnt.sum())
         dev = device

@@ -40,9 +40,8 @@
 struct BaState {
     double lambda, ni, currentChi, chi0, scale_p, rho;
     int iter, qmax, status, need_lin, cur, ok2, done_iters, err;
-    int sing, max_rows, hq_fresh, pad2; /* max_rows: most Hpl rows (6 per free-keyframe edge) any BA_CP-point Schur chunk has;
-                                          hq_fresh: the point pass of this trial already wrote the (inverse, bl) records;
-                                          sing: a point block was singular in this trial (solve fails, as in the CPU solver) */
+    int sing, pad0, hq_fresh, pad2; /* hq_fresh: the point pass of this trial already wrote the point records;
+                                       sing: a point block was not positive definite in this trial (solve fails, as in the CPU solver) */
 };
 
 struct BaDims {
@@ -63,7 +62,7 @@ __device__ __forceinline__ double ba_huber_rho0(double c, double delta) {
     return (c <= dsqr) ? c : 2 * sqrt(c) * delta - dsqr;
 }
 /* Linearisation of one observation at (Tk, X): Huber-weighted information ww, residual (e0, e1), the 2x3 point
- * Jacobian Jl and camera-frame point pc (for ba_jac_pose). ONE definition for every kernel that needs Hpl =
+ * Jacobian Jl and camera-frame point pc (for ba_jac_pose_iz). ONE definition for every kernel that needs Hpl =
  * ww Jp^T Jl: the blocks are never stored, the point pass, the Schur kernel and the back-substitution each rebuild
  * what they need from the 20-byte observation, and must agree bit for bit. */
 struct BaLin { double ww, e0, e1, c2, invz; double pc[3]; double Jl[6]; };
@@ -192,7 +191,7 @@ __device__ __forceinline__ int ba_ordered_rank(int n, int* tmp, Pred pred, Pred2
  * grid (nkf + 2, W): block k < nkf lists keyframe k's edges in ascending edge order (its base offset is
  * the count of edges with a smaller keyframe index, recounted per block so blocks stay independent);
  * block nkf initialises the LM state, checks the input, builds ptStart and converts poses / points;
- * block nkf + 1 numbers the free-keyframe edges compactly (Hpl rows, key list, ptFree). */
+ * block nkf + 1 numbers the free-keyframe edges compactly (16-byte edge records, ptFree). */
 __global__ void __launch_bounds__(BA_T)
 k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ pts, const tb_ba_obs* __restrict__ obsAll,
            const int32_t* __restrict__ obsCounts, double* __restrict__ dw, int* __restrict__ iw, BaState* __restrict__ states,
@@ -206,7 +205,7 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
     BaState* st = states + w;
     {   /* input check, a slice of the edges per block (errflag[w] was zeroed before the launch; k_ba_points turns it
          * into the window's status): indices in range, grouped by ascending point, and a point observed at most once
-         * per keyframe (the Schur tiles hold one Hpl block per (keyframe, point); within a sorted run the first
+         * per keyframe (the Schur tile holds one 6 x 3 block per (keyframe, point); within a sorted run the first
          * repeat lies at most nkf edges after its earlier occurrence). The look-back loads are issued eight at a time
          * without looking at them in between -- a compare-and-continue loop is one memory latency per step. */
         const int nb = gridDim.x, per = (nobs + nb - 1) / nb;
@@ -239,8 +238,8 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
         return;
     }
     if (k == d.nkf + 1) {
-        /* compact numbering of the free-keyframe edges (the only ones with an Hpl block): ce = rank among the free
-         * edges in edge order, so a point's / a chunk's free edges are contiguous in Hpl and in the key list
+        /* compact numbering of the free-keyframe edges (the only ones that enter the Schur complement): ce = rank among
+         * the free edges in edge order, so a point's / a chunk's free edges are contiguous in the record list
          * freeKP[ce] = {pt << 6 | free keyframe index, u, v, inv_sigma2}; ptFree[p] = first compact edge of point p */
         int unused = 0;
         const int nfreeE = ba_ordered_rank(nobs, tmp, [&](int e) { return obs[e].kf >= d.nfixed; }, [](int) { return false; }, &unused,
@@ -258,13 +257,6 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
             });
         for (int p = max((nobs > 0 ? obs[nobs - 1].pt : -1) + 1, 0) + tid; p <= d.npt; p += BA_T) I[d.oPtFree + p] = nfreeE;
         __syncthreads();
-        int mr = 0; /* most edge rows in a Schur chunk: picks how many the kernel keeps in registers per lane */
-        for (int c = tid; c < d.nChunks; c += BA_T)
-            mr = max(mr, (I[d.oPtFree + min(c * BA_CP + BA_CP, d.npt)] - I[d.oPtFree + c * BA_CP]) * 6);
-        mr = tb_wave_max_i(mr);
-        if ((tid & 63) == 0) tmp[tid >> 6] = mr;
-        __syncthreads();
-        if (tid == 0) st->max_rows = max(max(tmp[0], tmp[1]), max(tmp[2], tmp[3]));
         return;
     }
     if (tid == 0) {
