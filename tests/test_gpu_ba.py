@@ -50,8 +50,9 @@ def test_local_ba_vs_cpu_solver(ctx, seed, nkf, npt, nfixed, iters):
                                                          (12, 6, 300, 1, 6), (13, 4, 120, 1, 4), (14, 3, 90, 2, 3),
                                                          (15, 12, 150, 2, 12), (16, 10, 203, 0, 2)])
 def test_local_ba_chunk_capacities(ctx, seed, nkf, npt, nfixed, per_pt):
-    """The Schur kernel keeps 64 M Hpl rows per 4-point chunk in registers, M picked per window from its longest
-    chunk (M <= R = ceil(6 nfree / 16)): sparse to fully dense windows walk through every instance."""
+    """The Schur kernel maps one free-keyframe edge of a 4-point chunk to one lane (at most 4 nfree <= 40) and has one
+    tile set per R = ceil(6 nfree / 16): sparse to fully dense windows with 1..10 free keyframes walk through every
+    instance."""
     Pt, Pi, Xt, Xi, obs = synth.ba_problem(seed, nkf, npt, K, obs_per_pt=per_pt)
     io, Po, Xo, so = oracle.local_ba(K, Pi, nfixed, Xi, obs, 6)
     ig, Pg, Xg, sg = ctx.local_ba(K, Pi, nfixed, Xi, obs, 6)
