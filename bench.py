@@ -158,7 +158,7 @@ def main():
     def one_step():
         pipe.step()
         if world > 1:
-            tbd.gather_tracks(tbd.pipeline_records(pipe), dst=0)
+            tbd.gather_tracks(tbd.pipeline_records(pipe), dst=0, concat=False)
 
     def fence():
         if world > 1:

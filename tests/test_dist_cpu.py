@@ -37,8 +37,17 @@ def _worker(rank, world, port, q):
         ok = out["kps"].shape == (w * F, cap, 7) and torch.equal(out["kps"][F:], rec["kps"] + 1000) \
             and torch.equal(out["desc"][F:], rec["desc"] + 1) \
             and out["kp_counts"].tolist() == [0, 1, 2, 3, 4, 5] and out["pose"][F:].eq(1).all().item()
+        # steady-state form (what bench.py calls every step): per-rank parts in reused receive buffers
+        a = tbd.gather_tracks(rec, dst=0, concat=False)
+        first = a["kps"][1].data_ptr()
+        rec2 = {k: v + 1 for k, v in rec.items()}
+        b = tbd.gather_tracks(rec2, dst=0, concat=False)
+        ok = ok and len(b["kps"]) == w and b["kps"][1].data_ptr() == first and torch.equal(b["kps"][1], rec["kps"] + 1001) \
+            and torch.equal(b["desc"][0], rec2["desc"])
         q.put(bool(ok))
     else:
+        tbd.gather_tracks(rec, dst=0, concat=False)
+        tbd.gather_tracks({k: v + 1 for k, v in rec.items()}, dst=0, concat=False)
         q.put(out is None)
     torch.distributed.destroy_process_group()
 

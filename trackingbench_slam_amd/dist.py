@@ -35,13 +35,18 @@ def init_from_env(backend=None):
     return rank, world, local
 
 
-def gather_tracks(records, dst=0, group=None):
+_GATHER_BUFFERS = {}  # (name, shape, dtype, device, world) -> list of receive tensors, reused from batch to batch
+
+
+def gather_tracks(records, dst=0, group=None, concat=True):
     """Gather fixed-shape per-rank track tensors to `dst`.
 
     records: dict name -> tensor [F_local, ...] (same shape and dtype on every rank: rows are padded to the
     plan's keypoint capacity, the true lengths travel in the *_counts tensors).  Returns on `dst` a dict
     name -> tensor [world * F_local, ...] in rank order (= global frame order for contiguous shards), and
-    None elsewhere.  With one process it returns the records unchanged."""
+    None elsewhere.  With one process it returns the records unchanged.  concat=False returns the per-rank
+    parts instead (a list per name, receive buffers that the next call reuses): the steady-state form, one
+    exchange step per batch with no allocation and no extra copy on the receiving rank."""
     if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
         return dict(records)
     world = dist.get_world_size(group)
@@ -50,9 +55,13 @@ def gather_tracks(records, dst=0, group=None):
     for name in sorted(records):
         t = records[name].contiguous()
         if rank == dst:
-            parts = [torch.empty_like(t) for _ in range(world)]
+            key = (name, tuple(t.shape), t.dtype, str(t.device), world)
+            parts = _GATHER_BUFFERS.get(key)
+            if parts is None:
+                parts = [torch.empty_like(t) for _ in range(world)]
+                _GATHER_BUFFERS[key] = parts
             dist.gather(t, gather_list=parts, dst=dst, group=group)
-            out[name] = torch.cat(parts, 0)
+            out[name] = torch.cat(parts, 0) if concat else parts
         else:
             dist.gather(t, gather_list=None, dst=dst, group=group)
     return out
