@@ -155,12 +155,27 @@ def main():
                             ba_iters=args.ba_iters, seed=rank, ba_split=args.ba_split)
     pipe.set_synthetic(distinct=args.distinct, first=rank * args.frames)
 
+    state = {"sync_only": False}
+    pending = []  # exchange steps in flight: the pipeline alternates between two record sets, so at most two
+
     def one_step():
+        if len(pending) == 2:                     # the set this batch writes was sent two batches ago
+            tbd.wait_tracks(pending.pop(0))
         pipe.step()
         if world > 1:
+            if not state["sync_only"]:
+                try:
+                    _, handles = tbd.gather_tracks_async(tbd.pipeline_records(pipe), dst=0, slot=pipe._cur)
+                    pending.append(handles)
+                    return
+                except (RuntimeError, TypeError, ValueError) as e:  # a backend without background gathers
+                    print("warning: background track gather unavailable (%s); gathering in line" % e, file=sys.stderr)
+                    state["sync_only"] = True
             tbd.gather_tracks(tbd.pipeline_records(pipe), dst=0, concat=False)
 
     def fence():
+        while pending:
+            tbd.wait_tracks(pending.pop(0))
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()

@@ -44,10 +44,20 @@ def _worker(rank, world, port, q):
         b = tbd.gather_tracks(rec2, dst=0, concat=False)
         ok = ok and len(b["kps"]) == w and b["kps"][1].data_ptr() == first and torch.equal(b["kps"][1], rec["kps"] + 1001) \
             and torch.equal(b["desc"][0], rec2["desc"])
+        # background form: two exchanges in flight on alternating buffer sets, then waited for in order
+        o1, h1 = tbd.gather_tracks_async(rec, dst=0, slot=0)
+        o2, h2 = tbd.gather_tracks_async(rec2, dst=0, slot=1)
+        tbd.wait_tracks(h1); tbd.wait_tracks(h2)
+        ok = ok and torch.equal(o1["kps"][1], rec["kps"] + 1000) and torch.equal(o2["kps"][1], rec["kps"] + 1001) \
+            and torch.equal(o1["pose"][0], rec["pose"]) and o2["kp_counts"][1].tolist() == [4, 5, 6]
         q.put(bool(ok))
     else:
         tbd.gather_tracks(rec, dst=0, concat=False)
-        tbd.gather_tracks({k: v + 1 for k, v in rec.items()}, dst=0, concat=False)
+        rec2 = {k: v + 1 for k, v in rec.items()}
+        tbd.gather_tracks(rec2, dst=0, concat=False)
+        _, h1 = tbd.gather_tracks_async(rec, dst=0, slot=0)
+        _, h2 = tbd.gather_tracks_async(rec2, dst=0, slot=1)
+        tbd.wait_tracks(h1); tbd.wait_tracks(h2)
         q.put(out is None)
     torch.distributed.destroy_process_group()
 

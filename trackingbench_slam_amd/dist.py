@@ -67,6 +67,38 @@ def gather_tracks(records, dst=0, group=None, concat=True):
     return out
 
 
+def gather_tracks_async(records, dst=0, group=None, slot=0):
+    """The exchange step as a background operation: like gather_tracks(..., concat=False), but returns
+    (parts or None, handles) at once; call wait_tracks(handles) before the record tensors are written again (RCCL runs
+    the collective on its own stream after the work already queued on the current one; wait() orders the current
+    stream behind it, it does not block the host). `slot` picks the receive-buffer set on `dst`: alternate it when two
+    exchanges are in flight."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return dict(records), []
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    out = {} if rank == dst else None
+    handles = []
+    for name in sorted(records):
+        t = records[name].contiguous()
+        if rank == dst:
+            key = (name, tuple(t.shape), t.dtype, str(t.device), world, slot)
+            parts = _GATHER_BUFFERS.get(key)
+            if parts is None:
+                parts = [torch.empty_like(t) for _ in range(world)]
+                _GATHER_BUFFERS[key] = parts
+            handles.append(dist.gather(t, gather_list=parts, dst=dst, group=group, async_op=True))
+            out[name] = parts
+        else:
+            handles.append(dist.gather(t, gather_list=None, dst=dst, group=group, async_op=True))
+    return out, handles
+
+
+def wait_tracks(handles):
+    for h in handles:
+        h.wait()
+
+
 def pipeline_records(p):
     """The track records of a TrackingPipeline batch as a dict of device tensors."""
     return {

@@ -33,9 +33,17 @@ class TrackingPipeline:
         self.kps_ptr, self.desc_ptr, self.counts_ptr, self.kp_cap = self.ex.results_dev()
         F, cap = self.F, self.kp_cap
         self.images = None
-        # matcher outputs
-        self.matches = torch.zeros((F, cap, 4), dtype=torch.int32, device=self.dev)  # tb_match records
-        self.match_counts = torch.zeros(F, dtype=torch.int32, device=self.dev)
+        # Track records (what a batch hands on: keypoints, descriptors, matches, poses) exist twice: step() alternates
+        # between the sets, so the exchange step of one batch (dist.gather_tracks_async) can still read its set while
+        # the next batch is being computed into the other one.
+        self._sets = [dict(matches=torch.zeros((F, cap, 4), dtype=torch.int32, device=self.dev),  # tb_match records
+                           match_counts=torch.zeros(F, dtype=torch.int32, device=self.dev),
+                           Tout=torch.zeros((F, 16), dtype=torch.float32, device=self.dev),
+                           n_inliers=torch.zeros(F, dtype=torch.int32, device=self.dev),
+                           trk_kps=torch.zeros((F, cap, 7), dtype=torch.float32, device=self.dev),
+                           trk_desc=torch.zeros((F, cap, 32), dtype=torch.uint8, device=self.dev),
+                           trk_counts=torch.zeros(F, dtype=torch.int32, device=self.dev)) for _ in range(2)]
+        self._cur = 0
         # pose-opt inputs: one seeded synthetic problem per frame, the first #matches rows are used
         self.K = np.ascontiguousarray(KITTI_K, np.float64)
         self.obs_pitch = cap
@@ -47,14 +55,8 @@ class TrackingPipeline:
             Tin[f] = Ti.reshape(16)
         self.obs = torch.from_numpy(obs.view(np.float32).reshape(F, cap, 6)).to(self.dev)
         self.Tin = torch.from_numpy(Tin).to(self.dev)
-        self.Tout = torch.zeros((F, 16), dtype=torch.float32, device=self.dev)
         self.outlier = torch.zeros((F, cap), dtype=torch.uint8, device=self.dev)
-        self.n_inliers = torch.zeros(F, dtype=torch.int32, device=self.dev)
         self.pose_stats = torch.zeros((F, 8), dtype=torch.float64, device=self.dev)
-        # left-image keypoints / descriptors copied out for the track records
-        self.trk_kps = torch.zeros((F, cap, 7), dtype=torch.float32, device=self.dev)
-        self.trk_desc = torch.zeros((F, cap, 32), dtype=torch.uint8, device=self.dev)
-        self.trk_counts = torch.zeros(F, dtype=torch.int32, device=self.dev)
         # Local BA runs on its own HIP stream and context: its LM rounds are a chain of small, latency-bound
         # kernels (64-block solves, one-block decisions) that leave most CUs idle, while the extractor kernels
         # are throughput bound -- the two overlap on the chip instead of queueing behind each other.
@@ -74,6 +76,15 @@ class TrackingPipeline:
             # each partition's driver blocks on its own stream once per call (LM termination is data dependent):
             # one host thread per partition keeps the partitions' kernel chains in flight together
             self._pool = ThreadPoolExecutor(max_workers=nsplit)
+
+    # the record set the last (or running) step writes
+    matches = property(lambda self: self._sets[self._cur]["matches"])
+    match_counts = property(lambda self: self._sets[self._cur]["match_counts"])
+    Tout = property(lambda self: self._sets[self._cur]["Tout"])
+    n_inliers = property(lambda self: self._sets[self._cur]["n_inliers"])
+    trk_kps = property(lambda self: self._sets[self._cur]["trk_kps"])
+    trk_desc = property(lambda self: self._sets[self._cur]["trk_desc"])
+    trk_counts = property(lambda self: self._sets[self._cur]["trk_counts"])
 
     def close(self):
         torch.cuda.synchronize(self.dev)
@@ -122,6 +133,7 @@ class TrackingPipeline:
     def step(self):
         F, ex, ctx, L = self.F, self.ex, self.ctx, capi.lib()
         main = torch.cuda.current_stream(self.dev)
+        self._cur ^= 1                           # this batch's records go to the other set
         futures = []
         for ba, st, _ in self.bas:
             # the BA windows run beside the extractor chain on their own streams (and host threads)
