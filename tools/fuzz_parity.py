@@ -1,0 +1,103 @@
+#!/usr/bin/env python3
+"""Randomised parity sweep on the GPU box: every operator of the C ABI against the oracle on seeded random
+geometries, time bounded.  Not part of the test suite (minutes, not seconds); prints the first mismatch and exits 1.
+
+    python tools/fuzz_parity.py [--seconds 240] [--seed 1]"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np  # noqa: E402
+import oracle  # noqa: E402
+from trackingbench_slam_amd import capi, synth  # noqa: E402
+
+K = (718.856, 718.856, 607.1928, 185.2157)
+
+
+def same_rec(a, b):
+    return len(a) == len(b) and all(np.array_equal(a[f], b[f]) for f in a.dtype.names)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seconds", type=float, default=240.0)
+    ap.add_argument("--seed", type=int, default=1)
+    args = ap.parse_args()
+    rng = np.random.default_rng(args.seed)
+    ctx = capi.Context(0)
+    t0, it, counts = time.time(), 0, {}
+
+    def fail(what, **info):
+        print("MISMATCH in %s: %s" % (what, info))
+        sys.exit(1)
+
+    while time.time() - t0 < args.seconds:
+        it += 1
+        w, h = int(rng.integers(70, 900)), int(rng.integers(70, 700))
+        nl, sc = int(rng.integers(2, 9)), float(rng.choice([0.5, 0.6, 0.7, 0.75, 0.8, 0.85, 0.9]))
+        while nl > 2 and min(w, h) * sc ** (nl - 1) < 40:  # keep every level large enough for one 30-px cell + border
+            nl -= 1
+        img = synth.frame(int(rng.integers(0, 10 ** 6)), w, h)
+        lv, sf = ctx.pyramid(img, nl, sc)
+        olv, osf = oracle.pyramid(img, nl, sc)
+        if not all(np.array_equal(a, b) for a, b in zip(lv, olv)):
+            fail("pyramid", w=w, h=h, nl=nl, sc=sc)
+        tgt, ith, mth = int(rng.integers(20, 2500)), int(rng.integers(15, 90)), int(rng.integers(5, 30))
+        mth = min(mth, ith)
+        k1, d1, _ = ctx.orb_extract(lv, sf, tgt, ith, mth)
+        ko, do, _ = oracle.orb_extract(olv, sf, tgt, ith, mth)
+        if not (np.array_equal(k1, ko) and np.array_equal(d1, do)):
+            fail("orb_extract", w=w, h=h, nl=nl, sc=sc, tgt=tgt, ith=ith, mth=mth, n=(len(k1), len(ko)))
+        th = int(rng.integers(5, 60))
+        c1 = ctx.fast_detect(img, th)
+        c2 = oracle.fast9(img, th)
+        if not same_rec(c1, c2):
+            fail("fast_detect", w=w, h=h, th=th)
+        img2 = synth.frame(int(rng.integers(0, 10 ** 6)), w, h)
+        lv2, _ = ctx.pyramid(img2, nl, sc)
+        k2, d2, _ = ctx.orb_extract(lv2, sf, tgt, ith, mth)
+        if len(k1) and len(k2):
+            ratio, mt = float(rng.uniform(1.5, 12)), float(rng.uniform(20, 90))
+            if not same_rec(ctx.search_by_bf(d1, d2, ratio, mt), oracle.search_by_bf(d1, d2, ratio, mt)):
+                fail("search_by_bf", n1=len(k1), n2=len(k2), ratio=ratio, mt=mt)
+            r, tl, nr = float(rng.uniform(3, 60)), int(rng.integers(30, 120)), float(rng.uniform(0.5, 1.0))
+            a = (k1, d1, k2, d2, w, h, 0, nl, r, tl, nr, 30, bool(rng.integers(0, 2)))
+            if not same_rec(ctx.search_by_violence(*a), oracle.search_by_violence(*a)):
+                fail("search_by_violence", w=w, h=h, r=r, tl=tl, nr=nr)
+        c = synth.projection_case(int(rng.integers(0, 10 ** 6)), n1=int(rng.integers(50, 2500)), nmp=int(rng.integers(50, 2500)))
+        nrat = float(rng.uniform(1, 15))
+        pa = (c["Tcw"], c["cam"], c["width"], c["height"], c["k1"], c["d1"], c["taken1"], c["k2"], c["mp"], c["mp_desc"], c["sf"], nrat)
+        if not same_rec(ctx.search_by_projection(*pa), oracle.search_by_projection(*pa)):
+            fail("search_by_projection", nrat=nrat)
+        pm = (c["Tcw"], c["cam"], c["width"], c["height"], c["k1"], c["d1"], c["taken1"], c["mp"], c["mp_desc"], c["sf"], nrat, 0.8)
+        if not same_rec(ctx.search_by_projection_map(*pm), oracle.search_by_projection_map(*pm)):
+            fail("search_by_projection_map", nrat=nrat)
+        n = int(rng.integers(10, 1500))
+        _, Ti, obs = synth.pose_problem(int(rng.integers(0, 10 ** 6)), n, K)
+        ng, Tg, og, _ = ctx.pose_opt(K, Ti, obs)
+        no, To, oo, _ = oracle.pose_opt(K, Ti, obs)
+        if not (ng == no and np.array_equal(og, oo) and np.allclose(Tg, To, rtol=1e-6, atol=1e-6)):
+            fail("pose_opt", n=n, inl=(ng, no), dT=float(np.abs(Tg - To).max()))
+        nkf, nfx = int(rng.integers(3, 13)), int(rng.integers(0, 3))
+        nfx = min(nfx, nkf - 1)
+        if nkf - nfx <= 10:
+            npt, per = int(rng.integers(20, 1500)), int(rng.integers(2, nkf + 1))
+            Pt, Pi, Xt, Xi, bo = synth.ba_problem(int(rng.integers(0, 10 ** 6)), nkf, npt, K, obs_per_pt=per)
+            itn = int(rng.integers(1, 8))
+            ig, Pg, Xg, sg = ctx.local_ba(K, Pi, nfx, Xi, bo, itn)
+            io, Po, Xo, so = oracle.local_ba(K, Pi, nfx, Xi, bo, itn)
+            tol = 1e-6
+            if not (np.allclose(Pg, Po, rtol=tol, atol=tol * max(1.0, float(np.abs(Po).max()))) and
+                    np.allclose(Xg, Xo, rtol=tol, atol=tol * max(1.0, float(np.abs(Xo).max()))) and np.isclose(sg[2], so[2], rtol=1e-6, atol=1e-9)):
+                fail("local_ba", nkf=nkf, nfx=nfx, npt=npt, per=per, itn=itn, dP=float(np.abs(Pg - Po).max()), dX=float(np.abs(Xg - Xo).max()),
+                     chi=(float(sg[2]), float(so[2])))
+        if it % 10 == 0:
+            print("iteration %d, %.0f s" % (it, time.time() - t0), flush=True)
+    print("fuzz ok: %d iterations in %.0f s" % (it, time.time() - t0))
+    ctx.close()
+
+
+if __name__ == "__main__":
+    main()
