@@ -311,8 +311,20 @@ k_fast_cells(PlanGeom g, const uint8_t* __restrict__ slab, const CellDesc* __res
      *   X < V - t  <=>  bit 9 of  (V + 511 - t) - X        (value in [1, 766]: no borrow)
      * A 9-arc holds two adjacent cardinals, i.e. one of {0, 8} and one of {4, 12}. */
     const int sw = rw - 6, sh = rh - 6;
-    const int thA = min(init_th, min_th);
-    int nlist = 0;
+    /* The cell is tried at init_th first, as the reference does (ORBextractor.cpp:785-797): only where that leaves no
+     * corner after NMS is it redone at min_th. NMS does not depend on the threshold (a neighbour below the threshold
+     * scores below any corner at it), so the first pass is exact -- and on textured frames it sends a quarter of the
+     * pixels into the score stage that a single pass at min_th would (2.6 % of the pixels are corners at 80, 10 % at 30). */
+    int thA = init_th;
+    int nlist = 0, ncorner = 0;
+    auto nms_keep = [&](int idx) -> bool {
+        const int s = sc[idx];
+        return s > 0 && s > sc[idx - 1] && s > sc[idx + 1] && s > sc[idx - S - 1] && s > sc[idx - S] && s > sc[idx - S + 1] &&
+               s > sc[idx + S - 1] && s > sc[idx + S] && s > sc[idx + S + 1];
+    };
+    for (int pass = 0; pass < 2; pass++) {
+    nlist = 0;
+    ncorner = 0;
     if (sw > 0 && sh > 0) {
         const int cA = cx0 + 3, cB = cx0 + rw - 3;   /* scanned LDS columns [cA, cB) */
         const int gA = cA >> 2, ng = ((cB - 1) >> 2) - gA + 1;
@@ -367,7 +379,6 @@ k_fast_cells(PlanGeom g, const uint8_t* __restrict__ slab, const CellDesc* __res
      * score = max over the 16 arcs of min(d) and of min(-d), minus 1, with d = centre - ring; the min over a
      * 9-arc is a doubling network (2, 4, 8, 8+1), every step one v_pk_min_i16 / v_pk_max_i16 for both pixels.
      * A survivor is a corner at thA iff score >= thA; corners are compacted in place. */
-    int ncorner = 0;
     for (int base = 0; base < nlist; base += 128) {
         const int iA = base + lane, iB = base + 64 + lane;
         const bool vA = iA < nlist, vB = iB < nlist;
@@ -408,23 +419,27 @@ k_fast_cells(PlanGeom g, const uint8_t* __restrict__ slab, const CellDesc* __res
         ft_lds_fence();
     }
 
-    /* ---- stage 4: NMS, threshold choice, emit */
-    bool any_hi = false;
+    /* ---- stage 4: NMS; does this pass leave a corner? (list[] holds the corners at thA, sc[] their scores, 0 elsewhere) */
+    bool any = false;
     for (int base = 0; base < ncorner; base += 64) {
         const int i = base + lane;
-        bool hit = false;
-        if (i < ncorner) {
-            const int idx = list[i];
-            const int s = sc[idx];
-            const bool keep = s > 0 && s > sc[idx - 1] && s > sc[idx + 1] && s > sc[idx - S - 1] && s > sc[idx - S] &&
-                              s > sc[idx - S + 1] && s > sc[idx + S - 1] && s > sc[idx + S] && s > sc[idx + S + 1];
-            if (!keep) list[i] = 0xffff;
-            else hit = s >= init_th;
-        }
-        any_hi = any_hi || (__ballot(hit) != 0);
+        const bool keep = (i < ncorner) && nms_keep(list[i]);
+        any = any || (__ballot(keep) != 0);
+    }
+    if (any || pass == 1 || min_th >= init_th) break;
+    /* nothing at init_th: forget this pass's scores (corners that lost the NMS) and redo the cell at min_th */
+    for (int base = 0; base < ncorner; base += 64) {
+        const int i = base + lane;
+        if (i < ncorner) sc[list[i]] = 0;
     }
     ft_lds_fence();
-    const int th = any_hi ? init_th : min_th;
+    thA = min_th;
+    }
+    for (int base = 0; base < ncorner; base += 64) { /* drop the corners that lose the NMS */
+        const int i = base + lane;
+        if (i < ncorner && !nms_keep(list[i])) list[i] = 0xffff; /* only the scores are read across lanes */
+    }
+    ft_lds_fence();
     uint32_t* out = cand + (size_t)b * g.candPerImage + L.candOff;
     int* count = candCount + b * TB_MAX_LEVELS + c.level;
     /* ONE returning atomic per cell (a returning atomic per 64-lane pass cost 30-50 % of this kernel: every
@@ -435,9 +450,7 @@ k_fast_cells(PlanGeom g, const uint8_t* __restrict__ slab, const CellDesc* __res
         const int i = base + lane;
         bool e = false;
         if (i < ncorner) {
-            const int idx = list[i];
-            e = idx != 0xffff && sc[idx] >= th;
-            if (!e) list[i] = 0xffff;
+            e = list[i] != 0xffff;
         }
         total += __popcll(__ballot(e));
     }
