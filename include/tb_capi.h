@@ -168,6 +168,17 @@ int tb_search_by_projection_batch_dev(tb_ctx* ctx, int npairs, const float* Tcw1
                                       int th_high, int histo_len, int check_orientation, tb_match* out, int cap,
                                       int32_t* out_counts, int32_t* flags);
 
+/* Batched, device-resident Matcher::searchByProjection(map, F1, radio) (matcher.cpp:539-617): pair p = one current
+ * frame (pose, keys, descriptors, taken flags, lookup grid as above) against a map of nmp[p] points at
+ * mps + p*mp_pitch, mp_desc + p*mp_pitch*32; mp_pitch = 0 matches every frame against ONE shared map. max_nmp bounds
+ * nmp[]. Matches (queryIdx = F1 key, trainIdx = map point index) to out + p*cap in map order, counts to
+ * out_counts[p] (truncated list, untruncated count). Device pointers, asynchronous. */
+int tb_search_by_projection_map_batch_dev(tb_ctx* ctx, int npairs, const float* Tcw1, const tb_camera* cam1, int img1_width,
+                                          int img1_height, const tb_keypoint* k1, const uint8_t* d1, const uint8_t* taken1,
+                                          const int32_t* n1, int pitch1, const int32_t* cell_start, const int32_t* cell_items,
+                                          const tb_mappoint* mps, const uint8_t* mp_desc, const int32_t* nmp, int mp_pitch,
+                                          int max_nmp, const float* scale_factors, int nlevels, float nratio, float radio,
+                                          int th_high, tb_match* out, int cap, int32_t* out_counts, int32_t* flags);
 /* Batched, device-resident Matcher::searchByViolence (matcher.cpp:299-395): pair p matches F1's keys (k1 / d1 at stride
  * pitch1, n1[p] valid) against F2's (stride pitch2, n2[p] valid) through F2's lookup grid from
  * tb_frame_grid_batch_dev (built over k2 with img2_*). Matches (queryIdx = F1 key, trainIdx = F2 key) go to

@@ -185,3 +185,64 @@ def test_violence_batch_device_resident(ctx):
             _same(out[p, :n].cpu().numpy().view(capi.MATCH).reshape(-1), mo)
             _same(ctx.search_by_violence(a, b, c, d, W, H, 0, 5, rad, 60, ratio, 30, check), mo)
         assert int(oc.sum().item()) > 500
+
+
+def test_projection_map_batch_device_resident(ctx):
+    """searchByProjection(map, F1, radio) for a batch of current frames on device-built grids: one shared map
+    (mp_pitch = 0) and one map per frame; each frame equals the oracle."""
+    import ctypes as C
+    import torch
+    dev = torch.device("cuda", 0)
+    base = synth.projection_case(40, n1=2000, nmp=4000)
+    base["k1"]["octave"][::2] = 0
+    frames = []
+    for i in range(4):                       # the same keys seen from slightly different poses
+        T = base["Tcw"].copy()
+        T[0, 3] += 0.02 * i; T[2, 3] -= 0.03 * i
+        frames.append(T)
+    P, n1 = len(frames), len(base["k1"])
+    W, H = base["width"], base["height"]
+    up = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.uint8).reshape(-1)).to(dev)
+    vp = lambda t: C.c_void_p(t.data_ptr())
+    tk1 = up(np.tile(base["k1"], P)); td1 = up(np.tile(base["d1"], (P, 1))); ttk = up(np.tile(base["taken1"], P))
+    tn1 = torch.full((P,), n1, dtype=torch.int32, device=dev)
+    tT = torch.from_numpy(np.stack(frames).reshape(P, 16)).to(dev)
+    cs = torch.zeros((P, 120 * 36 + 1), dtype=torch.int32, device=dev); ci = torch.zeros((P, n1), dtype=torch.int32, device=dev)
+    L = capi.lib()
+    ctx.check(L.tb_frame_grid_batch_dev(ctx._h, P, vp(tk1), vp(tn1), n1, W, H, vp(cs), vp(ci)))
+    cam = np.ascontiguousarray(base["cam"], capi.CAMERA); sf = np.ascontiguousarray(base["sf"], np.float32)
+    nmp = len(base["mp"])
+    out = torch.zeros((P, nmp, 4), dtype=torch.int32, device=dev); oc = torch.zeros(P, dtype=torch.int32, device=dev)
+    fl = torch.zeros(P, dtype=torch.int32, device=dev)
+    # (a) one shared map
+    tmp, tmd = up(base["mp"]), up(base["mp_desc"])
+    tnm = torch.full((P,), nmp, dtype=torch.int32, device=dev)
+    ctx.check(L.tb_search_by_projection_map_batch_dev(ctx._h, P, vp(tT), cam.ctypes.data_as(C.c_void_p), W, H, vp(tk1), vp(td1), vp(ttk),
+                                                      vp(tn1), n1, vp(cs), vp(ci), vp(tmp), vp(tmd), vp(tnm), 0, nmp,
+                                                      sf.ctypes.data_as(C.c_void_p), len(sf), C.c_float(3.0), C.c_float(0.8), 100,
+                                                      vp(out), nmp, vp(oc), vp(fl)))
+    torch.cuda.synchronize()
+    total = 0
+    for p in range(P):
+        mo = oracle.search_by_projection_map(frames[p], base["cam"], W, H, base["k1"], base["d1"], base["taken1"], base["mp"],
+                                             base["mp_desc"], base["sf"], 3.0, 0.8)
+        n = int(oc[p].item()); total += n
+        _same(out[p, :n].cpu().numpy().view(capi.MATCH).reshape(-1), mo)
+    assert total > 100
+    # (b) a map per frame, different sizes
+    sizes = [4000, 1000, 17, 2500]
+    mps = np.zeros((P, nmp), capi.MAPPOINT); mds = np.zeros((P, nmp, 32), np.uint8)
+    for p, m in enumerate(sizes):
+        mps[p, :m] = base["mp"][p:p + m] if p + m <= nmp else base["mp"][:m]; mds[p, :m] = base["mp_desc"][p:p + m] if p + m <= nmp else base["mp_desc"][:m]
+    tmp2, tmd2 = up(mps), up(mds)
+    tnm2 = torch.tensor(sizes, dtype=torch.int32, device=dev)
+    ctx.check(L.tb_search_by_projection_map_batch_dev(ctx._h, P, vp(tT), cam.ctypes.data_as(C.c_void_p), W, H, vp(tk1), vp(td1), vp(ttk),
+                                                      vp(tn1), n1, vp(cs), vp(ci), vp(tmp2), vp(tmd2), vp(tnm2), nmp, nmp,
+                                                      sf.ctypes.data_as(C.c_void_p), len(sf), C.c_float(1.0), C.c_float(0.6), 100,
+                                                      vp(out), nmp, vp(oc), vp(fl)))
+    torch.cuda.synchronize()
+    for p, m in enumerate(sizes):
+        mo = oracle.search_by_projection_map(frames[p], base["cam"], W, H, base["k1"], base["d1"], base["taken1"], mps[p, :m], mds[p, :m],
+                                             base["sf"], 1.0, 0.6)
+        n = int(oc[p].item())
+        _same(out[p, :n].cpu().numpy().view(capi.MATCH).reshape(-1), mo)

@@ -37,7 +37,8 @@ EXPORTS = [
     "tb_pyramid", "tb_fast_detect", "tb_orb_extract", "tb_fastgrid_extract",
     "tb_descriptor_distance", "tb_three_maxima", "tb_match_bf", "tb_search_by_bf", "tb_search_by_bf_batch_dev",
     "tb_search_by_violence", "tb_search_by_projection", "tb_search_by_projection_map", "tb_frame_grid_batch_dev",
-    "tb_search_by_projection_batch_dev", "tb_search_by_violence_batch_dev", "tb_pose_opt", "tb_pose_opt_batch_dev", "tb_local_ba", "tb_local_ba_batch_dev",
+    "tb_search_by_projection_batch_dev", "tb_search_by_projection_map_batch_dev",
+    "tb_search_by_violence_batch_dev", "tb_pose_opt", "tb_pose_opt_batch_dev", "tb_local_ba", "tb_local_ba_batch_dev",
 ]
 
 

@@ -424,8 +424,10 @@ struct ProjBatch {
     const int32_t* cellStart; const int32_t* cellItems;
     const tb_keypoint* k2; const tb_mappoint* mp2; const uint8_t* mp2d; const int32_t* n2; int pitch2;
     float sf[TB_MAX_LEVELS * 2]; int nlevels;
-    float nratio, widthInv, heightInv;
+    float nratio, widthInv, heightInv, radio;
     int th_high, histo_len, check_orientation;
+    int max_n2;   /* rows of `best` per pair = most map points any pair has; pitch2 may be 0 (one map shared by all pairs) */
+    int map_mode; /* 0: searchByProjection(F1, F2); 1: searchByProjection(map, F1, radio) -- mp2 / mp2d are the map, k2 unused */
     int32_t* best;                   /* [npairs][pitch2][6] */
     tb_match* out; int cap; int32_t* out_counts; int32_t* flags; /* flags[p]: 1 = octave outside the table, 2 = bin outside the histogram */
 };
@@ -434,7 +436,7 @@ struct ProjBatch {
 __global__ void __launch_bounds__(256)
 k_proj_search_batch(ProjBatch B) {
     const int p = blockIdx.y, i2 = blockIdx.x * blockDim.x + threadIdx.x;
-    const int n2 = min(B.n2[p], B.pitch2);
+    const int n2 = min(B.n2[p], B.max_n2);
     if (i2 >= n2) return;
     ProjPose P;
 #pragma unroll
@@ -444,7 +446,7 @@ k_proj_search_batch(ProjBatch B) {
     bool search = false;
     float x = 0, y = 0, r = 0;
     int minL = 0, maxL = 0;
-    if (!mp.bad) {
+    if (!mp.bad && !B.map_mode) {
         float Pc[3], uv[2];
         pj_se3_map(P, mp.pos, Pc);
         const float invzc = 1.0f / Pc[2];
@@ -454,6 +456,30 @@ k_proj_search_batch(ProjBatch B) {
                 const int oct = B.k2[(size_t)p * B.pitch2 + i2].octave;
                 if (oct < 0 || oct >= B.nlevels) B.flags[p] = 1; /* benign race */
                 else { x = uv[0]; y = uv[1]; r = B.nratio * B.sf[oct]; minL = oct - 1; maxL = oct + 1; search = true; }
+            }
+        }
+    } else if (!mp.bad) { /* Frame::IsInFrustum (Frame.cpp:370-412) + the window of matcher.cpp:558-567, as k_project_map */
+        float Pc[3], uv[2], Ow[3];
+#pragma unroll
+        for (int i = 0; i < 3; i++) {
+            const float c0 = -P.T[i] * P.T[3], c1 = -P.T[4 + i] * P.T[7], c2 = -P.T[8 + i] * P.T[11];
+            Ow[i] = c0 + (c1 + c2);
+        }
+        pj_se3_map(P, mp.pos, Pc);
+        if (!(Pc[2] < 0.0f)) {
+            pj_world2cam(B.cam, Pc, uv);
+            if (pj_in_frame(B.cam, uv)) {
+                const float PO[3] = {mp.pos[0] - Ow[0], mp.pos[1] - Ow[1], mp.pos[2] - Ow[2]};
+                const float dist3 = sqrtf(PO[0] * PO[0] + (PO[1] * PO[1] + PO[2] * PO[2]));
+                if (!(dist3 < mp.min_dist || dist3 > mp.max_dist)) {
+                    const float viewCos = (PO[0] * mp.normal[0] + (PO[1] * mp.normal[1] + PO[2] * mp.normal[2])) / dist3;
+                    if (!(viewCos < 0.5f)) {
+                        float rr = 4.f;
+                        if ((double)viewCos > 0.998) rr = 2.5f;
+                        if ((double)B.nratio != 1.0) rr *= B.nratio;
+                        x = uv[0]; y = uv[1]; r = rr * B.sf[0]; minL = -1; maxL = 0; search = true;
+                    }
+                }
             }
         }
     }
@@ -496,7 +522,7 @@ k_proj_search_batch(ProjBatch B) {
                 }
         }
     }
-    int32_t* o = B.best + ((size_t)p * B.pitch2 + i2) * 6;
+    int32_t* o = B.best + ((size_t)p * B.max_n2 + i2) * 6;
     o[0] = bestDist; o[1] = bestDist2; o[2] = bestIdx; o[3] = bestLevel; o[4] = bestLevel2; o[5] = ncand;
 }
 
@@ -511,8 +537,8 @@ k_proj_accept_batch(ProjBatch B) {
     __shared__ int keep[3];
     __shared__ int srun;
     const int p = blockIdx.x, tid = threadIdx.x;
-    const int n2 = min(B.n2[p], B.pitch2);
-    const int32_t* best = B.best + (size_t)p * B.pitch2 * 6;
+    const int n2 = min(B.n2[p], B.max_n2);
+    const int32_t* best = B.best + (size_t)p * B.max_n2 * 6;
     const tb_keypoint* k1 = B.k1 + (size_t)p * B.pitch1;
     const tb_keypoint* k2 = B.k2 + (size_t)p * B.pitch2;
     tb_match* out = B.out + (size_t)p * B.cap;
@@ -521,6 +547,8 @@ k_proj_accept_batch(ProjBatch B) {
         if (i2 >= n2) return false;
         const int bd = best[6 * (size_t)i2], bi = best[6 * (size_t)i2 + 2];
         if (best[6 * (size_t)i2 + 5] == 0 || bi < 0 || bd > B.th_high) return false;
+        if (B.map_mode && best[6 * (size_t)i2 + 3] == best[6 * (size_t)i2 + 4] &&
+            (float)bd > B.radio * (float)best[6 * (size_t)i2 + 1]) return false; /* matcher.cpp:608-609 */
         bin = 0;
         if (B.check_orientation) {
             float rot = k2[i2].angle - k1[bi].angle;
@@ -596,9 +624,10 @@ int tbk_projection_batch(tb_ctx* ctx, int npairs, const float* d_Tcw, const tb_c
                          const int32_t* d_cellStart, const int32_t* d_cellItems, const tb_keypoint* d_k2, const tb_mappoint* d_mp2,
                          const uint8_t* d_mp2d, const int32_t* d_n2, int pitch2, const float* sf, int nlevels, float nratio,
                          int th_high, int histo_len, int check_orientation, int32_t* d_best, tb_match* d_out, int cap,
-                         int32_t* d_out_counts, int32_t* d_flags) {
-    if (npairs <= 0 || pitch2 <= 0) return TB_OK;
+                         int32_t* d_out_counts, int32_t* d_flags, int map_mode, float radio, int max_n2) {
+    if (npairs <= 0 || max_n2 <= 0) return TB_OK;
     ProjBatch B;
+    B.map_mode = map_mode; B.radio = radio; B.max_n2 = max_n2;
     B.Tcw = d_Tcw; B.cam = *cam;
     B.k1 = d_k1; B.d1 = d_d1; B.taken1 = d_taken1; B.n1 = d_n1; B.pitch1 = pitch1;
     B.cellStart = d_cellStart; B.cellItems = d_cellItems;
@@ -610,7 +639,7 @@ int tbk_projection_batch(tb_ctx* ctx, int npairs, const float* d_Tcw, const tb_c
     B.best = d_best; B.out = d_out; B.cap = cap; B.out_counts = d_out_counts; B.flags = d_flags;
     TB_HIP(ctx, hipMemsetAsync(d_flags, 0, (size_t)npairs * sizeof(int32_t), ctx->stream));
     tb_prof_begin(ctx, "k_proj_search");
-    hipLaunchKernelGGL(k_proj_search_batch, dim3((pitch2 + 255) / 256, npairs), dim3(256), 0, ctx->stream, B);
+    hipLaunchKernelGGL(k_proj_search_batch, dim3((max_n2 + 255) / 256, npairs), dim3(256), 0, ctx->stream, B);
     tb_prof_end(ctx);
     TB_HIP(ctx, hipGetLastError());
     tb_prof_begin(ctx, "k_proj_accept");

@@ -1093,7 +1093,27 @@ int tb_search_by_projection_batch_dev(tb_ctx* ctx, int npairs, const float* Tcw1
     if (rc) return rc;
     return tbk_projection_batch(ctx, npairs, Tcw1, cam1, img1_width, img1_height, k1, d1, taken1, n1, pitch1, cell_start, cell_items, k2, mp2,
                                 mp2_desc, n2, pitch2, scale_factors, nlevels, nratio, th_high, histo_len, check_orientation,
-                                (int32_t*)dbest, out, cap, out_counts, flags);
+                                (int32_t*)dbest, out, cap, out_counts, flags, 0, 0.f, pitch2);
+}
+
+int tb_search_by_projection_map_batch_dev(tb_ctx* ctx, int npairs, const float* Tcw1, const tb_camera* cam1, int img1_width,
+                                          int img1_height, const tb_keypoint* k1, const uint8_t* d1, const uint8_t* taken1,
+                                          const int32_t* n1, int pitch1, const int32_t* cell_start, const int32_t* cell_items,
+                                          const tb_mappoint* mps, const uint8_t* mp_desc, const int32_t* nmp, int mp_pitch,
+                                          int max_nmp, const float* scale_factors, int nlevels, float nratio, float radio,
+                                          int th_high, tb_match* out, int cap, int32_t* out_counts, int32_t* flags) {
+    if (!ctx || npairs < 0 || !cam1 || !scale_factors || nlevels < 1 || nlevels > TB_MAX_LEVELS * 2 || pitch1 < 1 || mp_pitch < 0 ||
+        max_nmp < 1 || (mp_pitch > 0 && mp_pitch < max_nmp) || cap < 0 || img1_width < 1 || img1_height < 1)
+        return TB_EINVAL;
+    if (npairs == 0) return TB_OK;
+    if (!Tcw1 || !k1 || !d1 || !taken1 || !n1 || !cell_start || !cell_items || !mps || !mp_desc || !nmp || !out || !out_counts || !flags)
+        return TB_EINVAL;
+    void* dbest;
+    int rc = tb_scratch(ctx, 6, (size_t)npairs * max_nmp * 6 * sizeof(int32_t), &dbest);
+    if (rc) return rc;
+    return tbk_projection_batch(ctx, npairs, Tcw1, cam1, img1_width, img1_height, k1, d1, taken1, n1, pitch1, cell_start, cell_items,
+                                nullptr, mps, mp_desc, nmp, mp_pitch, scale_factors, nlevels, nratio, th_high, 1, 0, (int32_t*)dbest, out,
+                                cap, out_counts, flags, 1, radio, max_nmp);
 }
 
 int tb_search_by_violence_batch_dev(tb_ctx* ctx, int npairs, const tb_keypoint* k1, const uint8_t* d1, const int32_t* n1, int pitch1,

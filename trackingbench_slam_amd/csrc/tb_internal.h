@@ -153,7 +153,7 @@ int tbk_projection_batch(tb_ctx* ctx, int npairs, const float* d_Tcw, const tb_c
                          const int32_t* d_cellStart, const int32_t* d_cellItems, const tb_keypoint* d_k2, const tb_mappoint* d_mp2,
                          const uint8_t* d_mp2d, const int32_t* d_n2, int pitch2, const float* sf, int nlevels, float nratio,
                          int th_high, int histo_len, int check_orientation, int32_t* d_best, tb_match* d_out, int cap,
-                         int32_t* d_out_counts, int32_t* d_flags);
+                         int32_t* d_out_counts, int32_t* d_flags, int map_mode, float radio, int max_n2);
 /* searchByProjection: project nq map points into F1 and search F1's lookup grid; best[6 nq] */
 int tbk_projection_search(tb_ctx* ctx, int map_overload, const float Tcw[16], const tb_camera* cam, const tb_keypoint* d_k2,
                           const tb_mappoint* d_mp, const uint8_t* d_mpdesc, int nq, const float* d_sf, int nlevels, float sf0,
