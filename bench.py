@@ -288,6 +288,7 @@ def main():
         print(json.dumps(out))
     pipe.close()
     if world > 1:
+        dist.barrier()  # rank 0 is the last to get here (isolated passes, CPU baseline): leave together
         dist.destroy_process_group()
 
 
