@@ -203,8 +203,9 @@ int tb_pose_opt_batch_dev(tb_ctx* ctx, int nproblems, const double K[4], const f
                           float* Tcw_out, int32_t* n_inliers, double* stats);
 /* Multi-keyframe local BA -- north-star extension, NO reference counterpart.
  * poses: nkf x 16 (in/out, first nfixed held), pts: npt x 3 (in/out). A point is observed at most once per
- * keyframe (repeated (kf, pt) pairs are rejected like out-of-range indices); at most 10 free keyframes, 2^25 points and
- * 99 iterations per window (TB_EUNSUPPORTED beyond). stats (nullable, 8 doubles):
+ * keyframe (repeated (kf, pt) pairs are rejected like out-of-range indices); at most 64 free keyframes (128 in all),
+ * 2^25 points and 99 iterations per window (TB_EUNSUPPORTED beyond). Windows with up to 10 free keyframes run the
+ * MFMA-tiled Schur path; 11..64 (reduced systems up to 384 x 384) the generic large-window kernels. stats (nullable, 8 doubles):
  * iterations, initial chi2, final chi2, final lambda. */
 int tb_local_ba(tb_ctx* ctx, const double K[4], int nkf, int nfixed, float* poses, int npt, float* pts,
                 const tb_ba_obs* obs, int nobs, int iters, double* stats);

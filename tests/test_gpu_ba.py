@@ -61,6 +61,39 @@ def test_local_ba_chunk_capacities(ctx, seed, nkf, npt, nfixed, per_pt):
     assert np.isclose(sg[2], so[2], rtol=1e-6, atol=1e-9) and np.isclose(sg[1], so[1], rtol=1e-9)
 
 
+@pytest.mark.parametrize("seed,nkf,npt,nfixed,per_pt,iters", [(31, 13, 300, 2, 6, 6),    # 11 free: first large-window size
+                                                               (32, 50, 2000, 2, 8, 5),   # BASELINE configs[4]: 50-KF window
+                                                               (33, 66, 800, 2, 12, 4),   # 64 free keyframes: the maximum
+                                                               (34, 30, 400, 0, 30, 4),   # dense: every keyframe sees every point
+                                                               (35, 20, 37, 1, 3, 10)])
+def test_local_ba_large_window(ctx, seed, nkf, npt, nfixed, per_pt, iters):
+    """More than 10 free keyframes (reduced system up to 384 x 384) take the generic Schur / solve kernels."""
+    Pt, Pi, Xt, Xi, obs = synth.ba_problem(seed, nkf, npt, K, obs_per_pt=per_pt)
+    io, Po, Xo, so = oracle.local_ba(K, Pi, nfixed, Xi, obs, iters)
+    ig, Pg, Xg, sg = ctx.local_ba(K, Pi, nfixed, Xi, obs, iters)
+    _close(Pg, Po)
+    _close(Xg, Xo)
+    assert np.isclose(sg[2], so[2], rtol=1e-6, atol=1e-9) and np.isclose(sg[1], so[1], rtol=1e-9)
+    assert ig == io and sg[2] < sg[1]
+
+
+def test_local_ba_large_window_batch(ctx):
+    import torch
+    from trackingbench_slam_amd.ba import BatchedLocalBA
+    ba = BatchedLocalBA(ctx, 3, nkf=24, npt=500, iters=5, seed=5, device=torch.device("cuda", 0), distinct=3)
+    ba.run()
+    torch.cuda.synchronize()
+    P1 = ba.poses.cpu().numpy().copy()
+    ba.run()
+    torch.cuda.synchronize()
+    assert np.array_equal(P1, ba.poses.cpu().numpy())  # deterministic
+    for w in range(3):
+        n = int(ba.host["counts"][w])
+        io, Po, Xo, so = oracle.local_ba(K, ba.host["poses"][w], 2, ba.host["pts"][w], ba.host["obs"][w, :n], 5)
+        _close(P1[w].reshape(-1, 4, 4), Po)
+        _close(ba.pts[w].cpu().numpy(), Xo)
+
+
 def test_local_ba_batched_windows(ctx):
     import torch
     from trackingbench_slam_amd.ba import BatchedLocalBA
@@ -87,8 +120,8 @@ def test_local_ba_rejects_bad_input(ctx):
         ctx.local_ba(K, Pi, 2, Xi, bad, 5)
     with pytest.raises(capi.TBError):  # a point seen twice by one keyframe
         ctx.local_ba(K, Pi, 2, Xi, np.concatenate([obs, obs[5:6]]), 5)
-    with pytest.raises(capi.TBError) as e:  # more free keyframes than one 64x64 Schur tile holds
-        P2 = np.tile(np.eye(4, dtype=np.float32), (14, 1, 1))
+    with pytest.raises(capi.TBError) as e:  # more free keyframes than the 6-bit free-edge key holds
+        P2 = np.tile(np.eye(4, dtype=np.float32), (70, 1, 1))
         ctx.local_ba(K, P2, 2, Xi, obs, 5)
     assert e.value.code == capi.TB_EUNSUPPORTED
 

@@ -36,6 +36,7 @@
 #define BA_LD (BA_CP * 3 + 1) /* LDS row stride (doubles) of the densified tiles */
 #define BA_KFCH 1024          /* edges per keyframe-pass chunk */
 #define BA_KFBLK 4            /* workgroups per keyframe in the keyframe pass */
+#define BA_BIG_MAXF 64        /* free keyframes of a large window (6 bits of the free-edge key) */
 
 struct BaState {
     double lambda, ni, currentChi, chi0, scale_p, rho;
@@ -47,6 +48,8 @@ struct BaState {
 struct BaDims {
     int W, nkf, nfixed, nfree, np, npt, obs_pitch, iters;
     int nblkP, kfChunks, G, nChunks;
+    int big, pad_;               /* more than 10 free keyframes: the generic-size Schur / solve kernels */
+    unsigned long long bigStride, oBigA; /* doubles per Schur partial of a large window; its assembled system */
     double fx, fy, cx, cy;
     /* per-window offsets, in doubles, into the double workspace */
     unsigned long long wstride, oT, oP, oHll, oBl, oHq, oHpp, oBp, oXp, oPartKF, oPartP, oPartS;
@@ -775,13 +778,165 @@ k_ba_solve(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) {
     }
 }
 
+/* ---- large windows (11..64 free keyframes, reduced system up to 384 x 384; SURVEY a17's 50-keyframe case).
+ * The 64 x 64 MFMA tile set above does not hold them; these two kernels trade its density for generality and stay
+ * deterministic. S' = sum_l Z_l Z_l^T is block sparse per point (a point seen by E free keyframes touches E(E+1)/2
+ * blocks of 6 x 6), so each workgroup walks a contiguous run of points and adds every point's blocks into its own
+ * lower-triangle partial in global memory (L2 resident), one entry per thread and a barrier between points; the
+ * partials are summed in index order by the solve. */
+__global__ void __launch_bounds__(BA_T)
+k_ba_schur_big(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, const BaState* __restrict__ states) {
+    __shared__ double sRtf[BA_BIG_MAXF * 12];
+    __shared__ double sz[BA_BIG_MAXF * 19]; /* one Z block (6 x 3, row-major) per free edge of the point */
+    __shared__ double srhs[6 * BA_BIG_MAXF];
+    __shared__ int skf[BA_BIG_MAXF];
+    const int w = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    const BaState st = states[w];
+    if (st.status) return;
+    double* D = dw + (size_t)w * d.wstride;
+    const int* I = iw + (size_t)w * d.istride;
+    const int np = d.np;
+    double* S = D + d.oPartS + (size_t)g * d.bigStride; /* [np][np], lower triangle used; then the rhs part [np] */
+    for (int i = tid; i < np * np; i += BA_T) S[i] = 0;
+    for (int i = tid; i < np; i += BA_T) srhs[i] = 0;
+    for (int k = tid; k < d.nfree; k += BA_T) ba_pose_to_Rt(D + d.oT + ((size_t)st.cur * d.nkf + d.nfixed + k) * 7, sRtf + k * 12);
+    __syncthreads();
+    const double delta = (double)sqrtf(5.991f);
+    const int4* KP = reinterpret_cast<const int4*>(I + d.oFreeKP);
+    const int per = (d.npt + d.G - 1) / d.G, p0 = g * per, p1 = min(p0 + per, d.npt);
+    for (int p = p0; p < p1; p++) {
+        const int ea = I[d.oPtFree + p], E = min(I[d.oPtFree + p + 1] - ea, BA_BIG_MAXF); /* setup rejects duplicates: E <= nfree */
+        if (E <= 0) continue; /* uniform over the workgroup */
+        if (tid < E) {
+            const int4 r = KP[ea + tid];
+            const int kf = r.x & 63;
+            const double* q = D + d.oHq + (size_t)p * 12;
+            const double u00 = q[0], u01 = q[1], u02 = q[2], u11 = q[3], u12 = q[4], u22 = q[5];
+            const double Xp[3] = {q[9], q[10], q[11]};
+            BaLin L;
+            double Jp[12], JU[6];
+            ba_linearize(sRtf + kf * 12, Xp, __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w), d.fx, d.fy, d.cx, d.cy, delta, L);
+            ba_jac_pose_iz(L.pc, L.invz, d.fx, d.fy, Jp);
+#pragma unroll
+            for (int k = 0; k < 2; k++) {
+                JU[3 * k] = L.Jl[3 * k] * u00;
+                JU[3 * k + 1] = L.Jl[3 * k] * u01 + L.Jl[3 * k + 1] * u11;
+                JU[3 * k + 2] = L.Jl[3 * k] * u02 + L.Jl[3 * k + 1] * u12 + L.Jl[3 * k + 2] * u22;
+            }
+            skf[tid] = kf;
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+                const double p0w = L.ww * Jp[a], p1w = L.ww * Jp[6 + a];
+                const double z0 = p0w * JU[0] + p1w * JU[3], z1 = p0w * JU[1] + p1w * JU[4], z2 = p0w * JU[2] + p1w * JU[5];
+                sz[tid * 19 + 3 * a] = z0; sz[tid * 19 + 3 * a + 1] = z1; sz[tid * 19 + 3 * a + 2] = z2;
+                srhs[6 * kf + a] += z0 * q[6] + z1 * q[7] + z2 * q[8]; /* the point's keyframes are distinct: no two lanes share a row */
+            }
+        }
+        __syncthreads();
+        for (int idx = tid; idx < E * E * 36; idx += BA_T) {
+            const int a = idx / (36 * E), rem = idx - a * 36 * E, b = rem / 36, ent = rem - b * 36, i = ent / 6, j = ent - i * 6;
+            const int ka = skf[a], kb = skf[b];
+            if (ka < kb || (a == b && j > i)) continue; /* lower triangle only */
+            const double* za = sz + a * 19 + 3 * i;
+            const double* zb = sz + b * 19 + 3 * j;
+            S[(size_t)(6 * ka + i) * np + 6 * kb + j] += za[0] * zb[0] + za[1] * zb[1] + za[2] * zb[2];
+        }
+        __syncthreads();
+    }
+    for (int i = tid; i < np; i += BA_T) S[(size_t)np * np + i] = srhs[i];
+}
+
+/* Assemble the damped reduced system of a large window, factor it (right-looking Cholesky on the lower triangle, in
+ * global memory: 1.2 MB at np = 384, L2 resident), substitute, update the free poses. One workgroup per window. */
+__global__ void __launch_bounds__(BA_T)
+k_ba_solve_big(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) {
+    __shared__ double col[6 * BA_BIG_MAXF], x[6 * BA_BIG_MAXF];
+    __shared__ double red[4];
+    const int w = blockIdx.x, tid = threadIdx.x;
+    BaState* st = states + w;
+    if (st->status) return;
+    double* D = dw + (size_t)w * d.wstride;
+    const int np = d.np, nPart = d.G;
+    const double lambda = st->lambda;
+    double* A = D + d.oBigA;
+    for (int i = tid; i < np * np; i += BA_T) {
+        const int r = i / np, c = i - r * np;
+        if (c > r) continue;
+        double s = 0;
+#pragma unroll 4
+        for (int g = 0; g < nPart; g++) s += D[d.oPartS + (size_t)g * d.bigStride + i]; /* ordered sum */
+        double h = 0;
+        if (r / 6 == c / 6) h = D[d.oHpp + (size_t)(r / 6) * 36 + (r % 6) * 6 + (c % 6)];
+        if (r == c) h += lambda;
+        A[i] = h - s;
+    }
+    for (int r = tid; r < np; r += BA_T) {
+        double s = 0;
+        for (int g = 0; g < nPart; g++) s += D[d.oPartS + (size_t)g * d.bigStride + (size_t)np * np + r];
+        x[r] = D[d.oBp + r] - s;
+    }
+    __syncthreads();
+    bool good = st->sing == 0; /* uniform: every thread reads the same pivots */
+    const int ty = tid >> 4, tx = tid & 15;
+    for (int j = 0; j < np; j++) {
+        const double dj = A[(size_t)j * np + j];
+        if (!(dj > 0) || !isfinite(dj)) good = false;
+        const double sj = sqrt(good ? dj : 1.0), isj = 1.0 / sj;
+        __syncthreads(); /* everyone holds the pivot before it is overwritten */
+        for (int i = j + tid; i < np; i += BA_T) {
+            const double v = (i == j) ? sj : A[(size_t)i * np + j] * isj;
+            col[i] = v;
+            A[(size_t)i * np + j] = v;
+        }
+        __syncthreads();
+        for (int i = j + 1 + ty; i < np; i += 16) {
+            const double ci = col[i];
+            for (int k = j + 1 + tx; k <= i; k += 16) A[(size_t)i * np + k] -= ci * col[k];
+        }
+        __syncthreads();
+    }
+    for (int j = 0; j < np; j++) { /* forward: L y = rhs */
+        const double yj = x[j] / A[(size_t)j * np + j];
+        __syncthreads();
+        for (int i = j + tid; i < np; i += BA_T) x[i] = (i == j) ? yj : x[i] - A[(size_t)i * np + j] * yj;
+        __syncthreads();
+    }
+    for (int j = np - 1; j >= 0; j--) { /* backward: L^T x = y, row j of L */
+        const double xj = x[j] / A[(size_t)j * np + j];
+        __syncthreads();
+        for (int i = tid; i <= j; i += BA_T) x[i] = (i == j) ? xj : x[i] - A[(size_t)j * np + i] * xj;
+        __syncthreads();
+    }
+    double term = 0;
+    for (int i = tid; i < np; i += BA_T) {
+        const double xi = good ? x[i] : 0.0;
+        x[i] = xi;
+        D[d.oXp + i] = xi;
+        term += xi * (lambda * xi + D[d.oBp + i]);
+    }
+    const double sc = ba_block_sum1(term, red);
+    if (tid == 0) { st->scale_p = sc; st->ok2 = good ? 1 : 0; }
+    __syncthreads();
+    const double* T = D + d.oT + (size_t)st->cur * d.nkf * 7;
+    double* Tn = D + d.oT + (size_t)(st->cur ^ 1) * d.nkf * 7;
+    for (int k = tid; k < d.nkf; k += BA_T) {
+        const PoSE3 Tk = ba_load_se3(T + k * 7);
+        if (k < d.nfixed) ba_store_se3(Tn + k * 7, Tk);
+        else {
+            double u[6];
+            for (int a = 0; a < 6; a++) u[a] = x[6 * (k - d.nfixed) + a];
+            ba_store_se3(Tn + k * 7, po_exp_mul(u, Tk));
+        }
+    }
+}
+
 /* ---- F: point back-substitution and trial errors */
 __global__ void __launch_bounds__(BA_T)
 k_ba_update(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw, const int* __restrict__ iw,
             const BaState* __restrict__ states) {
     __shared__ double red[4];
     __shared__ double sRt[TB_MAX_LEVELS * 8 * 12];  /* trial poses */
-    __shared__ double sx[64];
+    __shared__ double sx[6 * BA_BIG_MAXF];
     __shared__ double sRtc[TB_MAX_LEVELS * 8 * 12]; /* linearisation state */
     const int w = blockIdx.y, tid = threadIdx.x;
     const BaState st = states[w];
@@ -928,6 +1083,9 @@ static void ba_dims(BaDims& d, int W, const double K[4], int nkf, int nfixed, in
     d.kfChunks = (obs_pitch + BA_KFCH - 1) / BA_KFCH;
     d.nChunks = (npt + BA_CP - 1) / BA_CP;
     d.G = std::min(std::max(1024 / std::max(W, 1), 1), std::max((d.nChunks + 3) / 4, 1)); /* up to 4 resident Schur blocks per CU */
+    d.big = d.nfree > 10;
+    if (d.big) d.G = std::min(32, std::max((npt + 7) / 8, 1)); /* Schur partials of a large window */
+    d.bigStride = ((unsigned long long)d.np * d.np + d.np + 1) & ~1ull;
     d.fx = K[0]; d.fy = K[1]; d.cx = K[2]; d.cy = K[3];
     unsigned long long o = 0;
     auto take = [&](unsigned long long n) { unsigned long long r = o; o += (n + 1) & ~1ull; return r; };
@@ -937,11 +1095,12 @@ static void ba_dims(BaDims& d, int W, const double K[4], int nkf, int nfixed, in
     d.oBl = take(3ull * npt);
     d.oHq = take(12ull * npt);
     d.oHpp = take(36ull * std::max(d.nfree, 1));
-    d.oBp = take(64);
-    d.oXp = take(64);
+    d.oBp = take(std::max(64, d.np));
+    d.oXp = take(std::max(64, d.np));
     d.oPartKF = take(27ull * std::max(d.nfree, 1) * d.kfChunks);
     d.oPartP = take(4ull * d.nblkP);
-    d.oPartS = take(4096ull * d.G);
+    d.oPartS = take(d.big ? d.bigStride * d.G : 4096ull * d.G);
+    d.oBigA = take(d.big ? (unsigned long long)d.np * d.np : 0);
     d.wstride = o;
     unsigned long long io = 0;
     auto itake = [&](unsigned long long n) { unsigned long long r = io; io += (n + 3) & ~3ull; return r; };
@@ -965,8 +1124,8 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
                        size_t work_bytes) {
     if (W <= 0) return TB_OK;
     const int nfree = nkf - nfixed;
-    if (nfree < 1 || nfree > 10)
-        return tb_fail(ctx, TB_EUNSUPPORTED, "local BA: %d free keyframes (this build supports 1..10: one 64x64 Schur tile)", nfree);
+    if (nfree < 1 || nfree > BA_BIG_MAXF)
+        return tb_fail(ctx, TB_EUNSUPPORTED, "local BA: %d free keyframes (this build supports 1..64)", nfree);
     if (nkf > TB_MAX_LEVELS * 8) return tb_fail(ctx, TB_EUNSUPPORTED, "local BA: too many keyframes");
     if (npt > (1 << 25)) return tb_fail(ctx, TB_EUNSUPPORTED, "local BA: more than 2^25 points per window");
     if (iters > 99) return tb_fail(ctx, TB_EUNSUPPORTED, "local BA: more than 99 LM iterations (one still-running counter per trial, 1000 of them)");
@@ -1007,6 +1166,14 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
             tb_prof_begin(ctx, "k_ba_hinv");
             hipLaunchKernelGGL(k_ba_hinv, dim3(d.nblkP, W), dim3(BA_T), 0, s, d, dw, states);
             tb_prof_end(ctx);
+            if (d.big) {
+                tb_prof_begin(ctx, "k_ba_schur_big");
+                hipLaunchKernelGGL(k_ba_schur_big, dim3(d.G, W), dim3(BA_T), 0, s, d, dw, iw, states);
+                tb_prof_end(ctx);
+                tb_prof_begin(ctx, "k_ba_solve_big");
+                hipLaunchKernelGGL(k_ba_solve_big, dim3(W), dim3(BA_T), 0, s, d, dw, states);
+                tb_prof_end(ctx);
+            } else {
             tb_prof_begin(ctx, "k_ba_schur");
             {
                 const int R = (d.np + 15) >> 4;
@@ -1022,6 +1189,7 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
             else if (d.np <= 48) hipLaunchKernelGGL(k_ba_solve<48>, dim3(W), dim3(BA_T), 0, s, d, dw, states);
             else hipLaunchKernelGGL(k_ba_solve<64>, dim3(W), dim3(BA_T), 0, s, d, dw, states);
             tb_prof_end(ctx);
+            }
             tb_prof_begin(ctx, "k_ba_update");
             hipLaunchKernelGGL(k_ba_update, dim3(d.nblkP, W), dim3(BA_T), 0, s, d, d_obs, dw, iw, states);
             tb_prof_end(ctx);
