@@ -29,6 +29,12 @@ class BatchedLocalBA:
         # edges with a free keyframe enter the Schur complement (bench.py's roofline accounting)
         self.free_edges = int(sum(int((obs[w, :cnt[w]]["kf"] >= nfixed).sum()) for w in range(self.W)))
         self.edges = int(cnt.sum())
+        # (edge, edge) items of the block-pair lists the large-window Schur kernel walks (more than 10 free keyframes)
+        self.pair_items = 0
+        for w in range(self.W):
+            o = obs[w, :cnt[w]]
+            e = np.bincount(o["pt"][o["kf"] >= nfixed], minlength=npt).astype(np.int64)
+            self.pair_items += int((e * (e + 1) // 2).sum())
         dev = device
         self.obs = torch.from_numpy(obs.view(np.uint8).reshape(self.W, self.obs_pitch, capi.BA_OBS.itemsize)).to(dev)
         self.counts = torch.from_numpy(cnt).to(dev)

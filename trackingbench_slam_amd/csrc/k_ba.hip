@@ -48,8 +48,9 @@ struct BaState {
 struct BaDims {
     int W, nkf, nfixed, nfree, np, npt, obs_pitch, iters;
     int nblkP, kfChunks, G, nChunks;
-    int big, pad_;               /* more than 10 free keyframes: the generic-size Schur / solve kernels */
-    unsigned long long bigStride, oBigA; /* doubles per Schur partial of a large window; its assembled system */
+    int big, npairs;             /* more than 10 free keyframes: the block-pair Schur / panel solve kernels */
+    unsigned long long oZ, oBigA; /* large windows: Z records per free edge; the reduced system [np + 1][np] */
+    unsigned long long oPairStart, oPairCnt, oPairItems, maxItems; /* ints: block-pair item lists */
     double fx, fy, cx, cy;
     /* per-window offsets, in doubles, into the double workspace */
     unsigned long long wstride, oT, oP, oHll, oBl, oHq, oHpp, oBp, oXp, oPartKF, oPartP, oPartS;
@@ -779,152 +780,344 @@ k_ba_solve(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) {
 }
 
 /* ---- large windows (11..64 free keyframes, reduced system up to 384 x 384; SURVEY a17's 50-keyframe case).
- * The 64 x 64 MFMA tile set above does not hold them; these two kernels trade its density for generality and stay
- * deterministic. S' = sum_l Z_l Z_l^T is block sparse per point (a point seen by E free keyframes touches E(E+1)/2
- * blocks of 6 x 6), so each workgroup walks a contiguous run of points and adds every point's blocks into its own
- * lower-triangle partial in global memory (L2 resident), one entry per thread and a barrier between points; the
- * partials are summed in index order by the solve. */
+ * The 64 x 64 MFMA tile set above does not hold them, and S' = sum_l Z_l Z_l^T is block sparse per point (a point seen
+ * by E free keyframes touches E (E + 1) / 2 of the 6 x 6 blocks: ~10 % fill at 48 free keyframes), so the large path is
+ * organised by OUTPUT block instead:
+ *   setup, once per call: for every block pair (a >= b) the list of (edge of a, edge of b) items whose point both
+ *     keyframes see, in ascending edge order (k_ba_pairs, count pass + scan + fill pass; a wavefront per keyframe a
+ *     ranks its edges per b with ballots, so the order is fixed without sorting);
+ *   per trial: k_ba_zbuild rebuilds Z = Hpl U (6 x 3) and Z U^T bl per free edge from its 16-byte record;
+ *     k_ba_schur_pairs gives each pair one wavefront, lane = item, 36 register accumulators, a fixed butterfly sum, and
+ *     writes the damped reduced system (and the rhs, as row np) directly -- no partial matrices, no atomics;
+ *     k_ba_solve_big factors it panel by panel in LDS. */
+#define BA_ZREC 24 /* doubles per free edge: Z (6 x 3 row-major), Z U^T bl (6) */
+__device__ __forceinline__ int ba_pair_index(int a, int b) { return a * (a + 1) / 2 + b; }
+
+template <bool FILL>
+__global__ void __launch_bounds__(64)
+k_ba_pairs(BaDims d, const tb_ba_obs* __restrict__ obsAll, int* __restrict__ iw, const int* __restrict__ errflag) {
+    __shared__ int tb[64 * 65]; /* [lane][free keyframe b] -> compact edge of (b, this lane's point), or -1 */
+    const int w = blockIdx.y, a = blockIdx.x, lane = threadIdx.x;
+    if (errflag[w]) return;
+    const tb_ba_obs* obs = obsAll + (size_t)w * d.obs_pitch;
+    int* I = iw + (size_t)w * d.istride;
+    const int4* KP = reinterpret_cast<const int4*>(I + d.oFreeKP);
+    for (int i = lane; i < 64 * 65; i += 64) tb[i] = -1;
+    const int l0 = I[d.oKfStart + d.nfixed + a], l1 = I[d.oKfStart + d.nfixed + a + 1];
+    const unsigned long long ltmask = (1ull << lane) - 1ull;
+    int cnt = 0; /* lane b: items of pair (a, b) so far */
+    const int base = (FILL && lane <= a) ? I[d.oPairStart + ba_pair_index(a, lane)] : 0;
+    __syncthreads();
+    for (int r0 = l0; r0 < l1; r0 += 64) {
+        const bool valid = r0 + lane < l1;
+        int f0 = 0, f1 = 0;
+        if (valid) {
+            const int p = obs[I[d.oKfEdges + r0 + lane]].pt;
+            f0 = I[d.oPtFree + p];
+            f1 = min(I[d.oPtFree + p + 1], f0 + BA_BIG_MAXF);
+            for (int j = f0; j < f1; j++) tb[lane * 65 + (KP[j].x & 63)] = j;
+        }
+        ba_wave_lds_fence();
+        const int ea = tb[lane * 65 + a];
+        for (int b = 0; b <= a; b++) {
+            const int eb = tb[lane * 65 + b];
+            const unsigned long long m = __ballot(valid && eb >= 0);
+            if (m == 0) continue;
+            const int at = __builtin_amdgcn_readlane(base, b) + __builtin_amdgcn_readlane(cnt, b) + __popcll(m & ltmask);
+            if (FILL && valid && eb >= 0) *reinterpret_cast<int2*>(I + d.oPairItems + 2 * (size_t)at) = make_int2(ea, eb);
+            if (lane == b) cnt += __popcll(m);
+        }
+        ba_wave_lds_fence();
+        for (int j = f0; j < f1; j++) tb[lane * 65 + (KP[j].x & 63)] = -1;
+        ba_wave_lds_fence();
+    }
+    if (!FILL && lane <= a) I[d.oPairCnt + ba_pair_index(a, lane)] = cnt;
+}
+
 __global__ void __launch_bounds__(BA_T)
-k_ba_schur_big(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, const BaState* __restrict__ states) {
+k_ba_pair_scan(BaDims d, int* __restrict__ iw, const int* __restrict__ errflag) {
+    __shared__ int tot[BA_T];
+    const int w = blockIdx.x, tid = threadIdx.x;
+    if (errflag[w]) return;
+    int* I = iw + (size_t)w * d.istride;
+    const int per = (d.npairs + BA_T - 1) / BA_T, i0 = min(tid * per, d.npairs), i1 = min(i0 + per, d.npairs);
+    int sum = 0;
+    for (int i = i0; i < i1; i++) sum += I[d.oPairCnt + i];
+    tot[tid] = sum;
+    __syncthreads();
+    int run = 0;
+    for (int t = 0; t < tid; t++) run += tot[t];
+    for (int i = i0; i < i1; i++) { I[d.oPairStart + i] = run; run += I[d.oPairCnt + i]; }
+    if (tid == BA_T - 1) I[d.oPairStart + d.npairs] = run;
+}
+
+__global__ void __launch_bounds__(BA_T)
+k_ba_zbuild(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, const BaState* __restrict__ states) {
     __shared__ double sRtf[BA_BIG_MAXF * 12];
-    __shared__ double sz[BA_BIG_MAXF * 19]; /* one Z block (6 x 3, row-major) per free edge of the point */
-    __shared__ double srhs[6 * BA_BIG_MAXF];
-    __shared__ int skf[BA_BIG_MAXF];
-    const int w = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    const int w = blockIdx.y, tid = threadIdx.x;
     const BaState st = states[w];
     if (st.status) return;
     double* D = dw + (size_t)w * d.wstride;
     const int* I = iw + (size_t)w * d.istride;
-    const int np = d.np;
-    double* S = D + d.oPartS + (size_t)g * d.bigStride; /* [np][np], lower triangle used; then the rhs part [np] */
-    for (int i = tid; i < np * np; i += BA_T) S[i] = 0;
-    for (int i = tid; i < np; i += BA_T) srhs[i] = 0;
     for (int k = tid; k < d.nfree; k += BA_T) ba_pose_to_Rt(D + d.oT + ((size_t)st.cur * d.nkf + d.nfixed + k) * 7, sRtf + k * 12);
     __syncthreads();
+    const int ce = blockIdx.x * BA_T + tid;
+    if (ce >= I[d.oPtFree + d.npt]) return;
+    const int4 r = reinterpret_cast<const int4*>(I + d.oFreeKP)[ce];
+    const int kf = r.x & 63, p = (int)((unsigned)r.x >> 6);
+    const double* q = D + d.oHq + (size_t)p * 12;
+    const double u00 = q[0], u01 = q[1], u02 = q[2], u11 = q[3], u12 = q[4], u22 = q[5];
+    const double Xp[3] = {q[9], q[10], q[11]};
     const double delta = (double)sqrtf(5.991f);
-    const int4* KP = reinterpret_cast<const int4*>(I + d.oFreeKP);
-    const int per = (d.npt + d.G - 1) / d.G, p0 = g * per, p1 = min(p0 + per, d.npt);
-    for (int p = p0; p < p1; p++) {
-        const int ea = I[d.oPtFree + p], E = min(I[d.oPtFree + p + 1] - ea, BA_BIG_MAXF); /* setup rejects duplicates: E <= nfree */
-        if (E <= 0) continue; /* uniform over the workgroup */
-        if (tid < E) {
-            const int4 r = KP[ea + tid];
-            const int kf = r.x & 63;
-            const double* q = D + d.oHq + (size_t)p * 12;
-            const double u00 = q[0], u01 = q[1], u02 = q[2], u11 = q[3], u12 = q[4], u22 = q[5];
-            const double Xp[3] = {q[9], q[10], q[11]};
-            BaLin L;
-            double Jp[12], JU[6];
-            ba_linearize(sRtf + kf * 12, Xp, __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w), d.fx, d.fy, d.cx, d.cy, delta, L);
-            ba_jac_pose_iz(L.pc, L.invz, d.fx, d.fy, Jp);
+    BaLin L;
+    double Jp[12], JU[6];
+    ba_linearize(sRtf + kf * 12, Xp, __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w), d.fx, d.fy, d.cx, d.cy, delta, L);
+    ba_jac_pose_iz(L.pc, L.invz, d.fx, d.fy, Jp);
 #pragma unroll
-            for (int k = 0; k < 2; k++) {
-                JU[3 * k] = L.Jl[3 * k] * u00;
-                JU[3 * k + 1] = L.Jl[3 * k] * u01 + L.Jl[3 * k + 1] * u11;
-                JU[3 * k + 2] = L.Jl[3 * k] * u02 + L.Jl[3 * k + 1] * u12 + L.Jl[3 * k + 2] * u22;
-            }
-            skf[tid] = kf;
-#pragma unroll
-            for (int a = 0; a < 6; a++) {
-                const double p0w = L.ww * Jp[a], p1w = L.ww * Jp[6 + a];
-                const double z0 = p0w * JU[0] + p1w * JU[3], z1 = p0w * JU[1] + p1w * JU[4], z2 = p0w * JU[2] + p1w * JU[5];
-                sz[tid * 19 + 3 * a] = z0; sz[tid * 19 + 3 * a + 1] = z1; sz[tid * 19 + 3 * a + 2] = z2;
-                srhs[6 * kf + a] += z0 * q[6] + z1 * q[7] + z2 * q[8]; /* the point's keyframes are distinct: no two lanes share a row */
-            }
-        }
-        __syncthreads();
-        for (int idx = tid; idx < E * E * 36; idx += BA_T) {
-            const int a = idx / (36 * E), rem = idx - a * 36 * E, b = rem / 36, ent = rem - b * 36, i = ent / 6, j = ent - i * 6;
-            const int ka = skf[a], kb = skf[b];
-            if (ka < kb || (a == b && j > i)) continue; /* lower triangle only */
-            const double* za = sz + a * 19 + 3 * i;
-            const double* zb = sz + b * 19 + 3 * j;
-            S[(size_t)(6 * ka + i) * np + 6 * kb + j] += za[0] * zb[0] + za[1] * zb[1] + za[2] * zb[2];
-        }
-        __syncthreads();
+    for (int k = 0; k < 2; k++) {
+        JU[3 * k] = L.Jl[3 * k] * u00;
+        JU[3 * k + 1] = L.Jl[3 * k] * u01 + L.Jl[3 * k + 1] * u11;
+        JU[3 * k + 2] = L.Jl[3 * k] * u02 + L.Jl[3 * k + 1] * u12 + L.Jl[3 * k + 2] * u22;
     }
-    for (int i = tid; i < np; i += BA_T) S[(size_t)np * np + i] = srhs[i];
+    double* z = D + d.oZ + (size_t)ce * BA_ZREC;
+#pragma unroll
+    for (int a = 0; a < 6; a++) {
+        const double p0w = L.ww * Jp[a], p1w = L.ww * Jp[6 + a];
+        const double z0 = p0w * JU[0] + p1w * JU[3], z1 = p0w * JU[1] + p1w * JU[4], z2 = p0w * JU[2] + p1w * JU[5];
+        z[3 * a] = z0; z[3 * a + 1] = z1; z[3 * a + 2] = z2;
+        z[18 + a] = z0 * q[6] + z1 * q[7] + z2 * q[8];
+    }
 }
 
-/* Assemble the damped reduced system of a large window, factor it (right-looking Cholesky on the lower triangle, in
- * global memory: 1.2 MB at np = 384, L2 resident), substitute, update the free poses. One workgroup per window. */
+/* one wavefront per block pair (a >= b): A[6a.., 6b..] = [a == b] (Hpp_a + lambda I) - sum_items Z_ea Z_eb^T; the
+ * diagonal pairs also give row np of A, the reduced rhs bp_a - sum Z U^T bl */
 __global__ void __launch_bounds__(BA_T)
+k_ba_schur_pairs(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, const BaState* __restrict__ states) {
+    const int w = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
+    const BaState st = states[w];
+    if (st.status) return;
+    const int pr = blockIdx.x * 4 + (tid >> 6);
+    if (pr >= d.npairs) return; /* wave-uniform, no barriers below */
+    double* D = dw + (size_t)w * d.wstride;
+    const int* I = iw + (size_t)w * d.istride;
+    int a = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
+    while ((a + 1) * (a + 2) / 2 <= pr) a++;
+    while (a * (a + 1) / 2 > pr) a--;
+    const int b = pr - a * (a + 1) / 2;
+    const int i0 = I[d.oPairStart + pr], i1 = I[d.oPairStart + pr + 1];
+    const int2* items = reinterpret_cast<const int2*>(I + d.oPairItems);
+    const double* Z = D + d.oZ;
+    double acc[36], rh[6];
+#pragma unroll
+    for (int k = 0; k < 36; k++) acc[k] = 0;
+#pragma unroll
+    for (int k = 0; k < 6; k++) rh[k] = 0;
+    for (int it = i0 + lane; it < i1; it += 64) {
+        const int2 e = items[it];
+        const double2* za2 = reinterpret_cast<const double2*>(Z + (size_t)e.x * BA_ZREC);
+        const double2* zb2 = reinterpret_cast<const double2*>(Z + (size_t)e.y * BA_ZREC);
+        double za[18], zb[18];
+#pragma unroll
+        for (int k = 0; k < 9; k++) { const double2 v = za2[k]; za[2 * k] = v.x; za[2 * k + 1] = v.y; }
+#pragma unroll
+        for (int k = 0; k < 9; k++) { const double2 v = zb2[k]; zb[2 * k] = v.x; zb[2 * k + 1] = v.y; }
+#pragma unroll
+        for (int i = 0; i < 6; i++)
+#pragma unroll
+            for (int j = 0; j < 6; j++)
+                acc[6 * i + j] += za[3 * i] * zb[3 * j] + za[3 * i + 1] * zb[3 * j + 1] + za[3 * i + 2] * zb[3 * j + 2];
+        if (a == b) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) { const double2 v = za2[9 + k]; rh[2 * k] += v.x; rh[2 * k + 1] += v.y; }
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 36; k++) acc[k] = po_wave_sum(acc[k]);
+    double* A = D + d.oBigA;
+    const int np = d.np;
+    double mine = 0; /* lane k < 36 stores entry k */
+#pragma unroll
+    for (int k = 0; k < 36; k++) mine = (lane == k) ? acc[k] : mine;
+    if (lane < 36) {
+        const int i = lane / 6, j = lane - i * 6;
+        double h = 0;
+        if (a == b) h = D[d.oHpp + (size_t)a * 36 + lane] + ((i == j) ? st.lambda : 0.0);
+        if (a != b || j <= i) A[(size_t)(6 * a + i) * np + 6 * b + j] = h - mine;
+    }
+    if (a == b) {
+#pragma unroll
+        for (int k = 0; k < 6; k++) rh[k] = po_wave_sum(rh[k]);
+        double r = 0;
+#pragma unroll
+        for (int k = 0; k < 6; k++) r = (lane == k) ? rh[k] : r;
+        if (lane < 6) A[(size_t)np * np + 6 * a + lane] = D[d.oBp + 6 * a + lane] - r;
+    }
+}
+
+/* Factor the damped reduced system of a large window and update the free poses; one workgroup per window. Right-looking
+ * Cholesky on the lower triangle, BA_PB columns at a time: the panel (all rows below its diagonal block, plus row np =
+ * the rhs, which turns into y = L^-1 rhs on the way) sits in LDS while its columns are eliminated, then every thread
+ * applies the rank-BA_PB update to 4 x 4 register tiles of the trailing matrix in global memory (1.2 MB at np = 384,
+ * L2 resident). The back-substitution walks the panels in reverse. */
+#define BA_PB 32
+#define BA_ST 1024 /* threads of the large-window solve: the trailing update and the row solves are data parallel */
+#define BA_PLD (BA_PB + 1)
+__global__ void __launch_bounds__(BA_ST)
 k_ba_solve_big(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) {
-    __shared__ double col[6 * BA_BIG_MAXF], x[6 * BA_BIG_MAXF];
-    __shared__ double red[4];
+    extern __shared__ __attribute__((aligned(16))) double Pn[]; /* [np + 1 - k0][BA_PLD] */
+    __shared__ double xs[6 * BA_BIG_MAXF], part[(BA_ST / BA_PB) * BA_PB], red[BA_ST / 64];
     const int w = blockIdx.x, tid = threadIdx.x;
     BaState* st = states + w;
     if (st->status) return;
     double* D = dw + (size_t)w * d.wstride;
-    const int np = d.np, nPart = d.G;
+    const int np = d.np;
     const double lambda = st->lambda;
-    double* A = D + d.oBigA;
-    for (int i = tid; i < np * np; i += BA_T) {
-        const int r = i / np, c = i - r * np;
-        if (c > r) continue;
-        double s = 0;
-#pragma unroll 4
-        for (int g = 0; g < nPart; g++) s += D[d.oPartS + (size_t)g * d.bigStride + i]; /* ordered sum */
-        double h = 0;
-        if (r / 6 == c / 6) h = D[d.oHpp + (size_t)(r / 6) * 36 + (r % 6) * 6 + (c % 6)];
-        if (r == c) h += lambda;
-        A[i] = h - s;
-    }
-    for (int r = tid; r < np; r += BA_T) {
-        double s = 0;
-        for (int g = 0; g < nPart; g++) s += D[d.oPartS + (size_t)g * d.bigStride + (size_t)np * np + r];
-        x[r] = D[d.oBp + r] - s;
-    }
+    double* A = D + d.oBigA; /* [np + 1][np] */
+    __shared__ double invd[BA_PB];
+    __shared__ int sgood;
+    if (tid == 0) sgood = st->sing == 0;
     __syncthreads();
-    bool good = st->sing == 0; /* uniform: every thread reads the same pivots */
-    const int ty = tid >> 4, tx = tid & 15;
-    for (int j = 0; j < np; j++) {
-        const double dj = A[(size_t)j * np + j];
-        if (!(dj > 0) || !isfinite(dj)) good = false;
-        const double sj = sqrt(good ? dj : 1.0), isj = 1.0 / sj;
-        __syncthreads(); /* everyone holds the pivot before it is overwritten */
-        for (int i = j + tid; i < np; i += BA_T) {
-            const double v = (i == j) ? sj : A[(size_t)i * np + j] * isj;
-            col[i] = v;
-            A[(size_t)i * np + j] = v;
+    for (int k0 = 0; k0 < np; k0 += BA_PB) {
+        const int nb = min(BA_PB, np - k0), mr = np + 1 - k0;
+        if (tid < 64) {
+            /* diagonal block in one wavefront, lane = row, the row in registers, columns broadcast with readlane (as in
+             * k_ba_solve); rows >= nb are identity and factor to themselves */
+            const int r = tid;
+            double dr[BA_PB];
+#pragma unroll
+            for (int c = 0; c < BA_PB; c++)
+                dr[c] = (r < nb && c < nb) ? ((c <= r) ? A[(size_t)(k0 + r) * np + k0 + c] : 0.0) : ((c == r) ? 1.0 : 0.0);
+            bool good = sgood != 0;
+#pragma unroll
+            for (int j = 0; j < BA_PB; j++) {
+                const double dj = ba_readlane(dr[j], j);
+                if (!(dj > 0) || !isfinite(dj)) good = false;
+                const double sj = sqrt(good ? dj : 1.0), isj = 1.0 / sj;
+                dr[j] = (r == j) ? sj : dr[j] * isj;
+#pragma unroll
+                for (int k = j + 1; k < BA_PB; k++) dr[k] -= dr[j] * ba_readlane(dr[j], k);
+            }
+            if (r < nb) {
+#pragma unroll
+                for (int c = 0; c < BA_PB; c++) {
+                    if (c <= r) { Pn[r * BA_PLD + c] = dr[c]; A[(size_t)(k0 + r) * np + k0 + c] = dr[c]; }
+                    if (c == r) invd[r] = 1.0 / dr[c];
+                }
+            }
+            if (r == 0) sgood = good ? 1 : 0;
         }
         __syncthreads();
-        for (int i = j + 1 + ty; i < np; i += 16) {
-            const double ci = col[i];
-            for (int k = j + 1 + tx; k <= i; k += 16) A[(size_t)i * np + k] -= ci * col[k];
+        /* rows below the block (and the rhs row): L[r][:] = A[r][:] L_d^-T, every thread its own row, no barriers */
+        for (int r = nb + tid; r < mr; r += BA_ST) {
+            double row[BA_PB];
+            double* Ar = A + (size_t)(k0 + r) * np + k0;
+#pragma unroll
+            for (int c = 0; c < BA_PB; c++) row[c] = (c < nb) ? Ar[c] : 0.0;
+#pragma unroll
+            for (int c = 0; c < BA_PB; c++) {
+                if (c < nb) {
+                    row[c] *= invd[c];
+#pragma unroll
+                    for (int c2 = c + 1; c2 < BA_PB; c2++)
+                        if (c2 < nb) row[c2] -= row[c] * Pn[c2 * BA_PLD + c];
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < BA_PB; c++)
+                if (c < nb) { Pn[r * BA_PLD + c] = row[c]; Ar[c] = row[c]; }
+        }
+        __syncthreads();
+        /* trailing update: rows i in [k0 + nb, np], columns j in [k0 + nb, min(i, np - 1)], 4 x 4 tiles (ti >= tj) */
+        const int mt = np - k0 - nb;
+        if (mt > 0) {
+            const int nT = (mt + 1 + 3) >> 2, last = mr - 1;
+            for (int t = tid; t < nT * (nT + 1) / 2; t += BA_ST) {
+                int ti = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+                while ((ti + 1) * (ti + 2) / 2 <= t) ti++;
+                while (ti * (ti + 1) / 2 > t) ti--;
+                const int tj = t - ti * (ti + 1) / 2;
+                const int ra = nb + 4 * ti, rb = nb + 4 * tj; /* panel rows of the tile's rows / columns */
+                double acc[4][4] = {};
+                for (int c = 0; c < nb; c++) {
+                    double av[4], bv[4];
+#pragma unroll
+                    for (int q = 0; q < 4; q++) { av[q] = Pn[min(ra + q, last) * BA_PLD + c]; bv[q] = Pn[min(rb + q, last) * BA_PLD + c]; }
+#pragma unroll
+                    for (int q = 0; q < 4; q++)
+#pragma unroll
+                        for (int s = 0; s < 4; s++) acc[q][s] = fma(av[q], bv[s], acc[q][s]);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; q++)
+#pragma unroll
+                    for (int s = 0; s < 4; s++) {
+                        const int i = k0 + ra + q, j = k0 + rb + s;
+                        if (i <= np && j < np && j <= i) A[(size_t)i * np + j] -= acc[q][s];
+                    }
+            }
         }
         __syncthreads();
     }
-    for (int j = 0; j < np; j++) { /* forward: L y = rhs */
-        const double yj = x[j] / A[(size_t)j * np + j];
+    /* L^T x = y, panels in reverse; y = row np of the factored array */
+    for (int i = tid; i < np; i += BA_ST) xs[i] = A[(size_t)np * np + i];
+    __syncthreads();
+    for (int k0 = ((np - 1) / BA_PB) * BA_PB; k0 >= 0; k0 -= BA_PB) {
+        const int nb = min(BA_PB, np - k0), mr = np - k0;
+        for (int idx = tid; idx < mr * nb; idx += BA_ST) {
+            const int r = idx / nb, c = idx - r * nb;
+            Pn[r * BA_PLD + c] = (c <= r) ? A[(size_t)(k0 + r) * np + k0 + c] : 0.0;
+        }
         __syncthreads();
-        for (int i = j + tid; i < np; i += BA_T) x[i] = (i == j) ? yj : x[i] - A[(size_t)i * np + j] * yj;
+        {   /* sum_{i >= k0 + nb} L[i][k0 + c] x_i: BA_ST / BA_PB row classes per column, combined in order */
+            const int c = tid & (BA_PB - 1), cls = tid >> 5;
+            double s = 0;
+            if (c < nb)
+                for (int r = nb + cls; r < mr; r += BA_ST / BA_PB) s += Pn[r * BA_PLD + c] * xs[k0 + r];
+            part[cls * BA_PB + c] = s;
+        }
+        __syncthreads();
+        if (tid < 64) { /* the nb x nb triangle in one wavefront: lane c holds t_c */
+            const int c = tid;
+            double t = 0;
+            if (c < nb) {
+                double s = 0;
+                for (int k = 0; k < BA_ST / BA_PB; k++) s += part[k * BA_PB + c];
+                t = xs[k0 + c] - s;
+            }
+            for (int j = nb - 1; j >= 0; j--) {
+                const double xj = ba_readlane(t, j) / Pn[j * BA_PLD + j];
+                if (c == j) t = xj;
+                else if (c < j) t -= Pn[j * BA_PLD + c] * xj;
+            }
+            if (c < nb) xs[k0 + c] = t;
+        }
         __syncthreads();
     }
-    for (int j = np - 1; j >= 0; j--) { /* backward: L^T x = y, row j of L */
-        const double xj = x[j] / A[(size_t)j * np + j];
-        __syncthreads();
-        for (int i = tid; i <= j; i += BA_T) x[i] = (i == j) ? xj : x[i] - A[(size_t)j * np + i] * xj;
-        __syncthreads();
-    }
+    const bool good = sgood != 0;
     double term = 0;
-    for (int i = tid; i < np; i += BA_T) {
-        const double xi = good ? x[i] : 0.0;
-        x[i] = xi;
+    for (int i = tid; i < np; i += BA_ST) {
+        const double xi = good ? xs[i] : 0.0;
+        xs[i] = xi;
         D[d.oXp + i] = xi;
         term += xi * (lambda * xi + D[d.oBp + i]);
     }
-    const double sc = ba_block_sum1(term, red);
-    if (tid == 0) { st->scale_p = sc; st->ok2 = good ? 1 : 0; }
+    term = po_wave_sum(term);
+    if ((tid & 63) == 0) red[tid >> 6] = term;
+    __syncthreads();
+    if (tid == 0) {
+        double sc = 0;
+        for (int k = 0; k < BA_ST / 64; k++) sc += red[k];
+        st->scale_p = sc; st->ok2 = good ? 1 : 0;
+    }
     __syncthreads();
     const double* T = D + d.oT + (size_t)st->cur * d.nkf * 7;
     double* Tn = D + d.oT + (size_t)(st->cur ^ 1) * d.nkf * 7;
-    for (int k = tid; k < d.nkf; k += BA_T) {
+    for (int k = tid; k < d.nkf; k += BA_ST) {
         const PoSE3 Tk = ba_load_se3(T + k * 7);
         if (k < d.nfixed) ba_store_se3(Tn + k * 7, Tk);
         else {
             double u[6];
-            for (int a = 0; a < 6; a++) u[a] = x[6 * (k - d.nfixed) + a];
+            for (int a = 0; a < 6; a++) u[a] = xs[6 * (k - d.nfixed) + a];
             ba_store_se3(Tn + k * 7, po_exp_mul(u, Tk));
         }
     }
@@ -1084,8 +1277,8 @@ static void ba_dims(BaDims& d, int W, const double K[4], int nkf, int nfixed, in
     d.nChunks = (npt + BA_CP - 1) / BA_CP;
     d.G = std::min(std::max(1024 / std::max(W, 1), 1), std::max((d.nChunks + 3) / 4, 1)); /* up to 4 resident Schur blocks per CU */
     d.big = d.nfree > 10;
-    if (d.big) d.G = std::min(32, std::max((npt + 7) / 8, 1)); /* Schur partials of a large window */
-    d.bigStride = ((unsigned long long)d.np * d.np + d.np + 1) & ~1ull;
+    d.npairs = d.nfree * (d.nfree + 1) / 2;
+    d.maxItems = (unsigned long long)obs_pitch * (d.nfree + 1) / 2 + 1; /* sum_p E_p (E_p + 1) / 2 with E_p <= nfree */
     d.fx = K[0]; d.fy = K[1]; d.cx = K[2]; d.cy = K[3];
     unsigned long long o = 0;
     auto take = [&](unsigned long long n) { unsigned long long r = o; o += (n + 1) & ~1ull; return r; };
@@ -1099,8 +1292,9 @@ static void ba_dims(BaDims& d, int W, const double K[4], int nkf, int nfixed, in
     d.oXp = take(std::max(64, d.np));
     d.oPartKF = take(27ull * std::max(d.nfree, 1) * d.kfChunks);
     d.oPartP = take(4ull * d.nblkP);
-    d.oPartS = take(d.big ? d.bigStride * d.G : 4096ull * d.G);
-    d.oBigA = take(d.big ? (unsigned long long)d.np * d.np : 0);
+    d.oPartS = take(d.big ? 0 : 4096ull * d.G);
+    d.oZ = take(d.big ? (unsigned long long)BA_ZREC * obs_pitch : 0);
+    d.oBigA = take(d.big ? (unsigned long long)(d.np + 1) * d.np : 0);
     d.wstride = o;
     unsigned long long io = 0;
     auto itake = [&](unsigned long long n) { unsigned long long r = io; io += (n + 3) & ~3ull; return r; };
@@ -1109,6 +1303,9 @@ static void ba_dims(BaDims& d, int W, const double K[4], int nkf, int nfixed, in
     d.oKfStart = itake(nkf + 1);
     d.oKfEdges = itake(obs_pitch);
     d.oFreeKP = itake(4ull * obs_pitch);
+    d.oPairStart = itake(d.big ? d.npairs + 1 : 0);
+    d.oPairCnt = itake(d.big ? d.npairs : 0);
+    d.oPairItems = itake(d.big ? 2 * d.maxItems : 0);
     d.istride = io;
 }
 
@@ -1128,6 +1325,8 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
         return tb_fail(ctx, TB_EUNSUPPORTED, "local BA: %d free keyframes (this build supports 1..64)", nfree);
     if (nkf > TB_MAX_LEVELS * 8) return tb_fail(ctx, TB_EUNSUPPORTED, "local BA: too many keyframes");
     if (npt > (1 << 25)) return tb_fail(ctx, TB_EUNSUPPORTED, "local BA: more than 2^25 points per window");
+    if (nfree > 10 && (unsigned long long)obs_pitch * (nfree + 1) >= (1ull << 31))
+        return tb_fail(ctx, TB_EUNSUPPORTED, "local BA: large window with more than 2^31 / (free keyframes + 1) observations");
     if (iters > 99) return tb_fail(ctx, TB_EUNSUPPORTED, "local BA: more than 99 LM iterations (one still-running counter per trial, 1000 of them)");
     BaDims d;
     ba_dims(d, W, K, nkf, nfixed, npt, obs_pitch, iters);
@@ -1149,6 +1348,17 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
     hipLaunchKernelGGL(k_ba_setup, dim3(nkf + 2, W), dim3(BA_T), 0, s, d, d_poses, d_pts, d_obs, d_counts, dw, iw, states, errflag);
     tb_prof_end(ctx);
     TB_HIP(ctx, hipGetLastError());
+    const size_t big_lds = (size_t)(d.np + 1) * BA_PLD * sizeof(double);
+    if (d.big) {
+        /* block-pair item lists of the large-window Schur kernel: count, scan, fill */
+        TB_HIP(ctx, hipFuncSetAttribute((const void*)k_ba_solve_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
+        tb_prof_begin(ctx, "k_ba_pairs");
+        hipLaunchKernelGGL(k_ba_pairs<false>, dim3(d.nfree, W), dim3(64), 0, s, d, d_obs, iw, errflag);
+        hipLaunchKernelGGL(k_ba_pair_scan, dim3(W), dim3(BA_T), 0, s, d, iw, errflag);
+        hipLaunchKernelGGL(k_ba_pairs<true>, dim3(d.nfree, W), dim3(64), 0, s, d, d_obs, iw, errflag);
+        tb_prof_end(ctx);
+        TB_HIP(ctx, hipGetLastError());
+    }
     int host_running = 1, rounds = 0;
     const int max_rounds = std::min(iters * 10 + 1, 1000); /* ring size below */
     int batch = iters + 1;
@@ -1167,11 +1377,14 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
             hipLaunchKernelGGL(k_ba_hinv, dim3(d.nblkP, W), dim3(BA_T), 0, s, d, dw, states);
             tb_prof_end(ctx);
             if (d.big) {
-                tb_prof_begin(ctx, "k_ba_schur_big");
-                hipLaunchKernelGGL(k_ba_schur_big, dim3(d.G, W), dim3(BA_T), 0, s, d, dw, iw, states);
+                tb_prof_begin(ctx, "k_ba_zbuild");
+                hipLaunchKernelGGL(k_ba_zbuild, dim3((obs_pitch + BA_T - 1) / BA_T, W), dim3(BA_T), 0, s, d, dw, iw, states);
+                tb_prof_end(ctx);
+                tb_prof_begin(ctx, "k_ba_schur_pairs");
+                hipLaunchKernelGGL(k_ba_schur_pairs, dim3((d.npairs + 3) / 4, W), dim3(BA_T), 0, s, d, dw, iw, states);
                 tb_prof_end(ctx);
                 tb_prof_begin(ctx, "k_ba_solve_big");
-                hipLaunchKernelGGL(k_ba_solve_big, dim3(W), dim3(BA_T), 0, s, d, dw, states);
+                hipLaunchKernelGGL(k_ba_solve_big, dim3(W), dim3(BA_ST), big_lds, s, d, dw, states);
                 tb_prof_end(ctx);
             } else {
             tb_prof_begin(ctx, "k_ba_schur");
