@@ -259,14 +259,14 @@ def main():
                 roofline = {"bound": "mfma", "achieved": round(tf, 3), "peak": F64_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                             "frac": round(tf / F64_MFMA_PEAK_TFLOPS, 5), **common}
         else:
-            if name in ("k_ba_schur_pairs", "k_ba_solve_big", "k_ba_zbuild") and pipe.bas:
+            if name in ("k_ba_schur_pairs", "k_ba_solve_big") and pipe.bas:
                 # large windows (more than 10 free keyframes), one launch = one LM trial of one partition: bytes per step =
-                # bytes per launch x launches. Z records are 192 B per free edge; a pair item reads two of them and its
-                # 8-byte index pair; the reduced system [np + 1][np] is written once and read + written once by the solve.
+                # bytes per launch x launches. A pair item reads its 8-byte index pair, two 16-byte edge records and the
+                # 96-byte point record; the lower triangle of the reduced system [np + 1][np] is written once by the
+                # Schur kernel and read + written once by the solve.
                 np_ = 6 * (args.ba_kf - 2)
                 nwin_all = sum(b.W for b, _, _ in pipe.bas)
-                per_trial = {"k_ba_zbuild": sum(b.free_edges for b, _, _ in pipe.bas) * (16 + 96 + 192),
-                             "k_ba_schur_pairs": sum(b.pair_items for b, _, _ in pipe.bas) * (8 + 2 * 144) + nwin_all * (np_ + 1) * np_ * 4,
+                per_trial = {"k_ba_schur_pairs": sum(b.pair_items for b, _, _ in pipe.bas) * (8 + 2 * 16 + 96) + nwin_all * (np_ + 1) * np_ * 4,
                              "k_ba_solve_big": nwin_all * (np_ + 1) * np_ * 8}[name]
                 abytes = per_trial * max(calls // max(args.steps, 1), 1) // max(len(pipe.bas), 1)
             achieved = (abytes / 1e9) / (avg_ms_per_step / 1e3) if avg_ms_per_step > 0 else 0.0

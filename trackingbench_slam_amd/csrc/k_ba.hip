@@ -49,7 +49,7 @@ struct BaDims {
     int W, nkf, nfixed, nfree, np, npt, obs_pitch, iters;
     int nblkP, kfChunks, G, nChunks;
     int big, npairs;             /* more than 10 free keyframes: the block-pair Schur / panel solve kernels */
-    unsigned long long oZ, oBigA; /* large windows: Z records per free edge; the reduced system [np + 1][np] */
+    unsigned long long oBigA;    /* large windows: the reduced system [np + 1][np] (row np = rhs) */
     unsigned long long oPairStart, oPairCnt, oPairItems, maxItems; /* ints: block-pair item lists */
     double fx, fy, cx, cy;
     /* per-window offsets, in doubles, into the double workspace */
@@ -786,11 +786,10 @@ k_ba_solve(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) {
  *   setup, once per call: for every block pair (a >= b) the list of (edge of a, edge of b) items whose point both
  *     keyframes see, in ascending edge order (k_ba_pairs, count pass + scan + fill pass; a wavefront per keyframe a
  *     ranks its edges per b with ballots, so the order is fixed without sorting);
- *   per trial: k_ba_zbuild rebuilds Z = Hpl U (6 x 3) and Z U^T bl per free edge from its 16-byte record;
- *     k_ba_schur_pairs gives each pair one wavefront, lane = item, 36 register accumulators, a fixed butterfly sum, and
- *     writes the damped reduced system (and the rhs, as row np) directly -- no partial matrices, no atomics;
+ *   per trial: k_ba_schur_pairs gives each pair one wavefront, lane = item (both Z = Hpl U blocks rebuilt from the
+ *     16-byte edge records), 36 register accumulators, a fixed butterfly sum, and writes the damped reduced system (and
+ *     the rhs, as row np) directly -- no partial matrices, no atomics;
  *     k_ba_solve_big factors it panel by panel in LDS. */
-#define BA_ZREC 24 /* doubles per free edge: Z (6 x 3 row-major), Z U^T bl (6) */
 __device__ __forceinline__ int ba_pair_index(int a, int b) { return a * (a + 1) / 2 + b; }
 
 template <bool FILL>
@@ -851,84 +850,108 @@ k_ba_pair_scan(BaDims d, int* __restrict__ iw, const int* __restrict__ errflag) 
     if (tid == BA_T - 1) I[d.oPairStart + d.npairs] = run;
 }
 
-__global__ void __launch_bounds__(BA_T)
-k_ba_zbuild(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, const BaState* __restrict__ states) {
-    __shared__ double sRtf[BA_BIG_MAXF * 12];
-    const int w = blockIdx.y, tid = threadIdx.x;
-    const BaState st = states[w];
-    if (st.status) return;
-    double* D = dw + (size_t)w * d.wstride;
-    const int* I = iw + (size_t)w * d.istride;
-    for (int k = tid; k < d.nfree; k += BA_T) ba_pose_to_Rt(D + d.oT + ((size_t)st.cur * d.nkf + d.nfixed + k) * 7, sRtf + k * 12);
-    __syncthreads();
-    const int ce = blockIdx.x * BA_T + tid;
-    if (ce >= I[d.oPtFree + d.npt]) return;
-    const int4 r = reinterpret_cast<const int4*>(I + d.oFreeKP)[ce];
-    const int kf = r.x & 63, p = (int)((unsigned)r.x >> 6);
-    const double* q = D + d.oHq + (size_t)p * 12;
+/* Z = Hpl U = (ww Jp)^T (Jl U) (6 x 3, row-major) of one free-keyframe edge from its 16-byte record and its point's
+ * record q = [U (6), U^T bl (3), X (3)]; the same arithmetic as the tile fill of k_ba_schur */
+__device__ __forceinline__ void ba_edge_z(const double* __restrict__ sRtf, const int4 r, const double* __restrict__ q,
+                                          double fx, double fy, double cx, double cy, double delta, double* __restrict__ z) {
     const double u00 = q[0], u01 = q[1], u02 = q[2], u11 = q[3], u12 = q[4], u22 = q[5];
     const double Xp[3] = {q[9], q[10], q[11]};
-    const double delta = (double)sqrtf(5.991f);
     BaLin L;
     double Jp[12], JU[6];
-    ba_linearize(sRtf + kf * 12, Xp, __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w), d.fx, d.fy, d.cx, d.cy, delta, L);
-    ba_jac_pose_iz(L.pc, L.invz, d.fx, d.fy, Jp);
+    ba_linearize(sRtf + (r.x & 63) * 12, Xp, __int_as_float(r.y), __int_as_float(r.z), __int_as_float(r.w), fx, fy, cx, cy, delta, L);
+    ba_jac_pose_iz(L.pc, L.invz, fx, fy, Jp);
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         JU[3 * k] = L.Jl[3 * k] * u00;
         JU[3 * k + 1] = L.Jl[3 * k] * u01 + L.Jl[3 * k + 1] * u11;
         JU[3 * k + 2] = L.Jl[3 * k] * u02 + L.Jl[3 * k + 1] * u12 + L.Jl[3 * k + 2] * u22;
     }
-    double* z = D + d.oZ + (size_t)ce * BA_ZREC;
 #pragma unroll
     for (int a = 0; a < 6; a++) {
         const double p0w = L.ww * Jp[a], p1w = L.ww * Jp[6 + a];
-        const double z0 = p0w * JU[0] + p1w * JU[3], z1 = p0w * JU[1] + p1w * JU[4], z2 = p0w * JU[2] + p1w * JU[5];
-        z[3 * a] = z0; z[3 * a + 1] = z1; z[3 * a + 2] = z2;
-        z[18 + a] = z0 * q[6] + z1 * q[7] + z2 * q[8];
+        z[3 * a] = p0w * JU[0] + p1w * JU[3];
+        z[3 * a + 1] = p0w * JU[1] + p1w * JU[4];
+        z[3 * a + 2] = p0w * JU[2] + p1w * JU[5];
     }
 }
 
 /* one wavefront per block pair (a >= b): A[6a.., 6b..] = [a == b] (Hpp_a + lambda I) - sum_items Z_ea Z_eb^T; the
- * diagonal pairs also give row np of A, the reduced rhs bp_a - sum Z U^T bl */
+ * diagonal pairs also give row np of A, the reduced rhs bp_a - sum Z U^T bl. Lane = item; both Z blocks are rebuilt
+ * from the two 16-byte edge records and the point record they share (128 B per item; a stored Z would be 288 B per
+ * item plus a pass that writes it), the FP64 work this costs is a few percent of the vector peak at these sizes. */
 __global__ void __launch_bounds__(BA_T)
 k_ba_schur_pairs(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, const BaState* __restrict__ states) {
+    __shared__ double sRtf[BA_BIG_MAXF * 12];
     const int w = blockIdx.y, tid = threadIdx.x, lane = tid & 63;
     const BaState st = states[w];
     if (st.status) return;
-    const int pr = blockIdx.x * 4 + (tid >> 6);
-    if (pr >= d.npairs) return; /* wave-uniform, no barriers below */
     double* D = dw + (size_t)w * d.wstride;
     const int* I = iw + (size_t)w * d.istride;
+    for (int k = tid; k < d.nfree; k += BA_T) ba_pose_to_Rt(D + d.oT + ((size_t)st.cur * d.nkf + d.nfixed + k) * 7, sRtf + k * 12);
+    __syncthreads();
+    const int pr = blockIdx.x * 4 + (tid >> 6);
+    if (pr >= d.npairs) return; /* wave-uniform, no barriers below */
     int a = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
     while ((a + 1) * (a + 2) / 2 <= pr) a++;
     while (a * (a + 1) / 2 > pr) a--;
     const int b = pr - a * (a + 1) / 2;
     const int i0 = I[d.oPairStart + pr], i1 = I[d.oPairStart + pr + 1];
     const int2* items = reinterpret_cast<const int2*>(I + d.oPairItems);
-    const double* Z = D + d.oZ;
+    const int4* KP = reinterpret_cast<const int4*>(I + d.oFreeKP);
+    const double delta = (double)sqrtf(5.991f);
     double acc[36], rh[6];
 #pragma unroll
     for (int k = 0; k < 36; k++) acc[k] = 0;
 #pragma unroll
     for (int k = 0; k < 6; k++) rh[k] = 0;
-    for (int it = i0 + lane; it < i1; it += 64) {
-        const int2 e = items[it];
-        const double2* za2 = reinterpret_cast<const double2*>(Z + (size_t)e.x * BA_ZREC);
-        const double2* zb2 = reinterpret_cast<const double2*>(Z + (size_t)e.y * BA_ZREC);
-        double za[18], zb[18];
+    if (i0 < i1) {
+        /* three-level fetch chain (item -> edge records -> point record), each level one round ahead of the next, so
+         * every load has a round of arithmetic to land in; indices past the list are clamped and their lanes add zeros */
+        const int last = i1 - 1;
+        const double* Hq = D + d.oHq;
+        int it = i0 + lane;
+        int2 e2 = items[min(it + 64, last)];
+        int4 ra0, rb0, ra1, rb1;
+        { const int2 e0 = items[min(it, last)]; ra0 = KP[e0.x]; rb0 = KP[e0.y]; }
+        ra1 = KP[e2.x]; rb1 = KP[e2.y];
+        e2 = items[min(it + 128, last)];
+        double2 q0[6];
+        {
+            const double2* q2 = reinterpret_cast<const double2*>(Hq + (size_t)((unsigned)ra0.x >> 6) * 12);
 #pragma unroll
-        for (int k = 0; k < 9; k++) { const double2 v = za2[k]; za[2 * k] = v.x; za[2 * k + 1] = v.y; }
+            for (int k = 0; k < 6; k++) q0[k] = q2[k];
+        }
+        for (int base = i0; base < i1; base += 64, it += 64) {
+            const int2 e3 = items[min(it + 192, last)];
+            const int4 ra2 = KP[e2.x], rb2 = KP[e2.y];
+            double2 q1[6];
+            {
+                const double2* q2 = reinterpret_cast<const double2*>(Hq + (size_t)((unsigned)ra1.x >> 6) * 12);
 #pragma unroll
-        for (int k = 0; k < 9; k++) { const double2 v = zb2[k]; zb[2 * k] = v.x; zb[2 * k + 1] = v.y; }
+                for (int k = 0; k < 6; k++) q1[k] = q2[k];
+            }
+            const bool live = it < i1;
+            double q[12];
 #pragma unroll
-        for (int i = 0; i < 6; i++)
+            for (int k = 0; k < 6; k++) { q[2 * k] = q0[k].x; q[2 * k + 1] = q0[k].y; }
+            double za[18], zb[18];
+            ba_edge_z(sRtf, ra0, q, d.fx, d.fy, d.cx, d.cy, delta, za);
 #pragma unroll
-            for (int j = 0; j < 6; j++)
-                acc[6 * i + j] += za[3 * i] * zb[3 * j] + za[3 * i + 1] * zb[3 * j + 1] + za[3 * i + 2] * zb[3 * j + 2];
-        if (a == b) {
+            for (int k = 0; k < 18; k++) za[k] = live ? za[k] : 0.0;
+            if (a == b) {
 #pragma unroll
-            for (int k = 0; k < 3; k++) { const double2 v = za2[9 + k]; rh[2 * k] += v.x; rh[2 * k + 1] += v.y; }
+                for (int k = 0; k < 18; k++) zb[k] = za[k];
+#pragma unroll
+                for (int k = 0; k < 6; k++) rh[k] += za[3 * k] * q[6] + za[3 * k + 1] * q[7] + za[3 * k + 2] * q[8];
+            } else ba_edge_z(sRtf, rb0, q, d.fx, d.fy, d.cx, d.cy, delta, zb);
+#pragma unroll
+            for (int i = 0; i < 6; i++)
+#pragma unroll
+                for (int j = 0; j < 6; j++)
+                    acc[6 * i + j] += za[3 * i] * zb[3 * j] + za[3 * i + 1] * zb[3 * j + 1] + za[3 * i + 2] * zb[3 * j + 2];
+            ra0 = ra1; rb0 = rb1; ra1 = ra2; rb1 = rb2; e2 = e3;
+#pragma unroll
+            for (int k = 0; k < 6; k++) q0[k] = q1[k];
         }
     }
 #pragma unroll
@@ -973,7 +996,7 @@ k_ba_solve_big(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) 
     const int np = d.np;
     const double lambda = st->lambda;
     double* A = D + d.oBigA; /* [np + 1][np] */
-    __shared__ double invd[BA_PB];
+    __shared__ double invd[BA_PB], Ld[BA_PB * BA_PLD];
     __shared__ int sgood;
     if (tid == 0) sgood = st->sing == 0;
     __syncthreads();
@@ -997,34 +1020,45 @@ k_ba_solve_big(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) 
 #pragma unroll
                 for (int k = j + 1; k < BA_PB; k++) dr[k] -= dr[j] * ba_readlane(dr[j], k);
             }
-            if (r < nb) {
+            if (r < BA_PB) { /* identity-padded copy for the row solves below: no bounds tests in their inner loops */
 #pragma unroll
                 for (int c = 0; c < BA_PB; c++) {
-                    if (c <= r) { Pn[r * BA_PLD + c] = dr[c]; A[(size_t)(k0 + r) * np + k0 + c] = dr[c]; }
+                    Ld[r * BA_PLD + c] = (c <= r) ? dr[c] : 0.0;
                     if (c == r) invd[r] = 1.0 / dr[c];
+                    if (r < nb && c <= r) A[(size_t)(k0 + r) * np + k0 + c] = dr[c];
                 }
             }
             if (r == 0) sgood = good ? 1 : 0;
         }
         __syncthreads();
-        /* rows below the block (and the rhs row): L[r][:] = A[r][:] L_d^-T, every thread its own row, no barriers */
-        for (int r = nb + tid; r < mr; r += BA_ST) {
+        /* rows below the block (and the rhs row): L[r][:] = A[r][:] L_d^-T, every thread its own row, no barriers;
+         * columns >= nb of the panel are zero */
+        static_assert(BA_ST > 6 * BA_BIG_MAXF, "one thread per row below the diagonal block");
+        if (const int r = nb + tid; r < mr) { /* not a loop: the L_d reads below must not be hoisted out of one */
             double row[BA_PB];
             double* Ar = A + (size_t)(k0 + r) * np + k0;
 #pragma unroll
-            for (int c = 0; c < BA_PB; c++) row[c] = (c < nb) ? Ar[c] : 0.0;
-#pragma unroll
-            for (int c = 0; c < BA_PB; c++) {
-                if (c < nb) {
-                    row[c] *= invd[c];
-#pragma unroll
-                    for (int c2 = c + 1; c2 < BA_PB; c2++)
-                        if (c2 < nb) row[c2] -= row[c] * Pn[c2 * BA_PLD + c];
-                }
+            for (int c = 0; c < BA_PB; c++) { /* all 32 loads in flight (A is padded by a panel width), then masked */
+                row[c] = Ar[c];
+                asm volatile("" : "+v"(row[c]));
             }
 #pragma unroll
-            for (int c = 0; c < BA_PB; c++)
-                if (c < nb) { Pn[r * BA_PLD + c] = row[c]; Ar[c] = row[c]; }
+            for (int c = 0; c < BA_PB; c++) row[c] = (c < nb) ? row[c] : 0.0;
+#pragma unroll
+            for (int c = 0; c < BA_PB; c++) {
+                row[c] *= invd[c];
+#pragma unroll
+                for (int c2 = c + 1; c2 < BA_PB; c2++) row[c2] -= row[c] * Ld[c2 * BA_PLD + c];
+                /* pin this column's updates here: left alone, the scheduler issues the broadcast reads of all 496
+                 * steps first and spills them */
+#pragma unroll
+                for (int c2 = c + 1; c2 < BA_PB; c2++) asm volatile("" : "+v"(row[c2]) : : "memory");
+            }
+#pragma unroll
+            for (int c = 0; c < BA_PB; c++) {
+                Pn[r * BA_PLD + c] = row[c];
+                if (c < nb) Ar[c] = row[c];
+            }
         }
         __syncthreads();
         /* trailing update: rows i in [k0 + nb, np], columns j in [k0 + nb, min(i, np - 1)], 4 x 4 tiles (ti >= tj) */
@@ -1038,7 +1072,8 @@ k_ba_solve_big(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) 
                 const int tj = t - ti * (ti + 1) / 2;
                 const int ra = nb + 4 * ti, rb = nb + 4 * tj; /* panel rows of the tile's rows / columns */
                 double acc[4][4] = {};
-                for (int c = 0; c < nb; c++) {
+#pragma unroll 4
+                for (int c = 0; c < BA_PB; c++) { /* columns >= nb are zero */
                     double av[4], bv[4];
 #pragma unroll
                     for (int q = 0; q < 4; q++) { av[q] = Pn[min(ra + q, last) * BA_PLD + c]; bv[q] = Pn[min(rb + q, last) * BA_PLD + c]; }
@@ -1293,8 +1328,7 @@ static void ba_dims(BaDims& d, int W, const double K[4], int nkf, int nfixed, in
     d.oPartKF = take(27ull * std::max(d.nfree, 1) * d.kfChunks);
     d.oPartP = take(4ull * d.nblkP);
     d.oPartS = take(d.big ? 0 : 4096ull * d.G);
-    d.oZ = take(d.big ? (unsigned long long)BA_ZREC * obs_pitch : 0);
-    d.oBigA = take(d.big ? (unsigned long long)(d.np + 1) * d.np : 0);
+    d.oBigA = take(d.big ? (unsigned long long)(d.np + 1) * d.np + 32 : 0); /* + BA_PB: the last panel's row loads */
     d.wstride = o;
     unsigned long long io = 0;
     auto itake = [&](unsigned long long n) { unsigned long long r = io; io += (n + 3) & ~3ull; return r; };
@@ -1377,9 +1411,6 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
             hipLaunchKernelGGL(k_ba_hinv, dim3(d.nblkP, W), dim3(BA_T), 0, s, d, dw, states);
             tb_prof_end(ctx);
             if (d.big) {
-                tb_prof_begin(ctx, "k_ba_zbuild");
-                hipLaunchKernelGGL(k_ba_zbuild, dim3((obs_pitch + BA_T - 1) / BA_T, W), dim3(BA_T), 0, s, d, dw, iw, states);
-                tb_prof_end(ctx);
                 tb_prof_begin(ctx, "k_ba_schur_pairs");
                 hipLaunchKernelGGL(k_ba_schur_pairs, dim3((d.npairs + 3) / 4, W), dim3(BA_T), 0, s, d, dw, iw, states);
                 tb_prof_end(ctx);
