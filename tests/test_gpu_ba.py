@@ -155,3 +155,32 @@ def test_local_ba_unobserved_points_and_empty_window(ctx):
         io, Po, Xo, so = oracle.local_ba(K, ba.host["poses"][w], 2, ba.host["pts"][w], ba.host["obs"][w, :n], 6)
         _close(ba.poses[w].cpu().numpy().reshape(-1, 4, 4), Po)
         _close(ba.pts[w].cpu().numpy(), Xo)
+
+
+def test_local_ba_large_window_mixed_batch(ctx):
+    """Large windows (18 free keyframes) side by side in one batch: an ordinary one, one without observations (left as it
+    is), one with a repeated (keyframe, point) pair (flagged in stats[7], left as it is), one with unobserved points."""
+    import torch
+    from trackingbench_slam_amd.ba import BatchedLocalBA
+    ba = BatchedLocalBA(ctx, 4, nkf=20, npt=300, iters=5, seed=7, device=torch.device("cuda", 0), distinct=4)
+    obs = ba.host["obs"].copy()
+    cnt = ba.host["counts"].copy()
+    cnt[1] = 0
+    obs[2, 11] = obs[2, 10]                                     # same (kf, pt) twice
+    keep = ~np.isin(obs[3, :cnt[3]]["pt"], (0, 17, 299))        # three points nobody sees
+    o3 = obs[3, :cnt[3]][keep]
+    obs[3, :len(o3)] = o3
+    cnt[3] = len(o3)
+    ba.obs.copy_(torch.from_numpy(obs.view(np.uint8).reshape(ba.obs.shape)))
+    ba.counts.copy_(torch.from_numpy(cnt))
+    ba.run()
+    torch.cuda.synchronize()
+    st = ba.stats.cpu().numpy()
+    assert st[2, 7] == -1 and st[0, 7] != -1 and st[3, 7] != -1
+    for w in (1, 2):
+        assert torch.allclose(ba.poses[w], ba.poses0[w], rtol=0, atol=1e-6) and torch.equal(ba.pts[w], ba.pts0[w])
+    for w, o in ((0, obs[0, :cnt[0]]), (3, o3)):
+        io, Po, Xo, so = oracle.local_ba(K, ba.host["poses"][w], 2, ba.host["pts"][w], o, 5)
+        _close(ba.poses[w].cpu().numpy().reshape(-1, 4, 4), Po)
+        _close(ba.pts[w].cpu().numpy(), Xo)
+    assert torch.equal(ba.pts[3][[0, 17, 299]], ba.pts0[3][[0, 17, 299]])
