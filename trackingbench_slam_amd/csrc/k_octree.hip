@@ -22,7 +22,7 @@
 #include "tb_internal.h"
 #include "tb_device.h"
 
-#define OT_T 256
+#define OT_TMAX 1024 /* launched with 256 threads (default) or 1024 (large images: the per-key loops dominate) */
 
 struct OtNode { short x0, y0, x1, y1; };
 
@@ -67,7 +67,7 @@ __device__ __forceinline__ OtNode ot_child(const OtNode p, int q) {
 __device__ int ot_divide(OtLds& S, int cur, int L, int D, const uint32_t* __restrict__ rec, uint32_t* __restrict__ knode,
                          int n, const float* __restrict__ exitk, int32_t* __restrict__ enode, int n_exit,
                          int* nToExpand, int* sh_counter) {
-    const int tid = threadIdx.x;
+    const int tid = threadIdx.x, OT_T = blockDim.x;
     const OtNode* nb = S.nb[cur];
     for (int i = tid; i < 4 * D; i += OT_T) S.childCnt[i] = 0;
     if (tid == 0) *sh_counter = 0;
@@ -150,12 +150,12 @@ __device__ int ot_divide(OtLds& S, int cur, int L, int D, const uint32_t* __rest
     return C + Sv;
 }
 
-__global__ void __launch_bounds__(OT_T)
+__global__ void __launch_bounds__(OT_TMAX)
 k_octree(PlanGeom g, const uint32_t* __restrict__ cand, const int32_t* __restrict__ candCount,
          uint32_t* __restrict__ knodeAll, const float* __restrict__ exitk, int n_exit, int32_t* __restrict__ enodeAll,
          uint32_t* __restrict__ sel, int32_t* __restrict__ selCount, int capMax) {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    const int level = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+    const int level = blockIdx.x, b = blockIdx.y, tid = threadIdx.x, OT_T = blockDim.x;
     const LevelGeom& G = g.lv[level];
     const int n = min(candCount[b * TB_MAX_LEVELS + level], G.candCap);
     const uint32_t* rec = cand + (size_t)b * g.candPerImage + G.candOff;
@@ -189,8 +189,8 @@ k_octree(PlanGeom g, const uint32_t* __restrict__ cand, const int32_t* __restric
         S.tmp = (int*)p;
     }
     /* all LDS lives in the dynamic region (keeps its base 16-byte aligned) */
-    int& sh_counter = S.tmp[16];
-    int& sh_val = S.tmp[17];
+    int& sh_counter = S.tmp[32]; /* behind the scan scratch (one int per wavefront + 1) */
+    int& sh_val = S.tmp[33];
     const int N = G.quota;
     const int nIni = G.nIni;
     const float hX = G.hX;
@@ -400,8 +400,12 @@ int tbk_octree(tb_extractor* ex, int n, int n_exit) {
         attr_set = true;
     }
     dim3 grid(ex->g.nlevels, n);
+    /* one workgroup walks all candidates of its level once per divide step: on large images (candidates grow with the
+     * pixel count) those loops, not the node tables, set the time, and four times the threads are worth the idle lanes
+     * in the scans (3840x2160 / 8000 keypoints: 48 -> see DESIGN.md; 1280x720 stays at 256) */
+    const int threads = (long long)ex->g.lv[0].w * ex->g.lv[0].h >= (1 << 21) ? OT_TMAX : 256;
     tb_prof_begin(ctx, "k_octree");
-    hipLaunchKernelGGL(k_octree, grid, dim3(OT_T), lds, ctx->stream, ex->g, ex->d_cand, ex->d_candCount, ex->d_knode,
+    hipLaunchKernelGGL(k_octree, grid, dim3(threads), lds, ctx->stream, ex->g, ex->d_cand, ex->d_candCount, ex->d_knode,
                        ex->d_exit, n_exit, ex->d_enode, ex->d_sel, ex->d_selCount, capMax);
     tb_prof_end(ctx);
     TB_HIP(ctx, hipGetLastError());
