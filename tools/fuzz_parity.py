@@ -81,9 +81,11 @@ def main():
         if not (ng == no and np.array_equal(og, oo) and np.allclose(Tg, To, rtol=1e-6, atol=1e-6)):
             fail("pose_opt", n=n, inl=(ng, no), dT=float(np.abs(Tg - To).max()))
         nkf, nfx = int(rng.integers(3, 13)), int(rng.integers(0, 3))
+        if it % 3 == 0:  # a large window (11..64 free keyframes: the block-pair Schur kernel and the panel solve)
+            nkf = int(rng.integers(13, 67))
         nfx = min(nfx, nkf - 1)
-        if nkf - nfx <= 10:
-            npt, per = int(rng.integers(20, 1500)), int(rng.integers(2, nkf + 1))
+        if nkf - nfx <= 64:
+            npt, per = int(rng.integers(20, 1500)), int(rng.integers(2, min(nkf, 14) + 1))
             Pt, Pi, Xt, Xi, bo = synth.ba_problem(int(rng.integers(0, 10 ** 6)), nkf, npt, K, obs_per_pt=per)
             itn = int(rng.integers(1, 8))
             ig, Pg, Xg, sg = ctx.local_ba(K, Pi, nfx, Xi, bo, itn)
