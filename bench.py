@@ -75,11 +75,18 @@ def schur_roofs(ba_pts, nwin, ba_kf, free_edges, nfixed=2):
     return flops, nbytes
 
 
-def pmc_traffic(kernel, units):
+def pmc_traffic(kernel, units, geometry=None):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/, collected with 64
     images-pairs / BA windows per launch, the guide's gfx950 FETCH_SIZE correction applied), scaled to this run's
-    units per launch; None if absent."""
+    units per launch; None if absent. The passes are per workload: 1280x720 / 10-KF windows by default, and one
+    file per other measured geometry (`*_hbm_traffic_pmc_<W>x<H>.json`)."""
     path = os.path.join(ROOT, "profiles", "r01_hbm_traffic_pmc.json")
+    if geometry is not None and tuple(geometry) != (1280, 720):
+        import glob
+        hits = sorted(glob.glob(os.path.join(ROOT, "profiles", "*_hbm_traffic_pmc_%dx%d.json" % tuple(geometry))))
+        if not hits:
+            return None
+        path = hits[-1]
     try:
         with open(path) as f:
             rec = json.load(f)["kernels"]
@@ -242,7 +249,7 @@ def main():
             fl, nb = schur_roofs(args.ba_pts, nwin, args.ba_kf, free_edges)
             launch_s = tot_ms / max(calls, 1) / 1e3
             tf, gbs = fl / 1e12 / launch_s, nb / 1e9 / launch_s
-            common = {"kernel": name, "traffic": pmc_traffic(name, nwin), "launches_per_step": launches_per_step,
+            common = {"kernel": name, "traffic": pmc_traffic(name, nwin, (args.width, args.height)), "launches_per_step": launches_per_step,
                       "avg_launch_ms": round(1e3 * launch_s, 5), "algorithmic_bytes_per_launch": int(nb),
                       "algorithmic_flops_per_launch": fl, "windows_per_launch": nwin,
                       "hbm_frac": round(gbs / HBM_PEAK_GBS, 5), "mfma_f64_frac": round(tf / F64_MFMA_PEAK_TFLOPS, 5),
@@ -271,7 +278,9 @@ def main():
                 abytes = per_trial * max(calls // max(args.steps, 1), 1) // max(len(pipe.bas), 1)
             achieved = (abytes / 1e9) / (avg_ms_per_step / 1e3) if avg_ms_per_step > 0 else 0.0
             roofline = {"bound": "hbm", "kernel": name, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                        "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": pmc_traffic(name, args.frames),
+                        "frac": round(achieved / HBM_PEAK_GBS, 5),
+                        "traffic": pmc_traffic(name, pipe.bas[0][0].W if name.startswith("k_ba_") and pipe.bas else args.frames,
+                                               (args.width, args.height)),
                         "launches_per_step": launches_per_step, "avg_launch_ms": round(tot_ms / max(calls, 1), 5),
                         "algorithmic_bytes_per_step": abytes, "kernels_ms_per_step": kern_ms,
                         "isolated_kernels_ms_per_step": {k: round(v, 4) for k, v in sorted(iso_step.items())}}
