@@ -31,6 +31,16 @@ def test_local_ba_kat(ctx, golden):
     assert it == int(golden["ba_stats"][0])
 
 
+def test_local_ba_large_window_kat(ctx):
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_golden_ba_large_v1.npz"), allow_pickle=False)
+    it, P, X, st = ctx.local_ba(K, g["ba_poses_init"], 2, g["ba_pts_init"], g["ba_obs"], 6)
+    _close(P, g["ba_poses"])
+    _close(X, g["ba_pts"])
+    assert np.isclose(st[2], g["ba_stats"][2], rtol=1e-6) and np.isclose(st[1], g["ba_stats"][1], rtol=1e-9)
+    assert it == int(g["ba_stats"][0])
+
+
 @pytest.mark.parametrize("seed,nkf,npt,nfixed,iters", [(1, 5, 200, 2, 10), (2, 10, 5000, 2, 10), (3, 3, 50, 1, 5),
                                                         (4, 10, 1000, 0, 10), (5, 12, 700, 2, 3), (6, 4, 33, 2, 10)])
 def test_local_ba_vs_cpu_solver(ctx, seed, nkf, npt, nfixed, iters):

@@ -85,3 +85,14 @@ def test_synthetic_generator_is_pinned(golden):
     lv, sf = oracle.pyramid(S, 8, 0.8)
     k, d, _ = oracle.orb_extract(lv, sf, 1000, 80, 30)
     assert np.array_equal(k, golden["synth5_kps"]) and np.array_equal(d, golden["synth5_desc"])
+
+
+def test_local_ba_large_window_kat():
+    """24-keyframe window (22 free): the oracle against its committed known-answer vector (tools/gen_golden.py)."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "oracle_golden_ba_large_v1.npz"), allow_pickle=False)
+    K = (718.856, 718.856, 607.1928, 185.2157)
+    it, P, X, st = oracle.local_ba(K, g["ba_poses_init"], 2, g["ba_pts_init"], g["ba_obs"], 6)
+    assert np.allclose(P, g["ba_poses"], rtol=1e-6, atol=1e-7)
+    assert np.allclose(X, g["ba_pts"], rtol=1e-6, atol=1e-6)
+    assert np.allclose(st[2], g["ba_stats"][2], rtol=1e-6) and it == int(g["ba_stats"][0])

@@ -84,6 +84,19 @@ def main():
     path = os.path.join(GOLDEN, "oracle_golden_v1.npz")
     np.savez_compressed(path, **out)
     print("wrote", path, os.path.getsize(path), "bytes;", len(out), "arrays")
+    large_ba()
+
+
+def large_ba():
+    """Known-answer vector of a large local-BA window (22 free keyframes: the block-pair Schur / panel-solve path of
+    the HIP library), its own file so that oracle_golden_v1.npz stays as committed."""
+    K = (718.856, 718.856, 607.1928, 185.2157)
+    Pt, Pi, Xt, Xi, bo = synth.ba_problem(41, 24, 400, K, obs_per_pt=8)
+    it, P, X, st = oracle.local_ba(K, Pi, 2, Xi, bo, 6)
+    out = dict(ba_obs=bo, ba_poses_init=Pi, ba_pts_init=Xi, ba_poses=P, ba_pts=X, ba_stats=st)
+    path = os.path.join(GOLDEN, "oracle_golden_ba_large_v1.npz")
+    np.savez_compressed(path, **out)
+    print("wrote", path, os.path.getsize(path), "bytes;", len(out), "arrays")
 
 
 if __name__ == "__main__":
