@@ -201,6 +201,29 @@ int tb_pose_opt(tb_ctx* ctx, const double K[4], const float Tcw_in[16], const tb
 int tb_pose_opt_batch_dev(tb_ctx* ctx, int nproblems, const double K[4], const float* Tcw_in,
                           const tb_obs* obs, const int32_t* counts, int obs_pitch, uint8_t* outlier,
                           float* Tcw_out, int32_t* n_inliers, double* stats);
+/* SURVEY 8(f) row 2, first part -- the optical-flow matcher.
+ * tb_optical_flow_pyr_lk replaces the call cv::calcOpticalFlowPyrLK(prev, next, prev_pts, next_pts, status, err,
+ * Size(win, win), max_level) of matcher.cpp:744 (default criteria: 30 iterations / eps 0.01, flags 0,
+ * minEigThreshold 1e-4). win must be 21 (the reference's), max_level 0..5. Host pointers; prev_pts / next_pts are
+ * n (x, y) pairs; err nullable; *top_level (nullable) = coarsest pyramid level used. OpenCV is not part of the
+ * reference tree: the routine is restated, parity UNPINNED (oracle/oracle_flow.cpp says what was restated and the one
+ * deliberate difference, exact integer window sums).
+ * tb_search_by_opflow replaces Matcher::searchByOPFlow(F1, F2, cur_points, equalized, reject), matcher.cpp:724-768:
+ * tracks F2's keys (keys2_xy) from img2 into img1, clears the points that leave F1's frame (cam1->width / height,
+ * CameraModel.h:33-39) and returns DMatch(i, i) records (distance FLT_MAX, imgIdx -1, as a default-constructed
+ * cv::DMatch). equalized (Frame::Equalize = CLAHE) and reject (rejectWithF = RANSAC fundamental matrix, needs cv::RNG)
+ * are NOT built: non-zero gives TB_EUNSUPPORTED. cur_points: n (x, y) pairs out. */
+int tb_optical_flow_pyr_lk(tb_ctx* ctx, const uint8_t* prev, const uint8_t* next, int width, int height, int stride,
+                           const float* prev_pts, int n, int win, int max_level, float* next_pts, uint8_t* status,
+                           float* err, int* top_level);
+int tb_search_by_opflow(tb_ctx* ctx, const uint8_t* img1, const uint8_t* img2, int width, int height, int stride,
+                        const tb_camera* cam1, const float* keys2_xy, int n, int equalized, int reject,
+                        float* cur_points, tb_match* out, int cap, int* count);
+/* Device-resident form of the tracker: images, points and outputs in HBM, asynchronous on the context's stream. */
+int tb_optical_flow_pyr_lk_dev(tb_ctx* ctx, const uint8_t* prev, const uint8_t* next, int width, int height, int stride,
+                               const float* prev_pts, int n, int win, int max_level, float* next_pts, uint8_t* status,
+                               float* err);
+
 /* Multi-keyframe local BA -- north-star extension, NO reference counterpart.
  * poses: nkf x 16 (in/out, first nfixed held), pts: npt x 3 (in/out). A point is observed at most once per
  * keyframe (repeated (kf, pt) pairs are rejected like out-of-range indices); at most 64 free keyframes (128 in all),

@@ -315,3 +315,41 @@ def local_ba(K, poses, nfixed, pts, obs, iters=10):
     n = _chk(lib().orc_local_ba(_p(K), len(poses), int(nfixed), _p(poses), len(pts), _p(pts), _p(obs), len(obs),
                                 int(iters), _p(stats)))
     return n, poses.reshape(-1, 4, 4), pts, stats
+
+
+def pyr_down(img):
+    """cv::pyrDown (one level of cv::buildOpticalFlowPyramid)."""
+    img = _u8(img)
+    h, w = img.shape
+    out = np.zeros(((h + 1) // 2, (w + 1) // 2), np.uint8)
+    _chk(lib().orc_pyr_down(_p(img), w, h, w, _p(out), out.shape[1]))
+    return out
+
+
+def optical_flow_pyr_lk(prev, nxt, prev_pts, win=21, max_level=3):
+    """cv::calcOpticalFlowPyrLK(prev, next, prev_pts, ..., Size(win, win), max_level), default criteria / flags
+    (restated from OpenCV 3.3, parity unpinned). Returns (next_pts [n,2], status [n] u8, err [n], top level used)."""
+    prev, nxt = _u8(prev), _u8(nxt)
+    assert prev.shape == nxt.shape
+    h, w = prev.shape
+    pts = np.ascontiguousarray(prev_pts, np.float32).reshape(-1, 2)
+    n = len(pts)
+    out = np.zeros((max(n, 1), 2), np.float32)
+    status = np.zeros(max(n, 1), np.uint8)
+    err = np.zeros(max(n, 1), np.float32)
+    top = _chk(lib().orc_optical_flow_pyr_lk(_p(prev), _p(nxt), w, h, w, _p(pts), n, int(win), int(max_level), _p(out),
+                                             _p(status), _p(err)))
+    return out[:n], status[:n], err[:n], top
+
+
+def search_by_opflow(img1, img2, cam1, keys2_xy):
+    """Matcher::searchByOPFlow(F1, F2, cur_points, equalized=False, reject=False), matcher.cpp:724-768.
+    Returns (cur_points [n,2], matched indices i (queryIdx = trainIdx = i))."""
+    img1, img2 = _u8(img1), _u8(img2)
+    h, w = img1.shape
+    pts = np.ascontiguousarray(keys2_xy, np.float32).reshape(-1, 2)
+    n = len(pts)
+    cur = np.zeros((max(n, 1), 2), np.float32)
+    idx = np.zeros(max(n, 1), np.int32)
+    m = _chk(lib().orc_search_by_opflow(_p(img1), _p(img2), w, h, w, _p(cam1), _p(pts), n, _p(cur), _p(idx)))
+    return cur[:n], idx[:m].copy()

@@ -97,6 +97,15 @@ int orc_pose_opt(const double K[4], const float Tcw_in[16], const tb_obs* obs, i
 int orc_local_ba(const double K[4], int nkf, int nfixed, float* poses, int npt, float* pts,
                  const tb_ba_obs* obs, int nobs, int iters, double* stats /* nullable, 8 doubles */);
 
+/* ---- oracle_flow.cpp: Matcher::searchByOPFlow (matcher.cpp:724-768) and the cv::calcOpticalFlowPyrLK call it makes
+ * (OpenCV 3.3, not in the tree: restated, PARITY UNPINNED -- see the file header). */
+int orc_pyr_down(const uint8_t* src, int w, int h, int stride, uint8_t* dst, int dstride);
+/* returns the top pyramid level used (<= max_level), or < 0 on error */
+int orc_optical_flow_pyr_lk(const uint8_t* prev, const uint8_t* next, int w, int h, int stride, const float* prev_pts, int n,
+                            int win, int max_level, float* next_pts, uint8_t* status, float* err /* nullable */);
+int orc_search_by_opflow(const uint8_t* img1, const uint8_t* img2, int w, int h, int stride, const tb_camera* cam1,
+                         const float* keys2_xy, int n, float* cur_points, int32_t* match_idx);
+
 #ifdef __cplusplus
 }
 #endif

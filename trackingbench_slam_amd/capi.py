@@ -39,6 +39,7 @@ EXPORTS = [
     "tb_search_by_violence", "tb_search_by_projection", "tb_search_by_projection_map", "tb_frame_grid_batch_dev",
     "tb_search_by_projection_batch_dev", "tb_search_by_projection_map_batch_dev",
     "tb_search_by_violence_batch_dev", "tb_pose_opt", "tb_pose_opt_batch_dev", "tb_local_ba", "tb_local_ba_batch_dev",
+    "tb_optical_flow_pyr_lk", "tb_optical_flow_pyr_lk_dev", "tb_search_by_opflow",
 ]
 
 
@@ -267,6 +268,38 @@ class Context:
                                                C.c_float(nratio), int(histo_len), int(check_orientation), _p(out), len(out),
                                                C.byref(n)))
         return out[:n.value].copy()
+
+    def optical_flow_pyr_lk(self, prev, nxt, prev_pts, win=21, max_level=3):
+        """cv::calcOpticalFlowPyrLK as Matcher::searchByOPFlow calls it (reference matcher.cpp:744).
+        Returns (next_pts [n,2], status [n] u8, err [n], coarsest level used)."""
+        prev = np.ascontiguousarray(prev, np.uint8); nxt = np.ascontiguousarray(nxt, np.uint8)
+        assert prev.ndim == 2 and prev.shape == nxt.shape
+        h, w = prev.shape
+        pts = np.ascontiguousarray(prev_pts, np.float32).reshape(-1, 2)
+        n = len(pts)
+        out = np.zeros((max(n, 1), 2), np.float32)
+        status = np.zeros(max(n, 1), np.uint8)
+        err = np.zeros(max(n, 1), np.float32)
+        top = C.c_int(0)
+        self.check(lib().tb_optical_flow_pyr_lk(self._h, _p(prev), _p(nxt), w, h, w, _p(pts), n, int(win), int(max_level),
+                                                _p(out), _p(status), _p(err), C.byref(top)))
+        return out[:n], status[:n], err[:n], top.value
+
+    def search_by_opflow(self, img1, img2, cam1, keys2_xy, equalized=False, reject=False):
+        """Matcher::searchByOPFlow(F1, F2, cur_points, equalized, reject) (reference matcher.cpp:724-768).
+        Returns (cur_points [n,2], DMatch records)."""
+        img1 = np.ascontiguousarray(img1, np.uint8); img2 = np.ascontiguousarray(img2, np.uint8)
+        assert img1.ndim == 2 and img1.shape == img2.shape
+        h, w = img1.shape
+        cam1 = np.ascontiguousarray(cam1, CAMERA)
+        pts = np.ascontiguousarray(keys2_xy, np.float32).reshape(-1, 2)
+        n = len(pts)
+        cur = np.zeros((max(n, 1), 2), np.float32)
+        out = np.zeros(max(n, 1), MATCH)
+        cnt = C.c_int(0)
+        self.check(lib().tb_search_by_opflow(self._h, _p(img1), _p(img2), w, h, w, _p(cam1), _p(pts), n, int(equalized),
+                                             int(reject), _p(cur), _p(out), len(out), C.byref(cnt)))
+        return cur[:n], out[:cnt.value].copy()
 
     def search_by_projection(self, Tcw1, cam1, img1_w, img1_h, k1, d1, taken1, k2, mp2, mp2_desc, scale_factors, nratio,
                              th_high=100, histo_len=30, check_orientation=True):

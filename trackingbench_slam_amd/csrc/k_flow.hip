@@ -1,0 +1,257 @@
+/* SURVEY 8f row 2, first part -- pyramidal Lucas-Kanade tracking for Matcher::searchByOPFlow.
+ *
+ * Reference call site: src/matchers/matcher.cpp:744
+ *     cv::calcOpticalFlowPyrLK(img2, img1, F2->GetCVKeys(), cur_points, status, err, cv::Size(21, 21), 3);
+ * The routine itself is OpenCV 3.3 (not in the reference tree): restated from its published structure -- 5x5 Gaussian
+ * pyrDown pyramid read with BORDER_REFLECT_101 padding, Scharr derivatives (zero outside the image), W_BITS = 14
+ * fixed-point bilinear weights, iterative 2x2 solve, 30 iterations / eps 0.01, minEigThreshold 1e-4, L1 error.
+ * The window sums (A11, A12, A22, b1, b2, error) are exact 64-bit INTEGER sums converted to float once (OpenCV adds
+ * float products in a SIMD-path dependent order): the result does not depend on the order of summation, so a
+ * wavefront tree sum and a sequential loop agree bit for bit.
+ *
+ *   k_pyr_down  : thread per destination pixel, 25 taps, (sum + 128) >> 8
+ *   k_lk_track  : ONE WAVEFRONT PER POINT, all pyramid levels in one launch. Per level the 24 x 24 source patch goes to
+ *                 LDS once (reflect-101 indexing), the 22 x 22 Scharr derivatives are formed from it in LDS, every lane
+ *                 keeps its 7 of the 441 interpolated window samples (I, Ix, Iy) in registers; each iteration stages
+ *                 the 22 x 22 patch of the second image in LDS and reduces two 64-bit sums over the wavefront. No
+ *                 derivative images and no padded pyramid copies exist in HBM.
+ * Bound: latency / LDS (a few KB per point per iteration); no 8d row. */
+#include "tb_internal.h"
+#include "tb_device.h"
+
+#define LK_WIN 21
+#define LK_PW (LK_WIN + 3)      /* source patch: window + 1 for the bilinear neighbour + 1 on each side for Scharr */
+#define LK_DW (LK_WIN + 1)      /* derivative / second-image patch */
+#define LK_NPX (LK_WIN * LK_WIN)
+#define LK_PER ((LK_NPX + 63) / 64)
+#define LK_MAX_LEVELS 6
+
+struct LkLevels {
+    const uint8_t* prev[LK_MAX_LEVELS];
+    const uint8_t* next[LK_MAX_LEVELS];
+    int w[LK_MAX_LEVELS], h[LK_MAX_LEVELS], stride[LK_MAX_LEVELS];
+    int top; /* coarsest level used */
+};
+
+__device__ __forceinline__ int lk_refl(int p, int n) { /* BORDER_REFLECT_101 for |offset| < n */
+    p = p < 0 ? -p : p;
+    return p >= n ? 2 * n - 2 - p : p;
+}
+
+__global__ void __launch_bounds__(256)
+k_pyr_down(const uint8_t* __restrict__ src, int sw, int sh, int sstride, uint8_t* __restrict__ dst, int dw, int dh, int dstride) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= dw || y >= dh) return;
+    int col[5];
+#pragma unroll
+    for (int i = 0; i < 5; i++) col[i] = lk_refl(2 * x + i - 2, sw);
+    int sum = 0;
+#pragma unroll
+    for (int j = 0; j < 5; j++) {
+        const uint8_t* row = src + (size_t)lk_refl(2 * y + j - 2, sh) * sstride;
+        const int kj = (j == 0 || j == 4) ? 1 : (j == 2 ? 6 : 4);
+        sum += kj * ((int)row[col[0]] + 4 * (int)row[col[1]] + 6 * (int)row[col[2]] + 4 * (int)row[col[3]] + (int)row[col[4]]);
+    }
+    dst[(size_t)y * dstride + x] = (uint8_t)((sum + 128) >> 8);
+}
+
+__device__ __forceinline__ long long lk_wave_sum(long long v) { /* integer: any order gives the same sum */
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) {
+        const int lo = __shfl_xor((int)(v & 0xffffffffll), d, 64), hi = __shfl_xor((int)(v >> 32), d, 64);
+        v += ((long long)hi << 32) | (unsigned int)lo;
+    }
+    return v;
+}
+__device__ __forceinline__ int lk_descale(int v, int n) { return (v + (1 << (n - 1))) >> n; }
+struct LkW { int w00, w01, w10, w11; };
+__device__ __forceinline__ LkW lk_weights(float a, float b) {
+    LkW W;
+    W.w00 = __float2int_rn((1.f - a) * (1.f - b) * 16384.f);
+    W.w01 = __float2int_rn(a * (1.f - b) * 16384.f);
+    W.w10 = __float2int_rn((1.f - a) * b * 16384.f);
+    W.w11 = 16384 - W.w00 - W.w01 - W.w10;
+    return W;
+}
+
+__global__ void __launch_bounds__(64)
+k_lk_track(LkLevels L, const float* __restrict__ prev_pts, int n, float* __restrict__ next_pts, uint8_t* __restrict__ status,
+           float* __restrict__ err) {
+    __shared__ int Ip[LK_PW * LK_PW];        /* source patch, position (x, y) of the window at [(y + 1) * LK_PW + x + 1] */
+    __shared__ int dX[LK_DW * LK_DW], dY[LK_DW * LK_DW];
+    __shared__ int Jp[LK_DW * LK_DW];
+    const int i = blockIdx.x, lane = threadIdx.x;
+    if (i >= n) return;
+    const float FLT_SCALE = 1.f / (1 << 20);
+    const float half = (LK_WIN - 1) * 0.5f;
+    const float ptx = prev_pts[2 * i], pty = prev_pts[2 * i + 1];
+    float outx = 0.f, outy = 0.f, errv = 0.f;
+    int st = 1;
+    /* this lane's window samples: p = lane + 64 k */
+    int wy[LK_PER], wx[LK_PER];
+#pragma unroll
+    for (int k = 0; k < LK_PER; k++) { const int p = lane + 64 * k; wy[k] = p / LK_WIN; wx[k] = p - wy[k] * LK_WIN; }
+    for (int level = L.top; level >= 0; level--) {
+        const uint8_t* I = L.prev[level];
+        const uint8_t* J = L.next[level];
+        const int w = L.w[level], h = L.h[level], stride = L.stride[level];
+        const float sc = (float)(1. / (1 << level));
+        float px = ptx * sc, py = pty * sc, nx, ny;
+        if (level == L.top) { nx = px; ny = py; }
+        else { nx = outx * 2.f; ny = outy * 2.f; }
+        outx = nx; outy = ny;
+        px -= half; py -= half;
+        const int ix = (int)floorf(px), iy = (int)floorf(py);
+        if (ix < -LK_WIN || ix >= w || iy < -LK_WIN || iy >= h) { /* wave-uniform */
+            if (level == 0) { st = 0; errv = 0.f; }
+            continue;
+        }
+        __syncthreads(); /* the previous level is done with the LDS patches */
+        for (int t = lane; t < LK_PW * LK_PW; t += 64) {
+            const int yy = t / LK_PW, xx = t - yy * LK_PW;
+            Ip[t] = I[(size_t)lk_refl(iy - 1 + yy, h) * stride + lk_refl(ix - 1 + xx, w)];
+        }
+        __syncthreads();
+        for (int t = lane; t < LK_DW * LK_DW; t += 64) {
+            const int yy = t / LK_DW, xx = t - yy * LK_DW;
+            const int X = ix + xx, Y = iy + yy;
+            int gx = 0, gy = 0;
+            if (X >= 0 && X < w && Y >= 0 && Y < h) {
+                const int* c = Ip + (yy + 1) * LK_PW + xx + 1;
+                const int a00 = c[-LK_PW - 1], a01 = c[-LK_PW], a02 = c[-LK_PW + 1], a10 = c[-1], a12 = c[1];
+                const int a20 = c[LK_PW - 1], a21 = c[LK_PW], a22 = c[LK_PW + 1];
+                gx = 3 * (a02 - a00) + 10 * (a12 - a10) + 3 * (a22 - a20);
+                gy = 3 * (a20 - a00) + 10 * (a21 - a01) + 3 * (a22 - a02);
+            }
+            dX[t] = gx; dY[t] = gy;
+        }
+        __syncthreads();
+        LkW W = lk_weights(px - (float)ix, py - (float)iy);
+        int Iw[LK_PER], Ix[LK_PER], Iy[LK_PER];
+        long long A11 = 0, A12 = 0, A22 = 0;
+#pragma unroll
+        for (int k = 0; k < LK_PER; k++) {
+            Iw[k] = Ix[k] = Iy[k] = 0;
+            if (lane + 64 * k < LK_NPX) {
+                const int* c = Ip + (wy[k] + 1) * LK_PW + wx[k] + 1;
+                const int d = wy[k] * LK_DW + wx[k];
+                Iw[k] = lk_descale(c[0] * W.w00 + c[1] * W.w01 + c[LK_PW] * W.w10 + c[LK_PW + 1] * W.w11, 9);
+                Ix[k] = lk_descale(dX[d] * W.w00 + dX[d + 1] * W.w01 + dX[d + LK_DW] * W.w10 + dX[d + LK_DW + 1] * W.w11, 14);
+                Iy[k] = lk_descale(dY[d] * W.w00 + dY[d + 1] * W.w01 + dY[d + LK_DW] * W.w10 + dY[d + LK_DW + 1] * W.w11, 14);
+                A11 += (long long)Ix[k] * Ix[k]; A12 += (long long)Ix[k] * Iy[k]; A22 += (long long)Iy[k] * Iy[k];
+            }
+        }
+        A11 = lk_wave_sum(A11); A12 = lk_wave_sum(A12); A22 = lk_wave_sum(A22);
+        const float a11 = (float)A11 * FLT_SCALE, a12 = (float)A12 * FLT_SCALE, a22 = (float)A22 * FLT_SCALE;
+        float D = a11 * a22 - a12 * a12;
+        const float minEig = (a22 + a11 - sqrtf((a11 - a22) * (a11 - a22) + 4.f * a12 * a12)) / (float)(2 * LK_WIN * LK_WIN);
+        if (minEig < 1e-4f || D < 1.1920929e-07f /* FLT_EPSILON */) {
+            if (level == 0) st = 0;
+            continue;
+        }
+        D = 1.f / D;
+        nx -= half; ny -= half;
+        float pdx = 0.f, pdy = 0.f;
+        /* the second image's patch at (jx, jy) -> per-lane residuals against the stored window */
+        auto residuals = [&](int jx, int jy, const LkW& Wj, long long& s1, long long& s2, long long& sabs) {
+            __syncthreads();
+            for (int t = lane; t < LK_DW * LK_DW; t += 64) {
+                const int yy = t / LK_DW, xx = t - yy * LK_DW;
+                Jp[t] = J[(size_t)lk_refl(jy + yy, h) * stride + lk_refl(jx + xx, w)];
+            }
+            __syncthreads();
+            s1 = s2 = sabs = 0;
+#pragma unroll
+            for (int k = 0; k < LK_PER; k++)
+                if (lane + 64 * k < LK_NPX) {
+                    const int* c = Jp + wy[k] * LK_DW + wx[k];
+                    const int diff = lk_descale(c[0] * Wj.w00 + c[1] * Wj.w01 + c[LK_DW] * Wj.w10 + c[LK_DW + 1] * Wj.w11, 9) - Iw[k];
+                    s1 += (long long)diff * Ix[k]; s2 += (long long)diff * Iy[k];
+                    sabs += diff < 0 ? -diff : diff;
+                }
+        };
+        for (int j = 0; j < 30; j++) {
+            const int jx = (int)floorf(nx), jy = (int)floorf(ny);
+            if (jx < -LK_WIN || jx >= w || jy < -LK_WIN || jy >= h) {
+                if (level == 0) st = 0;
+                break;
+            }
+            const LkW Wj = lk_weights(nx - (float)jx, ny - (float)jy);
+            long long B1, B2, E;
+            residuals(jx, jy, Wj, B1, B2, E);
+            B1 = lk_wave_sum(B1); B2 = lk_wave_sum(B2);
+            const float b1 = (float)B1 * FLT_SCALE, b2 = (float)B2 * FLT_SCALE;
+            const float dx = (a12 * b2 - a22 * b1) * D, dy = (a12 * b1 - a11 * b2) * D;
+            nx += dx; ny += dy;
+            outx = nx + half; outy = ny + half;
+            if ((double)dx * dx + (double)dy * dy <= 0.01 * 0.01) break;
+            if (j > 0 && fabsf(dx + pdx) < 0.01f && fabsf(dy + pdy) < 0.01f) {
+                outx -= dx * 0.5f; outy -= dy * 0.5f;
+                break;
+            }
+            pdx = dx; pdy = dy;
+        }
+        if (st && level == 0) { /* L1 error at the final position */
+            const float fx = outx - half, fy = outy - half;
+            const int jx = (int)floorf(fx), jy = (int)floorf(fy);
+            if (jx < -LK_WIN || jx >= w || jy < -LK_WIN || jy >= h) st = 0;
+            else {
+                const LkW Wj = lk_weights(fx - (float)jx, fy - (float)jy);
+                long long B1, B2, E;
+                residuals(jx, jy, Wj, B1, B2, E);
+                E = lk_wave_sum(E);
+                errv = (float)E / (float)(32 * LK_WIN * LK_WIN);
+            }
+        }
+    }
+    if (lane == 0) {
+        next_pts[2 * i] = outx; next_pts[2 * i + 1] = outy;
+        status[i] = (uint8_t)st;
+        if (err) err[i] = errv;
+    }
+}
+
+/* Device entry: prev / next images and points resident; `work` holds the two pyramids above level 0
+ * (tbk_lk_work_bytes). Returns the coarsest level used through *top_level. */
+size_t tbk_lk_work_bytes(int w, int h, int max_level) {
+    size_t total = 0;
+    for (int l = 1; l <= max_level && l < LK_MAX_LEVELS; l++) {
+        w = (w + 1) / 2; h = (h + 1) / 2;
+        total += 2 * (((size_t)w * h + 255) & ~(size_t)255);
+    }
+    return total + 256;
+}
+
+int tbk_lk_track(tb_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_next, int w, int h, int stride, const float* d_prev_pts,
+                 int n, int win, int max_level, float* d_next_pts, uint8_t* d_status, float* d_err, void* d_work, int* top_level) {
+    if (win != LK_WIN) return tb_fail(ctx, TB_EUNSUPPORTED, "optical flow: window %d (this build: 21, the reference's)", win);
+    if (max_level < 0 || max_level >= LK_MAX_LEVELS) return tb_fail(ctx, TB_EUNSUPPORTED, "optical flow: max_level %d (0..5)", max_level);
+    if (w <= win || h <= win) return tb_fail(ctx, TB_EINVAL, "optical flow: image not larger than the window");
+    LkLevels L;
+    memset(&L, 0, sizeof L);
+    L.prev[0] = d_prev; L.next[0] = d_next; L.w[0] = w; L.h[0] = h; L.stride[0] = stride;
+    L.top = 0;
+    uint8_t* p = (uint8_t*)d_work;
+    for (int l = 1; l <= max_level; l++) { /* cv::buildOpticalFlowPyramid stops before a level no larger than the window */
+        const int lw = (L.w[l - 1] + 1) / 2, lh = (L.h[l - 1] + 1) / 2;
+        if (lw <= win || lh <= win) break;
+        const size_t bytes = ((size_t)lw * lh + 255) & ~(size_t)255;
+        uint8_t* a = p; p += bytes;
+        uint8_t* b = p; p += bytes;
+        dim3 grid((lw + 63) / 64, (lh + 3) / 4);
+        tb_prof_begin(ctx, "k_pyr_down");
+        hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), 0, ctx->stream, L.prev[l - 1], L.w[l - 1], L.h[l - 1], L.stride[l - 1], a, lw, lh, lw);
+        hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), 0, ctx->stream, L.next[l - 1], L.w[l - 1], L.h[l - 1], L.stride[l - 1], b, lw, lh, lw);
+        tb_prof_end(ctx);
+        L.prev[l] = a; L.next[l] = b; L.w[l] = lw; L.h[l] = lh; L.stride[l] = lw;
+        L.top = l;
+    }
+    if (top_level) *top_level = L.top;
+    if (n > 0) {
+        tb_prof_begin(ctx, "k_lk_track");
+        hipLaunchKernelGGL(k_lk_track, dim3(n), dim3(64), 0, ctx->stream, L, d_prev_pts, n, d_next_pts, d_status, d_err);
+        tb_prof_end(ctx);
+    }
+    TB_HIP(ctx, hipGetLastError());
+    return TB_OK;
+}

@@ -1230,4 +1230,76 @@ int tb_local_ba(tb_ctx* ctx, const double K[4], int nkf, int nfixed, float* pose
     return TB_OK;
 }
 
+int tb_optical_flow_pyr_lk_dev(tb_ctx* ctx, const uint8_t* prev, const uint8_t* next, int width, int height, int stride,
+                               const float* prev_pts, int n, int win, int max_level, float* next_pts, uint8_t* status, float* err) {
+    if (!ctx || !prev || !next || n < 0 || width < 1 || height < 1 || stride < width) return TB_EINVAL;
+    if (n && (!prev_pts || !next_pts || !status)) return TB_EINVAL;
+    if (max_level < 0 || max_level > 5) return tb_fail(ctx, TB_EUNSUPPORTED, "optical flow: max_level %d (0..5)", max_level);
+    void* work;
+    int rc;
+    if ((rc = tb_scratch(ctx, 7, tbk_lk_work_bytes(width, height, max_level), &work))) return rc;
+    return tbk_lk_track(ctx, prev, next, width, height, stride, prev_pts, n, win, max_level, next_pts, status, err, work, nullptr);
+}
+
+int tb_optical_flow_pyr_lk(tb_ctx* ctx, const uint8_t* prev, const uint8_t* next, int width, int height, int stride,
+                           const float* prev_pts, int n, int win, int max_level, float* next_pts, uint8_t* status, float* err,
+                           int* top_level) {
+    if (!ctx || !prev || !next || n < 0 || width < 1 || height < 1 || stride < width) return TB_EINVAL;
+    if (n && (!prev_pts || !next_pts || !status)) return TB_EINVAL;
+    if (max_level < 0 || max_level > 5) return tb_fail(ctx, TB_EUNSUPPORTED, "optical flow: max_level %d (0..5)", max_level);
+    const size_t img = (size_t)stride * height, np2 = (size_t)std::max(n, 1) * 2 * sizeof(float);
+    void *dp, *dn, *dpts, *dout, *dst, *derr, *work;
+    int rc;
+    if ((rc = tb_scratch(ctx, 0, img, &dp))) return rc;
+    if ((rc = tb_scratch(ctx, 1, img, &dn))) return rc;
+    if ((rc = tb_scratch(ctx, 2, np2, &dpts))) return rc;
+    if ((rc = tb_scratch(ctx, 3, np2, &dout))) return rc;
+    if ((rc = tb_scratch(ctx, 4, (size_t)std::max(n, 1), &dst))) return rc;
+    if ((rc = tb_scratch(ctx, 5, (size_t)std::max(n, 1) * sizeof(float), &derr))) return rc;
+    if ((rc = tb_scratch(ctx, 7, tbk_lk_work_bytes(width, height, max_level), &work))) return rc;
+    TB_HIP(ctx, hipMemcpyAsync(dp, prev, img, hipMemcpyHostToDevice, ctx->stream));
+    TB_HIP(ctx, hipMemcpyAsync(dn, next, img, hipMemcpyHostToDevice, ctx->stream));
+    if (n) TB_HIP(ctx, hipMemcpyAsync(dpts, prev_pts, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    int top = 0;
+    rc = tbk_lk_track(ctx, (const uint8_t*)dp, (const uint8_t*)dn, width, height, stride, (const float*)dpts, n, win, max_level,
+                      (float*)dout, (uint8_t*)dst, (float*)derr, work, &top);
+    if (rc) return rc;
+    if (n) {
+        TB_HIP(ctx, hipMemcpyAsync(next_pts, dout, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+        TB_HIP(ctx, hipMemcpyAsync(status, dst, (size_t)n, hipMemcpyDeviceToHost, ctx->stream));
+        if (err) TB_HIP(ctx, hipMemcpyAsync(err, derr, (size_t)n * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
+    }
+    TB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (top_level) *top_level = top;
+    return TB_OK;
+}
+
+int tb_search_by_opflow(tb_ctx* ctx, const uint8_t* img1, const uint8_t* img2, int width, int height, int stride,
+                        const tb_camera* cam1, const float* keys2_xy, int n, int equalized, int reject, float* cur_points,
+                        tb_match* out, int cap, int* count) {
+    if (!ctx || !count || !cam1 || n < 0 || cap < 0 || (n && (!cur_points || !keys2_xy)) || (cap && !out)) return TB_EINVAL;
+    *count = 0;
+    if (equalized) return tb_fail(ctx, TB_EUNSUPPORTED, "searchByOPFlow: equalized (Frame::Equalize = cv::CLAHE) is not built");
+    if (reject) return tb_fail(ctx, TB_EUNSUPPORTED, "searchByOPFlow: reject (rejectWithF = cv::findFundamentalMat RANSAC) is not built");
+    std::vector<uint8_t> status((size_t)std::max(n, 1));
+    /* matcher.cpp:744: calcOpticalFlowPyrLK(img2, img1, keys of F2, cur_points, ..., Size(21, 21), 3) */
+    int rc = tb_optical_flow_pyr_lk(ctx, img2, img1, width, height, stride, keys2_xy, n, 21, 3, cur_points, status.data(), nullptr, nullptr);
+    if (rc) return rc;
+    int m = 0;
+    for (int i = 0; i < n; i++) {
+        if (!status[i]) continue;
+        /* :746-748, IsInFrame(Vector2i(cur.x, cur.y)): the conversion truncates; out-of-int-range converts to INT_MIN on
+         * x86 and fails the test */
+        const float x = cur_points[2 * i], y = cur_points[2 * i + 1];
+        if (!(fabsf(x) < 2147483648.f) || !(fabsf(y) < 2147483648.f)) continue;
+        const int u = (int)x, v = (int)y;
+        if (!(u >= 0 && u < (int)((float)cam1->width * 1.f) && v >= 0 && v < (int)((float)cam1->height * 1.f))) continue;
+        if (m >= cap) return tb_fail(ctx, TB_ECAPACITY, "searchByOPFlow: more than %d matches", cap);
+        out[m].queryIdx = i; out[m].trainIdx = i; out[m].imgIdx = -1; out[m].distance = 3.402823466e+38f; /* cv::DMatch() */
+        m++;
+    }
+    *count = m;
+    return TB_OK;
+}
+
 }  // extern "C"
