@@ -66,6 +66,17 @@ namespace TRACKING_BENCH
                 const std::shared_ptr<Map>& map,
                 const std::shared_ptr<Frame>& F1, float r);
 
+        // Optical flow (reference :96-103, matcher.cpp:724-768). equalized (CLAHE) and reject (RANSAC fundamental matrix)
+        // are not built: passing true throws std::invalid_argument -- the reference's caller
+        // (LocalBA::AddMapPointsByStereo, LocalBA.cpp:54) passes both, see INTEGRATION.md.
+        std::vector<cv::DMatch> searchByOPFlow(
+                const std::shared_ptr<Frame>& F1,
+                const std::shared_ptr<Frame>& F2,
+                std::vector<cv::Point2f>& cur_points,
+                bool equalized,
+                bool reject,
+                bool MapPointOnly = false);
+
         static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b);
         static void ComputeThreeMaxima(std::vector<int>* histo, const int L, int &ind1, int &ind2, int &ind3);
     };

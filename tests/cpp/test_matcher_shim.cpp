@@ -10,6 +10,7 @@
 #include <fstream>
 #include <iostream>
 #include <memory>
+#include <stdexcept>
 #include <vector>
 
 #include "camera/CameraModel.h"
@@ -132,6 +133,15 @@ int main(int argc, char** argv)
     }
     for (int i2 = 0; i2 < n2p; i2++) nomp2[i2] = frame2_ptr->GetMapPoint(i2) ? 0 : 1;
 
+    // LocalBA::AddMapPointsByStereo's matcher call (LocalBA.cpp:54) without the two stages that are not built
+    // (equalized = CLAHE, reject = RANSAC F): the left frame's keys tracked into the right image
+    std::vector<cv::Point2f> flow_pts;
+    auto fmatches = matcher_ptr->searchByOPFlow(frame2_ptr, frame1_ptr, flow_pts, false, false);
+    bool threw = false;
+    try { std::vector<cv::Point2f> tmp; matcher_ptr->searchByOPFlow(frame2_ptr, frame1_ptr, tmp, true, true); }
+    catch (const std::invalid_argument&) { threw = true; }
+    if (!threw) { std::cerr << "searchByOPFlow(equalized, reject) must refuse" << std::endl; return 3; }
+
     std::ofstream o(argv[4], std::ios::binary);
     put(o, keypoints1.data(), keypoints1.size()); put(o, descriptors1.data, (size_t)descriptors1.rows * 32);
     put(o, keypoints2.data(), keypoints2.size()); put(o, descriptors2.data, (size_t)descriptors2.rows * 32);
@@ -143,8 +153,9 @@ int main(int argc, char** argv)
     put(o, k1now.data(), k1now.size()); put(o, taken1.data(), taken1.size()); put(o, nomp2.data(), nomp2.size());
     put(o, mp_rec.data(), mp_rec.size()); put(o, mp_desc.data(), mp_desc.size());
     put(o, pmatches.data(), pmatches.size()); put(o, mmatches.data(), mmatches.size());
+    put(o, flow_pts.data(), flow_pts.size()); put(o, fmatches.data(), fmatches.size());
     std::cout << "kps " << keypoints1.size() << "/" << keypoints2.size() << " added " << added.size() << " bf " << matches.size()
               << " violence " << vmatches.size() << " fast " << fast_kps.size() << " pose inliers " << inliers
-              << " projection " << pmatches.size() << " map projection " << mmatches.size() << std::endl;
+              << " projection " << pmatches.size() << " map projection " << mmatches.size() << " flow " << fmatches.size() << std::endl;
     return 0;
 }

@@ -234,6 +234,32 @@ namespace TRACKING_BENCH
         return out;
     }
 
+    /* SURVEY 8(f) row 2, first part: Matcher::searchByOPFlow (reference matcher.cpp:724-768) on tb_search_by_opflow */
+    std::vector<cv::DMatch> Matcher::searchByOPFlow(const std::shared_ptr<Frame>& F1, const std::shared_ptr<Frame>& F2,
+                                                    std::vector<cv::Point2f>& cur_points, bool equalized, bool reject, bool MapPointOnly)
+    {
+        if (equalized) throw std::invalid_argument("Matcher::searchByOPFlow: equalized (Frame::Equalize, CLAHE) is not built");
+        if (reject) throw std::invalid_argument("Matcher::searchByOPFlow: reject (rejectWithF, RANSAC fundamental matrix) is not built");
+        (void)MapPointOnly; /* the reference ignores it as well */
+        cv::Mat img1 = F1->GetImage(), img2 = F2->GetImage();
+        if (img1.cols != img2.cols || img1.rows != img2.rows) throw std::invalid_argument("Matcher::searchByOPFlow: image sizes differ");
+        std::vector<tb_keypoint> k2;
+        frame_keys(F2, k2);
+        std::vector<float> xy(2 * std::max<size_t>(k2.size(), 1)), cur(2 * std::max<size_t>(k2.size(), 1));
+        for (size_t i = 0; i < k2.size(); i++) { xy[2 * i] = k2[i].x; xy[2 * i + 1] = k2[i].y; }
+        tb_camera cam;
+        std::memset(&cam, 0, sizeof cam);
+        cam.width = F1->GetCameraModel()->Width(); cam.height = F1->GetCameraModel()->Height();
+        std::vector<cv::DMatch> out(std::max<size_t>(k2.size(), 1));
+        int n = 0;
+        check(tb_search_by_opflow(shim_ctx(), img1.data, img2.data, img1.cols, img1.rows, (int)img1.step, &cam, xy.data(), (int)k2.size(), 0, 0,
+                                  cur.data(), reinterpret_cast<tb_match*>(out.data()), (int)out.size(), &n), "Matcher::searchByOPFlow");
+        cur_points.resize(k2.size());
+        for (size_t i = 0; i < k2.size(); i++) cur_points[i] = cv::Point2f(cur[2 * i], cur[2 * i + 1]);
+        out.resize(n);
+        return out;
+    }
+
     /* the projection matchers (reference matcher.cpp:406-617) on tb_search_by_projection[_map] */
     static void frame_projection_inputs(const std::shared_ptr<Frame>& F1, float Tcw[16], tb_camera& cam, std::vector<tb_keypoint>& k1,
                                         std::vector<uint8_t>& d1, std::vector<uint8_t>& taken1)
