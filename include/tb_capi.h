@@ -223,6 +223,12 @@ int tb_search_by_opflow(tb_ctx* ctx, const uint8_t* img1, const uint8_t* img2, i
 int tb_optical_flow_pyr_lk_dev(tb_ctx* ctx, const uint8_t* prev, const uint8_t* next, int width, int height, int stride,
                                const float* prev_pts, int n, int win, int max_level, float* next_pts, uint8_t* status,
                                float* err);
+/* Batched device form: npairs image pairs of one geometry in one launch per stage (pair p at prev / next +
+ * p * image_pitch bytes; its points, results, status and err at slot p * pts_pitch, counts[p] <= pts_pitch of them,
+ * counts nullable = pts_pitch each). */
+int tb_optical_flow_pyr_lk_batch_dev(tb_ctx* ctx, int npairs, const uint8_t* prev, const uint8_t* next, int width, int height,
+                                     int stride, size_t image_pitch, const float* prev_pts, const int32_t* counts,
+                                     int pts_pitch, int win, int max_level, float* next_pts, uint8_t* status, float* err);
 
 /* Multi-keyframe local BA -- north-star extension, NO reference counterpart.
  * poses: nkf x 16 (in/out, first nfixed held), pts: npt x 3 (in/out). A point is observed at most once per

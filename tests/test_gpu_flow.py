@@ -69,3 +69,31 @@ def test_search_by_opflow(ctx):
     with pytest.raises(capi.TBError):
         ctx.search_by_opflow(R, L, cam, pts, reject=True)
     assert len(ctx.search_by_opflow(R, L, cam, np.zeros((0, 2), np.float32))[1]) == 0
+
+
+def test_lk_batch_device_resident(ctx):
+    """Batched device form: pairs of one geometry in one launch per stage, ragged point counts, against the oracle."""
+    import torch
+    dev = torch.device("cuda", 0)
+    W, H, cap = 320, 240, 256
+    pairs = [synth.frame(30 + i, W, H, stereo=True) for i in range(3)]
+    rng = np.random.default_rng(5)
+    counts = np.array([cap, 0, 97], np.int32)
+    pts = rng.uniform(-10, 330, (3, cap, 2)).astype(np.float32)
+    Ls = torch.from_numpy(np.stack([p[0] for p in pairs])).to(dev)
+    Rs = torch.from_numpy(np.stack([p[1] for p in pairs])).to(dev)
+    dp = torch.from_numpy(pts).to(dev)
+    dc = torch.from_numpy(counts).to(dev)
+    out = torch.full((3, cap, 2), -7.0, dtype=torch.float32, device=dev)
+    st = torch.full((3, cap), 9, dtype=torch.uint8, device=dev)
+    er = torch.full((3, cap), -1.0, dtype=torch.float32, device=dev)
+    ctx.optical_flow_pyr_lk_batch_dev(3, Ls.data_ptr(), Rs.data_ptr(), W, H, W, W * H, dp.data_ptr(), dc.data_ptr(), cap,
+                                      out.data_ptr(), st.data_ptr(), er.data_ptr())
+    ctx.synchronize()
+    out, st, er = out.cpu().numpy(), st.cpu().numpy(), er.cpu().numpy()
+    for p in range(3):
+        n = counts[p]
+        on, os_, oe, _ = oracle.optical_flow_pyr_lk(pairs[p][0], pairs[p][1], pts[p, :n])
+        assert np.array_equal(out[p, :n].view(np.uint32), on.view(np.uint32)) and np.array_equal(st[p, :n], os_)
+        assert np.array_equal(er[p, :n].view(np.uint32), oe.view(np.uint32))
+        assert (out[p, n:] == -7.0).all() and (st[p, n:] == 9).all()   # slots past the count are not written

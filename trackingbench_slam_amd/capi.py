@@ -39,7 +39,7 @@ EXPORTS = [
     "tb_search_by_violence", "tb_search_by_projection", "tb_search_by_projection_map", "tb_frame_grid_batch_dev",
     "tb_search_by_projection_batch_dev", "tb_search_by_projection_map_batch_dev",
     "tb_search_by_violence_batch_dev", "tb_pose_opt", "tb_pose_opt_batch_dev", "tb_local_ba", "tb_local_ba_batch_dev",
-    "tb_optical_flow_pyr_lk", "tb_optical_flow_pyr_lk_dev", "tb_search_by_opflow",
+    "tb_optical_flow_pyr_lk", "tb_optical_flow_pyr_lk_dev", "tb_optical_flow_pyr_lk_batch_dev", "tb_search_by_opflow",
 ]
 
 
@@ -284,6 +284,21 @@ class Context:
         self.check(lib().tb_optical_flow_pyr_lk(self._h, _p(prev), _p(nxt), w, h, w, _p(pts), n, int(win), int(max_level),
                                                 _p(out), _p(status), _p(err), C.byref(top)))
         return out[:n], status[:n], err[:n], top.value
+
+    def optical_flow_pyr_lk_dev(self, prev_ptr, next_ptr, width, height, stride, pts_ptr, n, out_ptr, status_ptr, err_ptr=0,
+                                win=21, max_level=3):
+        """Device-resident form (all arguments are device addresses); asynchronous on the context's stream."""
+        self.check(lib().tb_optical_flow_pyr_lk_dev(self._h, C.c_void_p(prev_ptr), C.c_void_p(next_ptr), int(width), int(height),
+                                                    int(stride), C.c_void_p(pts_ptr), int(n), int(win), int(max_level),
+                                                    C.c_void_p(out_ptr), C.c_void_p(status_ptr), C.c_void_p(err_ptr or None)))
+
+    def optical_flow_pyr_lk_batch_dev(self, npairs, prev_ptr, next_ptr, width, height, stride, image_pitch, pts_ptr, counts_ptr,
+                                      pts_pitch, out_ptr, status_ptr, err_ptr=0, win=21, max_level=3):
+        """Batched device-resident form: one launch per stage for all pairs; asynchronous on the context's stream."""
+        self.check(lib().tb_optical_flow_pyr_lk_batch_dev(
+            self._h, int(npairs), C.c_void_p(prev_ptr), C.c_void_p(next_ptr), int(width), int(height), int(stride),
+            C.c_size_t(image_pitch), C.c_void_p(pts_ptr), C.c_void_p(counts_ptr or None), int(pts_pitch), int(win), int(max_level),
+            C.c_void_p(out_ptr), C.c_void_p(status_ptr), C.c_void_p(err_ptr or None)))
 
     def search_by_opflow(self, img1, img2, cam1, keys2_xy, equalized=False, reject=False):
         """Matcher::searchByOPFlow(F1, F2, cur_points, equalized, reject) (reference matcher.cpp:724-768).

@@ -30,7 +30,9 @@ struct LkLevels {
     const uint8_t* prev[LK_MAX_LEVELS];
     const uint8_t* next[LK_MAX_LEVELS];
     int w[LK_MAX_LEVELS], h[LK_MAX_LEVELS], stride[LK_MAX_LEVELS];
-    int top; /* coarsest level used */
+    size_t pitch[LK_MAX_LEVELS]; /* bytes between the same level of consecutive pairs (batched form) */
+    int top;                     /* coarsest level used */
+    int pts_pitch;               /* points per pair slot (batched form) */
 };
 
 __device__ __forceinline__ int lk_refl(int p, int n) { /* BORDER_REFLECT_101 for |offset| < n */
@@ -39,9 +41,12 @@ __device__ __forceinline__ int lk_refl(int p, int n) { /* BORDER_REFLECT_101 for
 }
 
 __global__ void __launch_bounds__(256)
-k_pyr_down(const uint8_t* __restrict__ src, int sw, int sh, int sstride, uint8_t* __restrict__ dst, int dw, int dh, int dstride) {
+k_pyr_down(const uint8_t* __restrict__ src, int sw, int sh, int sstride, size_t spitch, uint8_t* __restrict__ dst, int dw, int dh,
+           int dstride, size_t dpitch) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= dw || y >= dh) return;
+    src += (size_t)blockIdx.z * spitch; /* blockIdx.z = image of the batch */
+    dst += (size_t)blockIdx.z * dpitch;
     int col[5];
 #pragma unroll
     for (int i = 0; i < 5; i++) col[i] = lk_refl(2 * x + i - 2, sw);
@@ -75,13 +80,14 @@ __device__ __forceinline__ LkW lk_weights(float a, float b) {
 }
 
 __global__ void __launch_bounds__(64)
-k_lk_track(LkLevels L, const float* __restrict__ prev_pts, int n, float* __restrict__ next_pts, uint8_t* __restrict__ status,
-           float* __restrict__ err) {
+k_lk_track(LkLevels L, const float* __restrict__ prev_pts, const int32_t* __restrict__ counts, int n, float* __restrict__ next_pts,
+           uint8_t* __restrict__ status, float* __restrict__ err) {
     __shared__ int Ip[LK_PW * LK_PW];        /* source patch, position (x, y) of the window at [(y + 1) * LK_PW + x + 1] */
     __shared__ int dX[LK_DW * LK_DW], dY[LK_DW * LK_DW];
     __shared__ int Jp[LK_DW * LK_DW];
-    const int i = blockIdx.x, lane = threadIdx.x;
-    if (i >= n) return;
+    const int pair = blockIdx.y, lane = threadIdx.x;
+    if ((int)blockIdx.x >= (counts ? min(counts[pair], n) : n)) return;
+    const int i = pair * L.pts_pitch + blockIdx.x; /* record index */
     const float FLT_SCALE = 1.f / (1 << 20);
     const float half = (LK_WIN - 1) * 0.5f;
     const float ptx = prev_pts[2 * i], pty = prev_pts[2 * i + 1];
@@ -92,8 +98,8 @@ k_lk_track(LkLevels L, const float* __restrict__ prev_pts, int n, float* __restr
 #pragma unroll
     for (int k = 0; k < LK_PER; k++) { const int p = lane + 64 * k; wy[k] = p / LK_WIN; wx[k] = p - wy[k] * LK_WIN; }
     for (int level = L.top; level >= 0; level--) {
-        const uint8_t* I = L.prev[level];
-        const uint8_t* J = L.next[level];
+        const uint8_t* I = L.prev[level] + (size_t)pair * L.pitch[level];
+        const uint8_t* J = L.next[level] + (size_t)pair * L.pitch[level];
         const int w = L.w[level], h = L.h[level], stride = L.stride[level];
         const float sc = (float)(1. / (1 << level));
         float px = ptx * sc, py = pty * sc, nx, ny;
@@ -211,45 +217,51 @@ k_lk_track(LkLevels L, const float* __restrict__ prev_pts, int n, float* __restr
     }
 }
 
-/* Device entry: prev / next images and points resident; `work` holds the two pyramids above level 0
- * (tbk_lk_work_bytes). Returns the coarsest level used through *top_level. */
-size_t tbk_lk_work_bytes(int w, int h, int max_level) {
+/* Device entry: npairs image pairs (pair p at prev / next + p * image_pitch bytes), points of pair p at
+ * prev_pts + p * pts_pitch (x, y) records, counts[p] of them (counts nullable: n each); `work` holds the pyramids above
+ * level 0 (tbk_lk_work_bytes). Returns the coarsest level used through *top_level. */
+size_t tbk_lk_work_bytes(int w, int h, int max_level, int npairs) {
     size_t total = 0;
     for (int l = 1; l <= max_level && l < LK_MAX_LEVELS; l++) {
         w = (w + 1) / 2; h = (h + 1) / 2;
-        total += 2 * (((size_t)w * h + 255) & ~(size_t)255);
+        total += 2 * (size_t)npairs * (((size_t)w * h + 255) & ~(size_t)255);
     }
     return total + 256;
 }
 
-int tbk_lk_track(tb_ctx* ctx, const uint8_t* d_prev, const uint8_t* d_next, int w, int h, int stride, const float* d_prev_pts,
-                 int n, int win, int max_level, float* d_next_pts, uint8_t* d_status, float* d_err, void* d_work, int* top_level) {
+int tbk_lk_track(tb_ctx* ctx, int npairs, const uint8_t* d_prev, const uint8_t* d_next, int w, int h, int stride, size_t image_pitch,
+                 const float* d_prev_pts, const int32_t* d_counts, int n, int pts_pitch, int win, int max_level, float* d_next_pts,
+                 uint8_t* d_status, float* d_err, void* d_work, int* top_level) {
     if (win != LK_WIN) return tb_fail(ctx, TB_EUNSUPPORTED, "optical flow: window %d (this build: 21, the reference's)", win);
     if (max_level < 0 || max_level >= LK_MAX_LEVELS) return tb_fail(ctx, TB_EUNSUPPORTED, "optical flow: max_level %d (0..5)", max_level);
     if (w <= win || h <= win) return tb_fail(ctx, TB_EINVAL, "optical flow: image not larger than the window");
+    if (npairs > 65535) return tb_fail(ctx, TB_EUNSUPPORTED, "optical flow: more than 65535 pairs per call");
     LkLevels L;
     memset(&L, 0, sizeof L);
-    L.prev[0] = d_prev; L.next[0] = d_next; L.w[0] = w; L.h[0] = h; L.stride[0] = stride;
+    L.prev[0] = d_prev; L.next[0] = d_next; L.w[0] = w; L.h[0] = h; L.stride[0] = stride; L.pitch[0] = image_pitch;
     L.top = 0;
+    L.pts_pitch = pts_pitch;
     uint8_t* p = (uint8_t*)d_work;
     for (int l = 1; l <= max_level; l++) { /* cv::buildOpticalFlowPyramid stops before a level no larger than the window */
         const int lw = (L.w[l - 1] + 1) / 2, lh = (L.h[l - 1] + 1) / 2;
         if (lw <= win || lh <= win) break;
         const size_t bytes = ((size_t)lw * lh + 255) & ~(size_t)255;
-        uint8_t* a = p; p += bytes;
-        uint8_t* b = p; p += bytes;
-        dim3 grid((lw + 63) / 64, (lh + 3) / 4);
+        uint8_t* a = p; p += bytes * npairs;
+        uint8_t* b = p; p += bytes * npairs;
+        dim3 grid((lw + 63) / 64, (lh + 3) / 4, npairs);
         tb_prof_begin(ctx, "k_pyr_down");
-        hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), 0, ctx->stream, L.prev[l - 1], L.w[l - 1], L.h[l - 1], L.stride[l - 1], a, lw, lh, lw);
-        hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), 0, ctx->stream, L.next[l - 1], L.w[l - 1], L.h[l - 1], L.stride[l - 1], b, lw, lh, lw);
+        hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), 0, ctx->stream, L.prev[l - 1], L.w[l - 1], L.h[l - 1], L.stride[l - 1],
+                           L.pitch[l - 1], a, lw, lh, lw, bytes);
+        hipLaunchKernelGGL(k_pyr_down, grid, dim3(256), 0, ctx->stream, L.next[l - 1], L.w[l - 1], L.h[l - 1], L.stride[l - 1],
+                           L.pitch[l - 1], b, lw, lh, lw, bytes);
         tb_prof_end(ctx);
-        L.prev[l] = a; L.next[l] = b; L.w[l] = lw; L.h[l] = lh; L.stride[l] = lw;
+        L.prev[l] = a; L.next[l] = b; L.w[l] = lw; L.h[l] = lh; L.stride[l] = lw; L.pitch[l] = bytes;
         L.top = l;
     }
     if (top_level) *top_level = L.top;
-    if (n > 0) {
+    if (n > 0 && npairs > 0) {
         tb_prof_begin(ctx, "k_lk_track");
-        hipLaunchKernelGGL(k_lk_track, dim3(n), dim3(64), 0, ctx->stream, L, d_prev_pts, n, d_next_pts, d_status, d_err);
+        hipLaunchKernelGGL(k_lk_track, dim3(n, npairs), dim3(64), 0, ctx->stream, L, d_prev_pts, d_counts, n, d_next_pts, d_status, d_err);
         tb_prof_end(ctx);
     }
     TB_HIP(ctx, hipGetLastError());

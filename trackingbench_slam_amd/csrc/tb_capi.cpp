@@ -1237,8 +1237,23 @@ int tb_optical_flow_pyr_lk_dev(tb_ctx* ctx, const uint8_t* prev, const uint8_t* 
     if (max_level < 0 || max_level > 5) return tb_fail(ctx, TB_EUNSUPPORTED, "optical flow: max_level %d (0..5)", max_level);
     void* work;
     int rc;
-    if ((rc = tb_scratch(ctx, 7, tbk_lk_work_bytes(width, height, max_level), &work))) return rc;
-    return tbk_lk_track(ctx, prev, next, width, height, stride, prev_pts, n, win, max_level, next_pts, status, err, work, nullptr);
+    if ((rc = tb_scratch(ctx, 7, tbk_lk_work_bytes(width, height, max_level, 1), &work))) return rc;
+    return tbk_lk_track(ctx, 1, prev, next, width, height, stride, 0, prev_pts, nullptr, n, n, win, max_level, next_pts, status, err, work,
+                        nullptr);
+}
+
+int tb_optical_flow_pyr_lk_batch_dev(tb_ctx* ctx, int npairs, const uint8_t* prev, const uint8_t* next, int width, int height,
+                                     int stride, size_t image_pitch, const float* prev_pts, const int32_t* counts, int pts_pitch,
+                                     int win, int max_level, float* next_pts, uint8_t* status, float* err) {
+    if (!ctx || npairs < 0 || pts_pitch < 0 || width < 1 || height < 1 || stride < width) return TB_EINVAL;
+    if (npairs == 0 || pts_pitch == 0) return TB_OK;
+    if (!prev || !next || !prev_pts || !next_pts || !status || image_pitch < (size_t)stride * height) return TB_EINVAL;
+    if (max_level < 0 || max_level > 5) return tb_fail(ctx, TB_EUNSUPPORTED, "optical flow: max_level %d (0..5)", max_level);
+    void* work;
+    int rc;
+    if ((rc = tb_scratch(ctx, 7, tbk_lk_work_bytes(width, height, max_level, npairs), &work))) return rc;
+    return tbk_lk_track(ctx, npairs, prev, next, width, height, stride, image_pitch, prev_pts, counts, pts_pitch, pts_pitch, win, max_level,
+                        next_pts, status, err, work, nullptr);
 }
 
 int tb_optical_flow_pyr_lk(tb_ctx* ctx, const uint8_t* prev, const uint8_t* next, int width, int height, int stride,
@@ -1256,13 +1271,13 @@ int tb_optical_flow_pyr_lk(tb_ctx* ctx, const uint8_t* prev, const uint8_t* next
     if ((rc = tb_scratch(ctx, 3, np2, &dout))) return rc;
     if ((rc = tb_scratch(ctx, 4, (size_t)std::max(n, 1), &dst))) return rc;
     if ((rc = tb_scratch(ctx, 5, (size_t)std::max(n, 1) * sizeof(float), &derr))) return rc;
-    if ((rc = tb_scratch(ctx, 7, tbk_lk_work_bytes(width, height, max_level), &work))) return rc;
+    if ((rc = tb_scratch(ctx, 7, tbk_lk_work_bytes(width, height, max_level, 1), &work))) return rc;
     TB_HIP(ctx, hipMemcpyAsync(dp, prev, img, hipMemcpyHostToDevice, ctx->stream));
     TB_HIP(ctx, hipMemcpyAsync(dn, next, img, hipMemcpyHostToDevice, ctx->stream));
     if (n) TB_HIP(ctx, hipMemcpyAsync(dpts, prev_pts, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
     int top = 0;
-    rc = tbk_lk_track(ctx, (const uint8_t*)dp, (const uint8_t*)dn, width, height, stride, (const float*)dpts, n, win, max_level,
-                      (float*)dout, (uint8_t*)dst, (float*)derr, work, &top);
+    rc = tbk_lk_track(ctx, 1, (const uint8_t*)dp, (const uint8_t*)dn, width, height, stride, 0, (const float*)dpts, nullptr, n, n, win,
+                      max_level, (float*)dout, (uint8_t*)dst, (float*)derr, work, &top);
     if (rc) return rc;
     if (n) {
         TB_HIP(ctx, hipMemcpyAsync(next_pts, dout, (size_t)n * 2 * sizeof(float), hipMemcpyDeviceToHost, ctx->stream));
