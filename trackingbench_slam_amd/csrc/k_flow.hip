@@ -25,6 +25,7 @@
 #define LK_NPX (LK_WIN * LK_WIN)
 #define LK_PER ((LK_NPX + 63) / 64)
 #define LK_MAX_LEVELS 6
+#define LK_JPER ((LK_DW * LK_DW + 63) / 64)
 
 struct LkLevels {
     const uint8_t* prev[LK_MAX_LEVELS];
@@ -60,13 +61,21 @@ k_pyr_down(const uint8_t* __restrict__ src, int sw, int sh, int sstride, size_t 
     dst[(size_t)y * dstride + x] = (uint8_t)((sum + 128) >> 8);
 }
 
-__device__ __forceinline__ long long lk_wave_sum(long long v) { /* integer: any order gives the same sum */
-#pragma unroll
-    for (int d = 32; d > 0; d >>= 1) {
-        const int lo = __shfl_xor((int)(v & 0xffffffffll), d, 64), hi = __shfl_xor((int)(v >> 32), d, 64);
-        v += ((long long)hi << 32) | (unsigned int)lo;
-    }
-    return v;
+/* Wave sum of one int per lane on the DPP data path (row shifts inside the 16-lane rows, then row_bcast 15 / 31 into
+ * lane 63): six dependent VALU adds instead of six LDS-permute round trips. Integer, so any order gives the same sum. */
+__device__ __forceinline__ int lk_dpp_sum(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); /* row_shr:1 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false); /* row_shr:2 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false); /* row_shr:4 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false); /* row_shr:8 -> lane 15 of a row holds its sum */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); /* row_bcast:15 into rows 1, 3 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); /* row_bcast:31 into rows 2, 3 */
+    return __builtin_amdgcn_readlane(v, 63);
+}
+/* per-lane 32-bit partial sums (|a| < 2^28) whose wave total needs 64 bits: 16-bit halves summed separately */
+__device__ __forceinline__ long long lk_wave_sum(int a) {
+    const int lo = lk_dpp_sum(a & 0xffff), hi = lk_dpp_sum(a >> 16);
+    return ((long long)hi << 16) + lo;
 }
 __device__ __forceinline__ int lk_descale(int v, int n) { return (v + (1 << (n - 1))) >> n; }
 struct LkW { int w00, w01, w10, w11; };
@@ -97,6 +106,9 @@ k_lk_track(LkLevels L, const float* __restrict__ prev_pts, const int32_t* __rest
     int wy[LK_PER], wx[LK_PER];
 #pragma unroll
     for (int k = 0; k < LK_PER; k++) { const int p = lane + 64 * k; wy[k] = p / LK_WIN; wx[k] = p - wy[k] * LK_WIN; }
+    int jyy[LK_JPER], jxx[LK_JPER]; /* this lane's pixels of the second image's 22 x 22 patch */
+#pragma unroll
+    for (int k = 0; k < LK_JPER; k++) { const int t = lane + 64 * k; jyy[k] = t / LK_DW; jxx[k] = t - jyy[k] * LK_DW; }
     for (int level = L.top; level >= 0; level--) {
         const uint8_t* I = L.prev[level] + (size_t)pair * L.pitch[level];
         const uint8_t* J = L.next[level] + (size_t)pair * L.pitch[level];
@@ -134,7 +146,7 @@ k_lk_track(LkLevels L, const float* __restrict__ prev_pts, const int32_t* __rest
         __syncthreads();
         LkW W = lk_weights(px - (float)ix, py - (float)iy);
         int Iw[LK_PER], Ix[LK_PER], Iy[LK_PER];
-        long long A11 = 0, A12 = 0, A22 = 0;
+        int A11l = 0, A12l = 0, A22l = 0; /* |Ix|, |Iy| <= 4080: 7 products per lane fit 32 bits */
 #pragma unroll
         for (int k = 0; k < LK_PER; k++) {
             Iw[k] = Ix[k] = Iy[k] = 0;
@@ -144,10 +156,10 @@ k_lk_track(LkLevels L, const float* __restrict__ prev_pts, const int32_t* __rest
                 Iw[k] = lk_descale(c[0] * W.w00 + c[1] * W.w01 + c[LK_PW] * W.w10 + c[LK_PW + 1] * W.w11, 9);
                 Ix[k] = lk_descale(dX[d] * W.w00 + dX[d + 1] * W.w01 + dX[d + LK_DW] * W.w10 + dX[d + LK_DW + 1] * W.w11, 14);
                 Iy[k] = lk_descale(dY[d] * W.w00 + dY[d + 1] * W.w01 + dY[d + LK_DW] * W.w10 + dY[d + LK_DW + 1] * W.w11, 14);
-                A11 += (long long)Ix[k] * Ix[k]; A12 += (long long)Ix[k] * Iy[k]; A22 += (long long)Iy[k] * Iy[k];
+                A11l += Ix[k] * Ix[k]; A12l += Ix[k] * Iy[k]; A22l += Iy[k] * Iy[k];
             }
         }
-        A11 = lk_wave_sum(A11); A12 = lk_wave_sum(A12); A22 = lk_wave_sum(A22);
+        const long long A11 = lk_wave_sum(A11l), A12 = lk_wave_sum(A12l), A22 = lk_wave_sum(A22l);
         const float a11 = (float)A11 * FLT_SCALE, a12 = (float)A12 * FLT_SCALE, a22 = (float)A22 * FLT_SCALE;
         float D = a11 * a22 - a12 * a12;
         const float minEig = (a22 + a11 - sqrtf((a11 - a22) * (a11 - a22) + 4.f * a12 * a12)) / (float)(2 * LK_WIN * LK_WIN);
@@ -159,22 +171,31 @@ k_lk_track(LkLevels L, const float* __restrict__ prev_pts, const int32_t* __rest
         nx -= half; ny -= half;
         float pdx = 0.f, pdy = 0.f;
         /* the second image's patch at (jx, jy) -> per-lane residuals against the stored window */
-        auto residuals = [&](int jx, int jy, const LkW& Wj, long long& s1, long long& s2, long long& sabs) {
+        auto residuals = [&](int jx, int jy, const LkW& Wj, int& s1, int& s2, int& sabs) {
             __syncthreads();
-            for (int t = lane; t < LK_DW * LK_DW; t += 64) {
-                const int yy = t / LK_DW, xx = t - yy * LK_DW;
-                Jp[t] = J[(size_t)lk_refl(jy + yy, h) * stride + lk_refl(jx + xx, w)];
+            if (jx >= 0 && jy >= 0 && jx + LK_DW <= w && jy + LK_DW <= h) { /* wave-uniform: no reflection needed */
+                const uint8_t* base = J + (size_t)jy * stride + jx;
+#pragma unroll
+                for (int k = 0; k < LK_JPER; k++)
+                    if (lane + 64 * k < LK_DW * LK_DW) Jp[lane + 64 * k] = base[jyy[k] * stride + jxx[k]];
+            } else {
+#pragma unroll
+                for (int k = 0; k < LK_JPER; k++)
+                    if (lane + 64 * k < LK_DW * LK_DW)
+                        Jp[lane + 64 * k] = J[(size_t)lk_refl(jy + jyy[k], h) * stride + lk_refl(jx + jxx[k], w)];
             }
             __syncthreads();
-            s1 = s2 = sabs = 0;
+            /* per lane the 7 products fit 32 bits (|diff| <= 8160, |Ix| <= 4080); the wave sum needs 64 */
+            int a1 = 0, a2 = 0, ab = 0;
 #pragma unroll
             for (int k = 0; k < LK_PER; k++)
                 if (lane + 64 * k < LK_NPX) {
                     const int* c = Jp + wy[k] * LK_DW + wx[k];
                     const int diff = lk_descale(c[0] * Wj.w00 + c[1] * Wj.w01 + c[LK_DW] * Wj.w10 + c[LK_DW + 1] * Wj.w11, 9) - Iw[k];
-                    s1 += (long long)diff * Ix[k]; s2 += (long long)diff * Iy[k];
-                    sabs += diff < 0 ? -diff : diff;
+                    a1 += diff * Ix[k]; a2 += diff * Iy[k];
+                    ab += diff < 0 ? -diff : diff;
                 }
+            s1 = a1; s2 = a2; sabs = ab;
         };
         for (int j = 0; j < 30; j++) {
             const int jx = (int)floorf(nx), jy = (int)floorf(ny);
@@ -183,9 +204,9 @@ k_lk_track(LkLevels L, const float* __restrict__ prev_pts, const int32_t* __rest
                 break;
             }
             const LkW Wj = lk_weights(nx - (float)jx, ny - (float)jy);
-            long long B1, B2, E;
-            residuals(jx, jy, Wj, B1, B2, E);
-            B1 = lk_wave_sum(B1); B2 = lk_wave_sum(B2);
+            int r1, r2, ra;
+            residuals(jx, jy, Wj, r1, r2, ra);
+            const long long B1 = lk_wave_sum(r1), B2 = lk_wave_sum(r2);
             const float b1 = (float)B1 * FLT_SCALE, b2 = (float)B2 * FLT_SCALE;
             const float dx = (a12 * b2 - a22 * b1) * D, dy = (a12 * b1 - a11 * b2) * D;
             nx += dx; ny += dy;
@@ -203,9 +224,9 @@ k_lk_track(LkLevels L, const float* __restrict__ prev_pts, const int32_t* __rest
             if (jx < -LK_WIN || jx >= w || jy < -LK_WIN || jy >= h) st = 0;
             else {
                 const LkW Wj = lk_weights(fx - (float)jx, fy - (float)jy);
-                long long B1, B2, E;
-                residuals(jx, jy, Wj, B1, B2, E);
-                E = lk_wave_sum(E);
+                int r1, r2, ra;
+                residuals(jx, jy, Wj, r1, r2, ra);
+                const long long E = lk_dpp_sum(ra); /* <= 64 * 7 * 8160 */
                 errv = (float)E / (float)(32 * LK_WIN * LK_WIN);
             }
         }
