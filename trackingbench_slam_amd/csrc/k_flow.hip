@@ -12,9 +12,9 @@
  *   k_pyr_down  : thread per destination pixel, 25 taps, (sum + 128) >> 8
  *   k_lk_track  : ONE WAVEFRONT PER POINT, all pyramid levels in one launch. Per level the 24 x 24 source patch goes to
  *                 LDS once (reflect-101 indexing), the 22 x 22 Scharr derivatives are formed from it in LDS, every lane
- *                 keeps its 7 of the 441 interpolated window samples (I, Ix, Iy) in registers; each iteration stages
- *                 the 22 x 22 patch of the second image in LDS and reduces two 64-bit sums over the wavefront. No
- *                 derivative images and no padded pyramid copies exist in HBM.
+ *                 keeps its 7 of the 441 interpolated window samples (I, Ix, Iy) in registers; the iterations read the
+ *                 second image from a 34 x 34 region cached in LDS and reduce two sums over the wavefront on the DPP
+ *                 path. No derivative images and no padded pyramid copies exist in HBM.
  * Bound: latency / LDS (a few KB per point per iteration); no 8d row. */
 #include "tb_internal.h"
 #include "tb_device.h"
@@ -25,7 +25,8 @@
 #define LK_NPX (LK_WIN * LK_WIN)
 #define LK_PER ((LK_NPX + 63) / 64)
 #define LK_MAX_LEVELS 6
-#define LK_JPER ((LK_DW * LK_DW + 63) / 64)
+#define LK_JM 6                 /* margin of the cached second-image region: most iterations move the window by < 1 px */
+#define LK_JS (LK_DW + 2 * LK_JM)
 
 struct LkLevels {
     const uint8_t* prev[LK_MAX_LEVELS];
@@ -93,7 +94,7 @@ k_lk_track(LkLevels L, const float* __restrict__ prev_pts, const int32_t* __rest
            uint8_t* __restrict__ status, float* __restrict__ err) {
     __shared__ int Ip[LK_PW * LK_PW];        /* source patch, position (x, y) of the window at [(y + 1) * LK_PW + x + 1] */
     __shared__ int dX[LK_DW * LK_DW], dY[LK_DW * LK_DW];
-    __shared__ int Jp[LK_DW * LK_DW];
+    __shared__ int Jc[LK_JS * LK_JS]; /* cached region of the second image around the current window */
     const int pair = blockIdx.y, lane = threadIdx.x;
     if ((int)blockIdx.x >= (counts ? min(counts[pair], n) : n)) return;
     const int i = pair * L.pts_pitch + blockIdx.x; /* record index */
@@ -106,9 +107,6 @@ k_lk_track(LkLevels L, const float* __restrict__ prev_pts, const int32_t* __rest
     int wy[LK_PER], wx[LK_PER];
 #pragma unroll
     for (int k = 0; k < LK_PER; k++) { const int p = lane + 64 * k; wy[k] = p / LK_WIN; wx[k] = p - wy[k] * LK_WIN; }
-    int jyy[LK_JPER], jxx[LK_JPER]; /* this lane's pixels of the second image's 22 x 22 patch */
-#pragma unroll
-    for (int k = 0; k < LK_JPER; k++) { const int t = lane + 64 * k; jyy[k] = t / LK_DW; jxx[k] = t - jyy[k] * LK_DW; }
     for (int level = L.top; level >= 0; level--) {
         const uint8_t* I = L.prev[level] + (size_t)pair * L.pitch[level];
         const uint8_t* J = L.next[level] + (size_t)pair * L.pitch[level];
@@ -171,27 +169,32 @@ k_lk_track(LkLevels L, const float* __restrict__ prev_pts, const int32_t* __rest
         nx -= half; ny -= half;
         float pdx = 0.f, pdy = 0.f;
         /* the second image's patch at (jx, jy) -> per-lane residuals against the stored window */
+        /* residuals of the window at (jx, jy) of the second image against the stored window. The LK_JS x LK_JS region around
+         * the window is staged in LDS and reused while the window stays inside it: a reload per iteration was one
+         * global-memory latency and two barriers on the critical path of every iteration (5.9 -> 4.9 ms per 128 k points).
+         * Its margin may reach past a single reflection on small levels: clamped there, never read back. */
+        int cx0 = 0, cy0 = 0;
+        bool cached = false;
         auto residuals = [&](int jx, int jy, const LkW& Wj, int& s1, int& s2, int& sabs) {
-            __syncthreads();
-            if (jx >= 0 && jy >= 0 && jx + LK_DW <= w && jy + LK_DW <= h) { /* wave-uniform: no reflection needed */
-                const uint8_t* base = J + (size_t)jy * stride + jx;
-#pragma unroll
-                for (int k = 0; k < LK_JPER; k++)
-                    if (lane + 64 * k < LK_DW * LK_DW) Jp[lane + 64 * k] = base[jyy[k] * stride + jxx[k]];
-            } else {
-#pragma unroll
-                for (int k = 0; k < LK_JPER; k++)
-                    if (lane + 64 * k < LK_DW * LK_DW)
-                        Jp[lane + 64 * k] = J[(size_t)lk_refl(jy + jyy[k], h) * stride + lk_refl(jx + jxx[k], w)];
+            if (!cached || jx < cx0 || jx + LK_DW > cx0 + LK_JS || jy < cy0 || jy + LK_DW > cy0 + LK_JS) { /* wave-uniform */
+                cx0 = jx - LK_JM; cy0 = jy - LK_JM;
+                cached = true;
+                __syncthreads();
+                for (int t = lane; t < LK_JS * LK_JS; t += 64) {
+                    const int yy = t / LK_JS, xx = t - yy * LK_JS;
+                    const int yr = min(max(lk_refl(cy0 + yy, h), 0), h - 1), xr = min(max(lk_refl(cx0 + xx, w), 0), w - 1);
+                    Jc[t] = J[(size_t)yr * stride + xr];
+                }
+                __syncthreads();
             }
-            __syncthreads();
+            const int* Jp = Jc + (jy - cy0) * LK_JS + (jx - cx0);
             /* per lane the 7 products fit 32 bits (|diff| <= 8160, |Ix| <= 4080); the wave sum needs 64 */
             int a1 = 0, a2 = 0, ab = 0;
 #pragma unroll
             for (int k = 0; k < LK_PER; k++)
                 if (lane + 64 * k < LK_NPX) {
-                    const int* c = Jp + wy[k] * LK_DW + wx[k];
-                    const int diff = lk_descale(c[0] * Wj.w00 + c[1] * Wj.w01 + c[LK_DW] * Wj.w10 + c[LK_DW + 1] * Wj.w11, 9) - Iw[k];
+                    const int* c = Jp + wy[k] * LK_JS + wx[k];
+                    const int diff = lk_descale(c[0] * Wj.w00 + c[1] * Wj.w01 + c[LK_JS] * Wj.w10 + c[LK_JS + 1] * Wj.w11, 9) - Iw[k];
                     a1 += diff * Ix[k]; a2 += diff * Iy[k];
                     ab += diff < 0 ? -diff : diff;
                 }
