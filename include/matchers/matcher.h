@@ -66,9 +66,9 @@ namespace TRACKING_BENCH
                 const std::shared_ptr<Map>& map,
                 const std::shared_ptr<Frame>& F1, float r);
 
-        // Optical flow (reference :96-103, matcher.cpp:724-768). equalized (CLAHE) and reject (RANSAC fundamental matrix)
-        // are not built: passing true throws std::invalid_argument -- the reference's caller
-        // (LocalBA::AddMapPointsByStereo, LocalBA.cpp:54) passes both, see INTEGRATION.md.
+        // Optical flow (reference :96-103, matcher.cpp:724-768). reject (rejectWithF: RANSAC fundamental matrix) is not
+        // built: passing true throws std::invalid_argument -- the reference's caller (LocalBA::AddMapPointsByStereo,
+        // LocalBA.cpp:54) passes it, see INTEGRATION.md.
         std::vector<cv::DMatch> searchByOPFlow(
                 const std::shared_ptr<Frame>& F1,
                 const std::shared_ptr<Frame>& F2,

@@ -211,8 +211,16 @@ int tb_pose_opt_batch_dev(tb_ctx* ctx, int nproblems, const double K[4], const f
  * tb_search_by_opflow replaces Matcher::searchByOPFlow(F1, F2, cur_points, equalized, reject), matcher.cpp:724-768:
  * tracks F2's keys (keys2_xy) from img2 into img1, clears the points that leave F1's frame (cam1->width / height,
  * CameraModel.h:33-39) and returns DMatch(i, i) records (distance FLT_MAX, imgIdx -1, as a default-constructed
- * cv::DMatch). equalized (Frame::Equalize = CLAHE) and reject (rejectWithF = RANSAC fundamental matrix, needs cv::RNG)
- * are NOT built: non-zero gives TB_EUNSUPPORTED. cur_points: n (x, y) pairs out. */
+ * cv::DMatch). equalized != 0: img1 goes through tb_clahe(3.0, 8 x 8) first (F1->Equalize(), matcher.cpp:736-739).
+ * reject (rejectWithF = cv::findFundamentalMat RANSAC, needs cv::RNG and the 7-point solver) is NOT built: non-zero
+ * gives TB_EUNSUPPORTED. cur_points: n (x, y) pairs out. */
+/* Frame::Equalize, Frame.cpp:453-458: cv::createCLAHE(clip_limit = 3.0, Size(tiles_x, tiles_y) = 8 x 8)->apply(src, dst)
+ * (OpenCV 3.3 routine restated, parity unpinned). Host pointers; dst has the size of src. tb_clahe_dev: device pointers,
+ * asynchronous on the context's stream. */
+int tb_clahe(tb_ctx* ctx, const uint8_t* src, int width, int height, int stride, double clip_limit, int tiles_x, int tiles_y,
+             uint8_t* dst, int dst_stride);
+int tb_clahe_dev(tb_ctx* ctx, const uint8_t* src, int width, int height, int stride, double clip_limit, int tiles_x, int tiles_y,
+                 uint8_t* dst, int dst_stride);
 int tb_optical_flow_pyr_lk(tb_ctx* ctx, const uint8_t* prev, const uint8_t* next, int width, int height, int stride,
                            const float* prev_pts, int n, int win, int max_level, float* next_pts, uint8_t* status,
                            float* err, int* top_level);

@@ -342,8 +342,8 @@ def optical_flow_pyr_lk(prev, nxt, prev_pts, win=21, max_level=3):
     return out[:n], status[:n], err[:n], top
 
 
-def search_by_opflow(img1, img2, cam1, keys2_xy):
-    """Matcher::searchByOPFlow(F1, F2, cur_points, equalized=False, reject=False), matcher.cpp:724-768.
+def search_by_opflow(img1, img2, cam1, keys2_xy, equalized=False):
+    """Matcher::searchByOPFlow(F1, F2, cur_points, equalized, reject=False), matcher.cpp:724-768.
     Returns (cur_points [n,2], matched indices i (queryIdx = trainIdx = i))."""
     img1, img2 = _u8(img1), _u8(img2)
     h, w = img1.shape
@@ -351,5 +351,14 @@ def search_by_opflow(img1, img2, cam1, keys2_xy):
     n = len(pts)
     cur = np.zeros((max(n, 1), 2), np.float32)
     idx = np.zeros(max(n, 1), np.int32)
-    m = _chk(lib().orc_search_by_opflow(_p(img1), _p(img2), w, h, w, _p(cam1), _p(pts), n, _p(cur), _p(idx)))
+    m = _chk(lib().orc_search_by_opflow(_p(img1), _p(img2), w, h, w, _p(cam1), _p(pts), n, int(equalized), _p(cur), _p(idx)))
     return cur[:n], idx[:m].copy()
+
+
+def clahe(img, clip_limit=3.0, tiles=(8, 8)):
+    """Frame::Equalize (Frame.cpp:453-458): cv::createCLAHE(3.0, Size(8, 8))->apply, restated (parity unpinned)."""
+    img = _u8(img)
+    h, w = img.shape
+    out = np.zeros_like(img)
+    _chk(lib().orc_clahe(_p(img), w, h, w, C.c_double(clip_limit), int(tiles[0]), int(tiles[1]), _p(out), w))
+    return out

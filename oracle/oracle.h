@@ -103,8 +103,10 @@ int orc_pyr_down(const uint8_t* src, int w, int h, int stride, uint8_t* dst, int
 /* returns the top pyramid level used (<= max_level), or < 0 on error */
 int orc_optical_flow_pyr_lk(const uint8_t* prev, const uint8_t* next, int w, int h, int stride, const float* prev_pts, int n,
                             int win, int max_level, float* next_pts, uint8_t* status, float* err /* nullable */);
+/* Frame::Equalize (Frame.cpp:453-458) = cv::CLAHE(clip_limit, tiles).apply, restated; parity unpinned */
+int orc_clahe(const uint8_t* src, int w, int h, int stride, double clip_limit, int tiles_x, int tiles_y, uint8_t* dst, int dstride);
 int orc_search_by_opflow(const uint8_t* img1, const uint8_t* img2, int w, int h, int stride, const tb_camera* cam1,
-                         const float* keys2_xy, int n, float* cur_points, int32_t* match_idx);
+                         const float* keys2_xy, int n, int equalized, float* cur_points, int32_t* match_idx);
 
 #ifdef __cplusplus
 }

@@ -197,11 +197,18 @@ int orc_optical_flow_pyr_lk(const uint8_t* prev, const uint8_t* next, int w, int
     return max_level;
 }
 
-/* Matcher::searchByOPFlow(F1, F2, cur_points, equalized = false, reject = false), matcher.cpp:724-768: img2 / keys2 belong
+/* Matcher::searchByOPFlow(F1, F2, cur_points, equalized, reject = false), matcher.cpp:724-768: img2 / keys2 belong
  * to F2 (the frame whose keys are tracked), img1 / cam1 to F1. Returns the number of matches (queryIdx = trainIdx = i). */
+int orc_clahe(const uint8_t* src, int w, int h, int stride, double clip_limit, int tiles_x, int tiles_y, uint8_t* dst, int dstride);
+
 int orc_search_by_opflow(const uint8_t* img1, const uint8_t* img2, int w, int h, int stride, const tb_camera* cam1,
-                         const float* keys2_xy, int n, float* cur_points, int32_t* match_idx) {
-    std::vector<uint8_t> status(n > 0 ? n : 1);
+                         const float* keys2_xy, int n, int equalized, float* cur_points, int32_t* match_idx) {
+    std::vector<uint8_t> status(n > 0 ? n : 1), eq;
+    if (equalized) { /* matcher.cpp:736-739: img1 = F1->Equalize() */
+        eq.resize((size_t)stride * h);
+        if (orc_clahe(img1, w, h, stride, 3.0, 8, 8, eq.data(), stride) < 0) return -1;
+        img1 = eq.data();
+    }
     std::vector<float> err(n > 0 ? n : 1);
     if (orc_optical_flow_pyr_lk(img2, img1, w, h, stride, keys2_xy, n, 21, 3, cur_points, status.data(), err.data()) < 0) return -1;
     int m = 0;
@@ -216,3 +223,64 @@ int orc_search_by_opflow(const uint8_t* img1, const uint8_t* img2, int w, int h,
 }
 
 }  // extern "C"
+
+/* Frame::Equalize, src/types/Frame.cpp:453-458: cv::createCLAHE(3.0, Size(8, 8))->apply(level 0, out).
+ * cv::CLAHE is OpenCV 3.3 (imgproc/clahe.cpp), not in the reference tree: restated from its published structure, PARITY
+ * UNPINNED -- per-tile histogram, clip at max(1, (int)(clipLimit * tileArea / 256)), the excess redistributed as
+ * excess / 256 to every bin plus one to each of the first (excess % 256) bins (the 3.3-era rule; later releases spread
+ * the remainder with a stride), LUT = saturate(cvRound(cumsum * 255 / tileArea)), then per pixel the bilinear blend of
+ * the four neighbouring tiles' LUT values in float. Images whose size is not a multiple of the tile grid are extended
+ * to the right / bottom with BORDER_REFLECT_101 for the histograms only. */
+extern "C" int orc_clahe(const uint8_t* src, int w, int h, int stride, double clip_limit, int tiles_x, int tiles_y, uint8_t* dst,
+                         int dstride) {
+    if (w < 1 || h < 1 || tiles_x < 1 || tiles_y < 1) return -1;
+    int ew = w, eh = h;
+    if (w % tiles_x || h % tiles_y) { ew = w + (tiles_x - w % tiles_x); eh = h + (tiles_y - h % tiles_y); }
+    if (ew - w >= w || eh - h >= h) return -1; /* reflection would leave the image */
+    const int tw = ew / tiles_x, th = eh / tiles_y, area = tw * th;
+    const float lutScale = (float)255 / (float)area;
+    int clip = 0;
+    if (clip_limit > 0.0) { clip = (int)(clip_limit * area / 256); if (clip < 1) clip = 1; }
+    std::vector<uint8_t> lut((size_t)tiles_x * tiles_y * 256);
+    for (int ty = 0; ty < tiles_y; ty++)
+        for (int tx = 0; tx < tiles_x; tx++) {
+            int hist[256] = {0};
+            for (int y = ty * th; y < (ty + 1) * th; y++)
+                for (int x = tx * tw; x < (tx + 1) * tw; x++) hist[src[(size_t)refl101(y, h) * stride + refl101(x, w)]]++;
+            if (clip > 0) {
+                int clipped = 0;
+                for (int i = 0; i < 256; i++)
+                    if (hist[i] > clip) { clipped += hist[i] - clip; hist[i] = clip; }
+                const int batch = clipped / 256, residual = clipped - batch * 256;
+                for (int i = 0; i < 256; i++) hist[i] += batch;
+                for (int i = 0; i < residual; i++) hist[i]++;
+            }
+            uint8_t* L = &lut[((size_t)ty * tiles_x + tx) * 256];
+            int sum = 0;
+            for (int i = 0; i < 256; i++) {
+                sum += hist[i];
+                const long r = lrintf((float)sum * lutScale);
+                L[i] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+            }
+        }
+    const float inv_tw = 1.0f / (float)tw, inv_th = 1.0f / (float)th;
+    for (int y = 0; y < h; y++) {
+        const float tyf = (float)y * inv_th - 0.5f;
+        int ty1 = (int)floorf(tyf), ty2 = ty1 + 1;
+        const float ya = tyf - (float)ty1, ya1 = 1.0f - ya;
+        ty1 = ty1 < 0 ? 0 : ty1; ty2 = ty2 > tiles_y - 1 ? tiles_y - 1 : ty2;
+        for (int x = 0; x < w; x++) {
+            const float txf = (float)x * inv_tw - 0.5f;
+            int tx1 = (int)floorf(txf), tx2 = tx1 + 1;
+            const float xa = txf - (float)tx1, xa1 = 1.0f - xa;
+            tx1 = tx1 < 0 ? 0 : tx1; tx2 = tx2 > tiles_x - 1 ? tiles_x - 1 : tx2;
+            const int v = src[(size_t)y * stride + x];
+            const float l11 = lut[((size_t)ty1 * tiles_x + tx1) * 256 + v], l12 = lut[((size_t)ty1 * tiles_x + tx2) * 256 + v];
+            const float l21 = lut[((size_t)ty2 * tiles_x + tx1) * 256 + v], l22 = lut[((size_t)ty2 * tiles_x + tx2) * 256 + v];
+            const float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
+            const long r = lrintf(res);
+            dst[(size_t)y * dstride + x] = (uint8_t)(r < 0 ? 0 : r > 255 ? 255 : r);
+        }
+    }
+    return 0;
+}

@@ -133,14 +133,14 @@ int main(int argc, char** argv)
     }
     for (int i2 = 0; i2 < n2p; i2++) nomp2[i2] = frame2_ptr->GetMapPoint(i2) ? 0 : 1;
 
-    // LocalBA::AddMapPointsByStereo's matcher call (LocalBA.cpp:54) without the two stages that are not built
-    // (equalized = CLAHE, reject = RANSAC F): the left frame's keys tracked into the right image
+    // LocalBA::AddMapPointsByStereo's matcher call (LocalBA.cpp:54) without the stage that is not built (reject =
+    // RANSAC F): the left frame's keys tracked into the CLAHE-equalised right image
     std::vector<cv::Point2f> flow_pts;
-    auto fmatches = matcher_ptr->searchByOPFlow(frame2_ptr, frame1_ptr, flow_pts, false, false);
+    auto fmatches = matcher_ptr->searchByOPFlow(frame2_ptr, frame1_ptr, flow_pts, true, false);
     bool threw = false;
     try { std::vector<cv::Point2f> tmp; matcher_ptr->searchByOPFlow(frame2_ptr, frame1_ptr, tmp, true, true); }
     catch (const std::invalid_argument&) { threw = true; }
-    if (!threw) { std::cerr << "searchByOPFlow(equalized, reject) must refuse" << std::endl; return 3; }
+    if (!threw) { std::cerr << "searchByOPFlow(reject) must refuse" << std::endl; return 3; }
 
     std::ofstream o(argv[4], std::ios::binary);
     put(o, keypoints1.data(), keypoints1.size()); put(o, descriptors1.data, (size_t)descriptors1.rows * 32);

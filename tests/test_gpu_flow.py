@@ -63,11 +63,12 @@ def test_search_by_opflow(ctx):
     ocur, oidx = oracle.search_by_opflow(R, L, cam, pts)
     assert np.array_equal(cur.view(np.uint32), ocur.view(np.uint32))
     assert np.array_equal(m["queryIdx"], oidx) and np.array_equal(m["trainIdx"], oidx) and (m["imgIdx"] == -1).all()
+    cur, m = ctx.search_by_opflow(R, L, cam, pts, equalized=True)   # F1's image through Frame::Equalize first
+    ocur, oidx = oracle.search_by_opflow(R, L, cam, pts, equalized=True)
+    assert np.array_equal(cur.view(np.uint32), ocur.view(np.uint32)) and np.array_equal(m["queryIdx"], oidx)
     with pytest.raises(capi.TBError) as e:
-        ctx.search_by_opflow(R, L, cam, pts, equalized=True)
-    assert e.value.code == capi.TB_EUNSUPPORTED
-    with pytest.raises(capi.TBError):
         ctx.search_by_opflow(R, L, cam, pts, reject=True)
+    assert e.value.code == capi.TB_EUNSUPPORTED
     assert len(ctx.search_by_opflow(R, L, cam, np.zeros((0, 2), np.float32))[1]) == 0
 
 
@@ -97,3 +98,18 @@ def test_lk_batch_device_resident(ctx):
         assert np.array_equal(out[p, :n].view(np.uint32), on.view(np.uint32)) and np.array_equal(st[p, :n], os_)
         assert np.array_equal(er[p, :n].view(np.uint32), oe.view(np.uint32))
         assert (out[p, n:] == -7.0).all() and (st[p, n:] == 9).all()   # slots past the count are not written
+
+
+@pytest.mark.parametrize("seed,w,h", [(1, 1241, 376), (2, 640, 480), (3, 333, 211), (4, 64, 64)])
+def test_clahe(ctx, seed, w, h):
+    img = synth.frame(seed, w, h)
+    assert np.array_equal(ctx.clahe(img), oracle.clahe(img))
+    low = (img // 4 + 90).astype(np.uint8)          # low contrast: clipping and redistribution matter
+    assert np.array_equal(ctx.clahe(low), oracle.clahe(low))
+    assert np.array_equal(ctx.clahe(low, 40.0, (4, 3)), oracle.clahe(low, 40.0, (4, 3)))
+    assert np.array_equal(ctx.clahe(low, 0.0), oracle.clahe(low, 0.0))   # no clipping: plain tile equalisation
+
+
+def test_clahe_kitti(ctx, kitti_pair):
+    for img in kitti_pair:
+        assert np.array_equal(ctx.clahe(img), oracle.clahe(img))

@@ -72,9 +72,9 @@ def test_reference_style_driver_on_shims(golden, kitti_pair):
     assert len(po) > 50 and np.array_equal(pm, po)
     mo = oracle.search_by_projection_map(T, cam, 1241, 376, k1now, d1.reshape(-1, 32), taken1, mp, mpd.reshape(-1, 32), sf, 3.0, 0.8)
     assert len(mo) > 5 and np.array_equal(mm, mo)
-    # optical-flow matcher through the class API == oracle: the left frame's keys tracked into the right image
+    # optical-flow matcher through the class API == oracle: the left frame's keys tracked into the equalised right image
     imgL, imgR = kitti_pair
-    ocur, oidx = oracle.search_by_opflow(imgR, imgL, cam, np.stack([k1now["x"], k1now["y"]], 1))
+    ocur, oidx = oracle.search_by_opflow(imgR, imgL, cam, np.stack([k1now["x"], k1now["y"]], 1), equalized=True)
     assert np.array_equal(np.stack([fpts["x"], fpts["y"]], 1).view(np.uint32), ocur.view(np.uint32))
     assert len(oidx) > 200 and np.array_equal(fm["queryIdx"], oidx) and np.array_equal(fm["trainIdx"], oidx)
 

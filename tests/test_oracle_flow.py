@@ -54,3 +54,19 @@ def test_search_by_opflow_filters_frame():
     u, v = cur[:, 0].astype(np.int32), cur[:, 1].astype(np.int32)
     keep = (st > 0) & (u >= 0) & (u < 640) & (v >= 0) & (v < 480)
     assert np.array_equal(idx, np.nonzero(keep)[0]) and len(idx) > 50
+
+
+def test_clahe_properties():
+    g = synth.frame(1, 640, 480)
+    low = (g // 4 + 90).astype(np.uint8)
+    e = oracle.clahe(low)
+    assert e.std() > 1.5 * low.std()                      # contrast is stretched
+    assert np.array_equal(oracle.clahe(low), e)           # deterministic
+    # without a clip limit a single tile is plain histogram equalisation: LUT = round(cdf * 255 / area)
+    one = oracle.clahe(low, 0.0, (1, 1))
+    hist = np.bincount(low.ravel(), minlength=256)
+    lut = np.clip(np.rint(np.cumsum(hist).astype(np.float32) * np.float32(255.0 / low.size)), 0, 255).astype(np.uint8)
+    assert np.array_equal(one, lut[low])
+    # sizes that are not multiples of the tile grid take the padded-histogram path
+    odd = synth.frame(2, 333, 211)
+    assert oracle.clahe(odd).shape == odd.shape

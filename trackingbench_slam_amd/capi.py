@@ -39,7 +39,7 @@ EXPORTS = [
     "tb_search_by_violence", "tb_search_by_projection", "tb_search_by_projection_map", "tb_frame_grid_batch_dev",
     "tb_search_by_projection_batch_dev", "tb_search_by_projection_map_batch_dev",
     "tb_search_by_violence_batch_dev", "tb_pose_opt", "tb_pose_opt_batch_dev", "tb_local_ba", "tb_local_ba_batch_dev",
-    "tb_optical_flow_pyr_lk", "tb_optical_flow_pyr_lk_dev", "tb_optical_flow_pyr_lk_batch_dev", "tb_search_by_opflow",
+    "tb_clahe", "tb_clahe_dev", "tb_optical_flow_pyr_lk", "tb_optical_flow_pyr_lk_dev", "tb_optical_flow_pyr_lk_batch_dev", "tb_search_by_opflow",
 ]
 
 
@@ -268,6 +268,15 @@ class Context:
                                                C.c_float(nratio), int(histo_len), int(check_orientation), _p(out), len(out),
                                                C.byref(n)))
         return out[:n.value].copy()
+
+    def clahe(self, img, clip_limit=3.0, tiles=(8, 8)):
+        """Frame::Equalize (reference Frame.cpp:453-458): cv::createCLAHE(3.0, Size(8, 8))->apply."""
+        img = np.ascontiguousarray(img, np.uint8)
+        assert img.ndim == 2
+        h, w = img.shape
+        out = np.zeros_like(img)
+        self.check(lib().tb_clahe(self._h, _p(img), w, h, w, C.c_double(clip_limit), int(tiles[0]), int(tiles[1]), _p(out), w))
+        return out
 
     def optical_flow_pyr_lk(self, prev, nxt, prev_pts, win=21, max_level=3):
         """cv::calcOpticalFlowPyrLK as Matcher::searchByOPFlow calls it (reference matcher.cpp:744).

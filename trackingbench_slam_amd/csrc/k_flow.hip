@@ -291,3 +291,80 @@ int tbk_lk_track(tb_ctx* ctx, int npairs, const uint8_t* d_prev, const uint8_t* 
     TB_HIP(ctx, hipGetLastError());
     return TB_OK;
 }
+
+/* ---- Frame::Equalize, src/types/Frame.cpp:453-458: cv::createCLAHE(3.0, Size(8, 8))->apply(level 0).
+ * cv::CLAHE is OpenCV 3.3 (not in the reference tree): restated, parity unpinned (DESIGN.md section 2 lists what: tile
+ * histograms over the reflect-101 extended image, clip at max(1, (int)(clip * area / 256)), excess / 256 to every bin
+ * plus one to each of the first excess % 256 bins, LUT = saturate(cvRound(cumsum * 255 / area))).
+ *   k_clahe_lut   : one workgroup per tile -- LDS histogram (integer atomics), clip, redistribute, prefix sum, LUT
+ *   k_clahe_apply : thread per pixel -- bilinear blend of the four neighbouring tiles' LUT entries: (l11 xa1 + l12 xa) ya1 +
+ *                   (l21 xa1 + l22 xa) ya in float, no contraction */
+__global__ void __launch_bounds__(256)
+k_clahe_lut(const uint8_t* __restrict__ src, int w, int h, int stride, int tw, int th, int clip, float lutScale,
+            uint8_t* __restrict__ lut) {
+    __shared__ int hist[256];
+    __shared__ int tmp[8];
+    const int tx = blockIdx.x, ty = blockIdx.y, tid = threadIdx.x;
+    hist[tid] = 0;
+    __syncthreads();
+    for (int p = tid; p < tw * th; p += 256) {
+        const int yy = p / tw, xx = p - yy * tw;
+        atomicAdd(&hist[src[(size_t)lk_refl(ty * th + yy, h) * stride + lk_refl(tx * tw + xx, w)]], 1);
+    }
+    __syncthreads();
+    int mine = hist[tid];
+    if (clip > 0) {
+        const int over = mine > clip ? mine - clip : 0;
+        mine -= over;
+        int tot = tb_wave_sum(over);
+        if ((tid & 63) == 0) tmp[tid >> 6] = tot;
+        __syncthreads();
+        const int clipped = tmp[0] + tmp[1] + tmp[2] + tmp[3];
+        const int batch = clipped / 256, residual = clipped - batch * 256;
+        mine += batch + (tid < residual ? 1 : 0);
+        __syncthreads();
+    }
+    hist[tid] = mine;
+    __syncthreads();
+    const int before = tb_block_excl_scan(hist, 256, tmp); /* in place; returns the total */
+    (void)before;
+    const int sum = hist[tid] + mine;                      /* inclusive */
+    const int r = __float2int_rn((float)sum * lutScale);
+    lut[((size_t)ty * gridDim.x + tx) * 256 + tid] = (uint8_t)min(max(r, 0), 255);
+}
+
+__global__ void __launch_bounds__(256)
+k_clahe_apply(const uint8_t* __restrict__ src, int w, int h, int stride, int tiles_x, int tiles_y, float inv_tw, float inv_th,
+              const uint8_t* __restrict__ lut, uint8_t* __restrict__ dst, int dstride) {
+    const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (x >= w || y >= h) return;
+    const float tyf = (float)y * inv_th - 0.5f, txf = (float)x * inv_tw - 0.5f;
+    int ty1 = (int)floorf(tyf), tx1 = (int)floorf(txf);
+    const float ya = tyf - (float)ty1, ya1 = 1.0f - ya, xa = txf - (float)tx1, xa1 = 1.0f - xa;
+    const int ty2 = min(ty1 + 1, tiles_y - 1), tx2 = min(tx1 + 1, tiles_x - 1);
+    ty1 = max(ty1, 0); tx1 = max(tx1, 0);
+    const int v = src[(size_t)y * stride + x];
+    const float l11 = lut[((size_t)ty1 * tiles_x + tx1) * 256 + v], l12 = lut[((size_t)ty1 * tiles_x + tx2) * 256 + v];
+    const float l21 = lut[((size_t)ty2 * tiles_x + tx1) * 256 + v], l22 = lut[((size_t)ty2 * tiles_x + tx2) * 256 + v];
+    const float res = (l11 * xa1 + l12 * xa) * ya1 + (l21 * xa1 + l22 * xa) * ya;
+    dst[(size_t)y * dstride + x] = (uint8_t)min(max(__float2int_rn(res), 0), 255);
+}
+
+int tbk_clahe(tb_ctx* ctx, const uint8_t* d_src, int w, int h, int stride, double clip_limit, int tiles_x, int tiles_y,
+              uint8_t* d_dst, int dstride, uint8_t* d_lut) {
+    if (tiles_x < 1 || tiles_y < 1 || tiles_x * tiles_y > 65535) return tb_fail(ctx, TB_EINVAL, "CLAHE: bad tile grid");
+    int ew = w, eh = h;
+    if (w % tiles_x || h % tiles_y) { ew = w + (tiles_x - w % tiles_x); eh = h + (tiles_y - h % tiles_y); }
+    if (ew - w >= w || eh - h >= h) return tb_fail(ctx, TB_EINVAL, "CLAHE: image smaller than its tile grid");
+    const int tw = ew / tiles_x, th = eh / tiles_y, area = tw * th;
+    int clip = 0;
+    if (clip_limit > 0.0) { clip = (int)(clip_limit * area / 256); if (clip < 1) clip = 1; }
+    tb_prof_begin(ctx, "k_clahe");
+    hipLaunchKernelGGL(k_clahe_lut, dim3(tiles_x, tiles_y), dim3(256), 0, ctx->stream, d_src, w, h, stride, tw, th, clip,
+                       (float)255 / (float)area, d_lut);
+    hipLaunchKernelGGL(k_clahe_apply, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, ctx->stream, d_src, w, h, stride, tiles_x, tiles_y,
+                       1.0f / (float)tw, 1.0f / (float)th, d_lut, d_dst, dstride);
+    tb_prof_end(ctx);
+    TB_HIP(ctx, hipGetLastError());
+    return TB_OK;
+}

@@ -1230,6 +1230,29 @@ int tb_local_ba(tb_ctx* ctx, const double K[4], int nkf, int nfixed, float* pose
     return TB_OK;
 }
 
+int tb_clahe_dev(tb_ctx* ctx, const uint8_t* src, int width, int height, int stride, double clip_limit, int tiles_x, int tiles_y,
+                 uint8_t* dst, int dst_stride) {
+    if (!ctx || !src || !dst || width < 1 || height < 1 || stride < width || dst_stride < width || tiles_x < 1 || tiles_y < 1) return TB_EINVAL;
+    void* lut;
+    int rc;
+    if ((rc = tb_scratch(ctx, 6, (size_t)tiles_x * tiles_y * 256, &lut))) return rc;
+    return tbk_clahe(ctx, src, width, height, stride, clip_limit, tiles_x, tiles_y, dst, dst_stride, (uint8_t*)lut);
+}
+
+int tb_clahe(tb_ctx* ctx, const uint8_t* src, int width, int height, int stride, double clip_limit, int tiles_x, int tiles_y,
+             uint8_t* dst, int dst_stride) {
+    if (!ctx || !src || !dst || width < 1 || height < 1 || stride < width || dst_stride < width || tiles_x < 1 || tiles_y < 1) return TB_EINVAL;
+    void *ds, *dd;
+    int rc;
+    if ((rc = tb_scratch(ctx, 0, (size_t)stride * height, &ds))) return rc;
+    if ((rc = tb_scratch(ctx, 1, (size_t)dst_stride * height, &dd))) return rc;
+    TB_HIP(ctx, hipMemcpyAsync(ds, src, (size_t)stride * height, hipMemcpyHostToDevice, ctx->stream));
+    if ((rc = tb_clahe_dev(ctx, (const uint8_t*)ds, width, height, stride, clip_limit, tiles_x, tiles_y, (uint8_t*)dd, dst_stride))) return rc;
+    TB_HIP(ctx, hipMemcpy2DAsync(dst, dst_stride, dd, dst_stride, width, height, hipMemcpyDeviceToHost, ctx->stream));
+    TB_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return TB_OK;
+}
+
 int tb_optical_flow_pyr_lk_dev(tb_ctx* ctx, const uint8_t* prev, const uint8_t* next, int width, int height, int stride,
                                const float* prev_pts, int n, int win, int max_level, float* next_pts, uint8_t* status, float* err) {
     if (!ctx || !prev || !next || n < 0 || width < 1 || height < 1 || stride < width) return TB_EINVAL;
@@ -1294,11 +1317,16 @@ int tb_search_by_opflow(tb_ctx* ctx, const uint8_t* img1, const uint8_t* img2, i
                         tb_match* out, int cap, int* count) {
     if (!ctx || !count || !cam1 || n < 0 || cap < 0 || (n && (!cur_points || !keys2_xy)) || (cap && !out)) return TB_EINVAL;
     *count = 0;
-    if (equalized) return tb_fail(ctx, TB_EUNSUPPORTED, "searchByOPFlow: equalized (Frame::Equalize = cv::CLAHE) is not built");
     if (reject) return tb_fail(ctx, TB_EUNSUPPORTED, "searchByOPFlow: reject (rejectWithF = cv::findFundamentalMat RANSAC) is not built");
-    std::vector<uint8_t> status((size_t)std::max(n, 1));
+    std::vector<uint8_t> status((size_t)std::max(n, 1)), eq;
+    int rc;
+    if (equalized) { /* matcher.cpp:736-739: img1 = F1->Equalize() = CLAHE(3.0, 8 x 8) of F1's level 0 (Frame.cpp:453-458) */
+        eq.resize((size_t)stride * height);
+        if ((rc = tb_clahe(ctx, img1, width, height, stride, 3.0, 8, 8, eq.data(), stride))) return rc;
+        img1 = eq.data();
+    }
     /* matcher.cpp:744: calcOpticalFlowPyrLK(img2, img1, keys of F2, cur_points, ..., Size(21, 21), 3) */
-    int rc = tb_optical_flow_pyr_lk(ctx, img2, img1, width, height, stride, keys2_xy, n, 21, 3, cur_points, status.data(), nullptr, nullptr);
+    rc = tb_optical_flow_pyr_lk(ctx, img2, img1, width, height, stride, keys2_xy, n, 21, 3, cur_points, status.data(), nullptr, nullptr);
     if (rc) return rc;
     int m = 0;
     for (int i = 0; i < n; i++) {

@@ -238,7 +238,6 @@ namespace TRACKING_BENCH
     std::vector<cv::DMatch> Matcher::searchByOPFlow(const std::shared_ptr<Frame>& F1, const std::shared_ptr<Frame>& F2,
                                                     std::vector<cv::Point2f>& cur_points, bool equalized, bool reject, bool MapPointOnly)
     {
-        if (equalized) throw std::invalid_argument("Matcher::searchByOPFlow: equalized (Frame::Equalize, CLAHE) is not built");
         if (reject) throw std::invalid_argument("Matcher::searchByOPFlow: reject (rejectWithF, RANSAC fundamental matrix) is not built");
         (void)MapPointOnly; /* the reference ignores it as well */
         cv::Mat img1 = F1->GetImage(), img2 = F2->GetImage();
@@ -252,7 +251,7 @@ namespace TRACKING_BENCH
         cam.width = F1->GetCameraModel()->Width(); cam.height = F1->GetCameraModel()->Height();
         std::vector<cv::DMatch> out(std::max<size_t>(k2.size(), 1));
         int n = 0;
-        check(tb_search_by_opflow(shim_ctx(), img1.data, img2.data, img1.cols, img1.rows, (int)img1.step, &cam, xy.data(), (int)k2.size(), 0, 0,
+        check(tb_search_by_opflow(shim_ctx(), img1.data, img2.data, img1.cols, img1.rows, (int)img1.step, &cam, xy.data(), (int)k2.size(), equalized ? 1 : 0, 0,
                                   cur.data(), reinterpret_cast<tb_match*>(out.data()), (int)out.size(), &n), "Matcher::searchByOPFlow");
         cur_points.resize(k2.size());
         for (size_t i = 0; i < k2.size(); i++) cur_points[i] = cv::Point2f(cur[2 * i], cur[2 * i + 1]);
