@@ -66,6 +66,20 @@ def main():
             a = (k1, d1, k2, d2, w, h, 0, nl, r, tl, nr, 30, bool(rng.integers(0, 2)))
             if not same_rec(ctx.search_by_violence(*a), oracle.search_by_violence(*a)):
                 fail("search_by_violence", w=w, h=h, r=r, tl=tl, nr=nr)
+        # optical flow (img -> img2 are unrelated frames: most tracks fail or wander, which is the interesting part) and CLAHE
+        npt, ml = int(rng.integers(1, 400)), int(rng.integers(0, 6))
+        pts = np.stack([rng.uniform(-30, w + 30, npt), rng.uniform(-30, h + 30, npt)], 1).astype(np.float32)
+        if len(k1):
+            pts[:min(npt, len(k1))] = np.stack([k1["x"], k1["y"]], 1)[:npt]
+        shifted = np.roll(img, (int(rng.integers(-6, 7)), int(rng.integers(-9, 10))), (0, 1)) if it % 2 else img2
+        fg, fo = ctx.optical_flow_pyr_lk(img, shifted, pts, max_level=ml), oracle.optical_flow_pyr_lk(img, shifted, pts, max_level=ml)
+        if not (fg[3] == fo[3] and np.array_equal(fg[1], fo[1]) and np.array_equal(fg[0].view(np.uint32), fo[0].view(np.uint32)) and
+                np.array_equal(fg[2].view(np.uint32), fo[2].view(np.uint32))):
+            fail("optical_flow_pyr_lk", w=w, h=h, npt=npt, ml=ml, status=(int(fg[1].sum()), int(fo[1].sum())))
+        clip, tiles = float(rng.choice([0.0, 0.5, 2.0, 3.0, 40.0])), (int(rng.integers(1, 10)), int(rng.integers(1, 10)))
+        low = (img // int(rng.integers(1, 6)) + int(rng.integers(0, 60))).astype(np.uint8)
+        if not np.array_equal(ctx.clahe(low, clip, tiles), oracle.clahe(low, clip, tiles)):
+            fail("clahe", w=w, h=h, clip=clip, tiles=tiles)
         c = synth.projection_case(int(rng.integers(0, 10 ** 6)), n1=int(rng.integers(50, 2500)), nmp=int(rng.integers(50, 2500)))
         nrat = float(rng.uniform(1, 15))
         pa = (c["Tcw"], c["cam"], c["width"], c["height"], c["k1"], c["d1"], c["taken1"], c["k2"], c["mp"], c["mp_desc"], c["sf"], nrat)
