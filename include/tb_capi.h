@@ -227,6 +227,15 @@ int tb_optical_flow_pyr_lk(tb_ctx* ctx, const uint8_t* prev, const uint8_t* next
 int tb_search_by_opflow(tb_ctx* ctx, const uint8_t* img1, const uint8_t* img2, int width, int height, int stride,
                         const tb_camera* cam1, const float* keys2_xy, int n, int equalized, int reject,
                         float* cur_points, tb_match* out, int cap, int* count);
+/* Batched device-resident searchByOPFlow: npairs (F1, F2) image pairs of one geometry (pair p at img1 / img2 +
+ * p * image_pitch bytes), F2's keys of pair p at keys2_xy + p * pts_pitch (x, y) records (counts[p] of them; counts
+ * nullable = pts_pitch each). Outputs per pair: cur_points and status (1 = matched, after the IsInFrame filter) at slot
+ * p * pts_pitch, DMatch(i, i) records in index order at out + p * cap, their number in out_counts[p] (clamped to cap).
+ * cam1 is a HOST pointer (only width / height are read). Asynchronous on the context's stream. */
+int tb_search_by_opflow_batch_dev(tb_ctx* ctx, int npairs, const uint8_t* img1, const uint8_t* img2, int width, int height,
+                                  int stride, size_t image_pitch, const tb_camera* cam1, const float* keys2_xy,
+                                  const int32_t* counts, int pts_pitch, int equalized, int reject, float* cur_points,
+                                  uint8_t* status, tb_match* out, int cap, int32_t* out_counts);
 /* Device-resident form of the tracker: images, points and outputs in HBM, asynchronous on the context's stream. */
 int tb_optical_flow_pyr_lk_dev(tb_ctx* ctx, const uint8_t* prev, const uint8_t* next, int width, int height, int stride,
                                const float* prev_pts, int n, int win, int max_level, float* next_pts, uint8_t* status,

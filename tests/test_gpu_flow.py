@@ -113,3 +113,37 @@ def test_clahe(ctx, seed, w, h):
 def test_clahe_kitti(ctx, kitti_pair):
     for img in kitti_pair:
         assert np.array_equal(ctx.clahe(img), oracle.clahe(img))
+
+
+@pytest.mark.parametrize("equalized", [False, True])
+def test_search_by_opflow_batch_device_resident(ctx, equalized):
+    """Batched device form of Matcher::searchByOPFlow (CLAHE -> LK -> IsInFrame filter -> DMatch compaction) == oracle."""
+    import torch
+    dev = torch.device("cuda", 0)
+    W, H, cap = 333, 211, 320
+    pairs = [synth.frame(60 + i, W, H, stereo=True) for i in range(3)]
+    rng = np.random.default_rng(8)
+    counts = np.array([cap, 150, 0], np.int32)
+    pts = rng.uniform(-5, 338, (3, cap, 2)).astype(np.float32)
+    pts[..., 1] = rng.uniform(-5, 216, (3, cap))
+    F2 = torch.from_numpy(np.stack([p[0] for p in pairs])).to(dev)       # the frame whose keys are tracked (left)
+    F1 = torch.from_numpy(np.stack([p[1] for p in pairs])).to(dev)
+    dp, dc = torch.from_numpy(pts).to(dev), torch.from_numpy(counts).to(dev)
+    cur = torch.zeros((3, cap, 2), dtype=torch.float32, device=dev)
+    st = torch.zeros((3, cap), dtype=torch.uint8, device=dev)
+    out = torch.zeros((3, cap, 4), dtype=torch.int32, device=dev)
+    oc = torch.zeros(3, dtype=torch.int32, device=dev)
+    cam = oracle.camera(300, 300, W / 2, H / 2, W, H)
+    ctx.search_by_opflow_batch_dev(3, F1.data_ptr(), F2.data_ptr(), W, H, W, W * H, cam, dp.data_ptr(), dc.data_ptr(), cap,
+                                   cur.data_ptr(), st.data_ptr(), out.data_ptr(), cap, oc.data_ptr(), equalized=equalized)
+    ctx.synchronize()
+    cur, st, out, oc = cur.cpu().numpy(), st.cpu().numpy(), out.cpu().numpy(), oc.cpu().numpy()
+    for p in range(3):
+        n = counts[p]
+        ocur, oidx = oracle.search_by_opflow(pairs[p][1], pairs[p][0], cam, pts[p, :n], equalized=equalized)
+        assert np.array_equal(cur[p, :n].view(np.uint32), ocur.view(np.uint32))
+        assert oc[p] == len(oidx) and np.array_equal(out[p, :oc[p], 0], oidx) and np.array_equal(out[p, :oc[p], 1], oidx)
+        assert np.array_equal(np.nonzero(st[p, :n])[0], oidx)
+    with pytest.raises(capi.TBError):
+        ctx.search_by_opflow_batch_dev(3, F1.data_ptr(), F2.data_ptr(), W, H, W, W * H, cam, dp.data_ptr(), dc.data_ptr(), cap,
+                                       cur.ctypes.data, 0, 0, cap, 0, reject=True)

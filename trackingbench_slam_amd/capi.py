@@ -39,7 +39,7 @@ EXPORTS = [
     "tb_search_by_violence", "tb_search_by_projection", "tb_search_by_projection_map", "tb_frame_grid_batch_dev",
     "tb_search_by_projection_batch_dev", "tb_search_by_projection_map_batch_dev",
     "tb_search_by_violence_batch_dev", "tb_pose_opt", "tb_pose_opt_batch_dev", "tb_local_ba", "tb_local_ba_batch_dev",
-    "tb_clahe", "tb_clahe_dev", "tb_optical_flow_pyr_lk", "tb_optical_flow_pyr_lk_dev", "tb_optical_flow_pyr_lk_batch_dev", "tb_search_by_opflow",
+    "tb_clahe", "tb_clahe_dev", "tb_optical_flow_pyr_lk", "tb_optical_flow_pyr_lk_dev", "tb_optical_flow_pyr_lk_batch_dev", "tb_search_by_opflow", "tb_search_by_opflow_batch_dev",
 ]
 
 
@@ -308,6 +308,15 @@ class Context:
             self._h, int(npairs), C.c_void_p(prev_ptr), C.c_void_p(next_ptr), int(width), int(height), int(stride),
             C.c_size_t(image_pitch), C.c_void_p(pts_ptr), C.c_void_p(counts_ptr or None), int(pts_pitch), int(win), int(max_level),
             C.c_void_p(out_ptr), C.c_void_p(status_ptr), C.c_void_p(err_ptr or None)))
+
+    def search_by_opflow_batch_dev(self, npairs, img1_ptr, img2_ptr, width, height, stride, image_pitch, cam1, keys_ptr, counts_ptr,
+                                   pts_pitch, cur_ptr, status_ptr, out_ptr, cap, out_counts_ptr, equalized=False, reject=False):
+        """Batched device-resident Matcher::searchByOPFlow (cam1: host CAMERA record); asynchronous on the context's stream."""
+        cam1 = np.ascontiguousarray(cam1, CAMERA)
+        self.check(lib().tb_search_by_opflow_batch_dev(
+            self._h, int(npairs), C.c_void_p(img1_ptr), C.c_void_p(img2_ptr), int(width), int(height), int(stride),
+            C.c_size_t(image_pitch), _p(cam1), C.c_void_p(keys_ptr), C.c_void_p(counts_ptr or None), int(pts_pitch), int(equalized),
+            int(reject), C.c_void_p(cur_ptr), C.c_void_p(status_ptr), C.c_void_p(out_ptr), int(cap), C.c_void_p(out_counts_ptr)))
 
     def search_by_opflow(self, img1, img2, cam1, keys2_xy, equalized=False, reject=False):
         """Matcher::searchByOPFlow(F1, F2, cur_points, equalized, reject) (reference matcher.cpp:724-768).

@@ -300,11 +300,13 @@ int tbk_lk_track(tb_ctx* ctx, int npairs, const uint8_t* d_prev, const uint8_t* 
  *   k_clahe_apply : thread per pixel -- bilinear blend of the four neighbouring tiles' LUT entries: (l11 xa1 + l12 xa) ya1 +
  *                   (l21 xa1 + l22 xa) ya in float, no contraction */
 __global__ void __launch_bounds__(256)
-k_clahe_lut(const uint8_t* __restrict__ src, int w, int h, int stride, int tw, int th, int clip, float lutScale,
+k_clahe_lut(const uint8_t* __restrict__ src, int w, int h, int stride, size_t spitch, int tw, int th, int clip, float lutScale,
             uint8_t* __restrict__ lut) {
     __shared__ int hist[256];
     __shared__ int tmp[8];
     const int tx = blockIdx.x, ty = blockIdx.y, tid = threadIdx.x;
+    src += (size_t)blockIdx.z * spitch;                               /* blockIdx.z = image of the batch */
+    lut += (size_t)blockIdx.z * gridDim.x * gridDim.y * 256;
     hist[tid] = 0;
     __syncthreads();
     for (int p = tid; p < tw * th; p += 256) {
@@ -334,10 +336,13 @@ k_clahe_lut(const uint8_t* __restrict__ src, int w, int h, int stride, int tw, i
 }
 
 __global__ void __launch_bounds__(256)
-k_clahe_apply(const uint8_t* __restrict__ src, int w, int h, int stride, int tiles_x, int tiles_y, float inv_tw, float inv_th,
-              const uint8_t* __restrict__ lut, uint8_t* __restrict__ dst, int dstride) {
+k_clahe_apply(const uint8_t* __restrict__ src, int w, int h, int stride, size_t spitch, int tiles_x, int tiles_y, float inv_tw,
+              float inv_th, const uint8_t* __restrict__ lut, uint8_t* __restrict__ dst, int dstride, size_t dpitch) {
     const int x = blockIdx.x * 64 + (threadIdx.x & 63), y = blockIdx.y * 4 + (threadIdx.x >> 6);
     if (x >= w || y >= h) return;
+    src += (size_t)blockIdx.z * spitch;
+    dst += (size_t)blockIdx.z * dpitch;
+    lut += (size_t)blockIdx.z * tiles_x * tiles_y * 256;
     const float tyf = (float)y * inv_th - 0.5f, txf = (float)x * inv_tw - 0.5f;
     int ty1 = (int)floorf(tyf), tx1 = (int)floorf(txf);
     const float ya = tyf - (float)ty1, ya1 = 1.0f - ya, xa = txf - (float)tx1, xa1 = 1.0f - xa;
@@ -350,9 +355,10 @@ k_clahe_apply(const uint8_t* __restrict__ src, int w, int h, int stride, int til
     dst[(size_t)y * dstride + x] = (uint8_t)min(max(__float2int_rn(res), 0), 255);
 }
 
-int tbk_clahe(tb_ctx* ctx, const uint8_t* d_src, int w, int h, int stride, double clip_limit, int tiles_x, int tiles_y,
-              uint8_t* d_dst, int dstride, uint8_t* d_lut) {
-    if (tiles_x < 1 || tiles_y < 1 || tiles_x * tiles_y > 65535) return tb_fail(ctx, TB_EINVAL, "CLAHE: bad tile grid");
+int tbk_clahe(tb_ctx* ctx, int nimg, const uint8_t* d_src, int w, int h, int stride, size_t spitch, double clip_limit, int tiles_x,
+              int tiles_y, uint8_t* d_dst, int dstride, size_t dpitch, uint8_t* d_lut) {
+    if (tiles_x < 1 || tiles_y < 1 || tiles_x * tiles_y > 65535 || nimg < 1 || nimg > 65535)
+        return tb_fail(ctx, TB_EINVAL, "CLAHE: bad tile grid / image count");
     int ew = w, eh = h;
     if (w % tiles_x || h % tiles_y) { ew = w + (tiles_x - w % tiles_x); eh = h + (tiles_y - h % tiles_y); }
     if (ew - w >= w || eh - h >= h) return tb_fail(ctx, TB_EINVAL, "CLAHE: image smaller than its tile grid");
@@ -360,10 +366,51 @@ int tbk_clahe(tb_ctx* ctx, const uint8_t* d_src, int w, int h, int stride, doubl
     int clip = 0;
     if (clip_limit > 0.0) { clip = (int)(clip_limit * area / 256); if (clip < 1) clip = 1; }
     tb_prof_begin(ctx, "k_clahe");
-    hipLaunchKernelGGL(k_clahe_lut, dim3(tiles_x, tiles_y), dim3(256), 0, ctx->stream, d_src, w, h, stride, tw, th, clip,
+    hipLaunchKernelGGL(k_clahe_lut, dim3(tiles_x, tiles_y, nimg), dim3(256), 0, ctx->stream, d_src, w, h, stride, spitch, tw, th, clip,
                        (float)255 / (float)area, d_lut);
-    hipLaunchKernelGGL(k_clahe_apply, dim3((w + 63) / 64, (h + 3) / 4), dim3(256), 0, ctx->stream, d_src, w, h, stride, tiles_x, tiles_y,
-                       1.0f / (float)tw, 1.0f / (float)th, d_lut, d_dst, dstride);
+    hipLaunchKernelGGL(k_clahe_apply, dim3((w + 63) / 64, (h + 3) / 4, nimg), dim3(256), 0, ctx->stream, d_src, w, h, stride, spitch,
+                       tiles_x, tiles_y, 1.0f / (float)tw, 1.0f / (float)th, d_lut, d_dst, dstride, dpitch);
+    tb_prof_end(ctx);
+    TB_HIP(ctx, hipGetLastError());
+    return TB_OK;
+}
+
+/* Matcher::searchByOPFlow's bookkeeping on the device (matcher.cpp:746-766): a point stays matched when the tracker kept it
+ * and its truncated position lies in F1's frame (CameraModel.h:33-39); the matches DMatch(i, i) come out in index order.
+ * One wavefront per pair, ballot-ranked compaction. status is updated like the reference's vector. */
+__global__ void __launch_bounds__(64)
+k_flow_accept(const float* __restrict__ cur, uint8_t* __restrict__ status, const int32_t* __restrict__ counts, int pts_pitch, int width,
+              int height, tb_match* __restrict__ out, int cap, int32_t* __restrict__ out_counts) {
+    const int pair = blockIdx.x, lane = threadIdx.x;
+    const int n = counts ? min(counts[pair], pts_pitch) : pts_pitch;
+    const float* c = cur + (size_t)pair * pts_pitch * 2;
+    uint8_t* st = status + (size_t)pair * pts_pitch;
+    tb_match* o = out + (size_t)pair * cap;
+    int m = 0;
+    for (int i0 = 0; i0 < n; i0 += 64) {
+        const int i = i0 + lane;
+        bool keep = false;
+        if (i < n && st[i]) {
+            const float x = c[2 * i], y = c[2 * i + 1];
+            if (fabsf(x) < 2147483648.f && fabsf(y) < 2147483648.f) { /* out-of-range converts to INT_MIN on x86: not in frame */
+                const int u = (int)x, v = (int)y;
+                keep = u >= 0 && u < (int)((float)width * 1.f) && v >= 0 && v < (int)((float)height * 1.f);
+            }
+            if (!keep) st[i] = 0;
+        }
+        const unsigned long long b = __ballot(keep);
+        const int at = m + __popcll(b & ((1ull << lane) - 1ull));
+        if (keep && at < cap) { tb_match r; r.queryIdx = i; r.trainIdx = i; r.imgIdx = -1; r.distance = 3.402823466e+38f; o[at] = r; }
+        m += __popcll(b);
+    }
+    if (lane == 0) out_counts[pair] = min(m, cap);
+}
+
+int tbk_flow_accept(tb_ctx* ctx, int npairs, const float* d_cur, uint8_t* d_status, const int32_t* d_counts, int pts_pitch, int width,
+                    int height, tb_match* d_out, int cap, int32_t* d_out_counts) {
+    tb_prof_begin(ctx, "k_flow_accept");
+    hipLaunchKernelGGL(k_flow_accept, dim3(npairs), dim3(64), 0, ctx->stream, d_cur, d_status, d_counts, pts_pitch, width, height, d_out,
+                       cap, d_out_counts);
     tb_prof_end(ctx);
     TB_HIP(ctx, hipGetLastError());
     return TB_OK;

@@ -1236,7 +1236,7 @@ int tb_clahe_dev(tb_ctx* ctx, const uint8_t* src, int width, int height, int str
     void* lut;
     int rc;
     if ((rc = tb_scratch(ctx, 6, (size_t)tiles_x * tiles_y * 256, &lut))) return rc;
-    return tbk_clahe(ctx, src, width, height, stride, clip_limit, tiles_x, tiles_y, dst, dst_stride, (uint8_t*)lut);
+    return tbk_clahe(ctx, 1, src, width, height, stride, 0, clip_limit, tiles_x, tiles_y, dst, dst_stride, 0, (uint8_t*)lut);
 }
 
 int tb_clahe(tb_ctx* ctx, const uint8_t* src, int width, int height, int stride, double clip_limit, int tiles_x, int tiles_y,
@@ -1343,6 +1343,35 @@ int tb_search_by_opflow(tb_ctx* ctx, const uint8_t* img1, const uint8_t* img2, i
     }
     *count = m;
     return TB_OK;
+}
+
+int tb_search_by_opflow_batch_dev(tb_ctx* ctx, int npairs, const uint8_t* img1, const uint8_t* img2, int width, int height, int stride,
+                                  size_t image_pitch, const tb_camera* cam1, const float* keys2_xy, const int32_t* counts, int pts_pitch,
+                                  int equalized, int reject, float* cur_points, uint8_t* status, tb_match* out, int cap,
+                                  int32_t* out_counts) {
+    if (!ctx || !cam1 || npairs < 0 || pts_pitch < 0 || cap < 0 || width < 1 || height < 1 || stride < width) return TB_EINVAL;
+    if (reject) return tb_fail(ctx, TB_EUNSUPPORTED, "searchByOPFlow: reject (rejectWithF = cv::findFundamentalMat RANSAC) is not built");
+    if (npairs == 0) return TB_OK;
+    if (!img1 || !img2 || !out_counts || image_pitch < (size_t)stride * height) return TB_EINVAL;
+    if (pts_pitch && (!keys2_xy || !cur_points || !status || (cap && !out))) return TB_EINVAL;
+    int rc;
+    const uint8_t* next = img1;
+    if (equalized) { /* matcher.cpp:736-739: img1 = F1->Equalize() (Frame.cpp:453-458) */
+        void *eq, *lut;
+        if ((rc = tb_scratch(ctx, 5, (size_t)npairs * image_pitch, &eq))) return rc;
+        if ((rc = tb_scratch(ctx, 6, (size_t)npairs * 8 * 8 * 256, &lut))) return rc;
+        if ((rc = tbk_clahe(ctx, npairs, img1, width, height, stride, image_pitch, 3.0, 8, 8, (uint8_t*)eq, stride, image_pitch, (uint8_t*)lut))) return rc;
+        next = (const uint8_t*)eq;
+    }
+    if (pts_pitch) {
+        void* work;
+        if ((rc = tb_scratch(ctx, 7, tbk_lk_work_bytes(width, height, 3, npairs), &work))) return rc;
+        /* matcher.cpp:744: calcOpticalFlowPyrLK(img2, img1, keys of F2, cur_points, ..., Size(21, 21), 3) */
+        if ((rc = tbk_lk_track(ctx, npairs, img2, next, width, height, stride, image_pitch, keys2_xy, counts, pts_pitch, pts_pitch, 21, 3,
+                               cur_points, status, nullptr, work, nullptr)))
+            return rc;
+    }
+    return tbk_flow_accept(ctx, npairs, cur_points, status, counts, pts_pitch, cam1->width, cam1->height, out, cap, out_counts);
 }
 
 }  // extern "C"

@@ -167,8 +167,10 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
                        const tb_ba_obs* d_obs, const int32_t* d_counts, int obs_pitch, int iters, double* d_stats, void* d_work,
                        size_t work_bytes);
 size_t tbk_local_ba_work_bytes(int W, int nkf, int nfixed, int npt, int obs_pitch);
-int tbk_clahe(tb_ctx* ctx, const uint8_t* d_src, int w, int h, int stride, double clip_limit, int tiles_x, int tiles_y,
-              uint8_t* d_dst, int dstride, uint8_t* d_lut);
+int tbk_clahe(tb_ctx* ctx, int nimg, const uint8_t* d_src, int w, int h, int stride, size_t spitch, double clip_limit, int tiles_x,
+              int tiles_y, uint8_t* d_dst, int dstride, size_t dpitch, uint8_t* d_lut);
+int tbk_flow_accept(tb_ctx* ctx, int npairs, const float* d_cur, uint8_t* d_status, const int32_t* d_counts, int pts_pitch, int width,
+                    int height, tb_match* d_out, int cap, int32_t* d_out_counts);
 size_t tbk_lk_work_bytes(int w, int h, int max_level, int npairs);
 int tbk_lk_track(tb_ctx* ctx, int npairs, const uint8_t* d_prev, const uint8_t* d_next, int w, int h, int stride, size_t image_pitch,
                  const float* d_prev_pts, const int32_t* d_counts, int n, int pts_pitch, int win, int max_level, float* d_next_pts,
