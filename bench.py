@@ -146,7 +146,8 @@ def main():
     ap.add_argument("--no-ba", action="store_true", help="diagnostic only: drop the local-BA stage")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
-    ap.add_argument("--ba-split", type=int, default=3, help="partitions of the BA windows, one stream + host thread each")
+    ap.add_argument("--ba-split", type=int, default=0,
+                    help="partitions of the BA windows, one stream + host thread each (0 = by batch size: 1 up to 64 frames, else 3)")
     ap.add_argument("--distinct", type=int, default=8, help="distinct synthetic stereo pairs tiled over the batch")
     args = ap.parse_args()
 
@@ -159,7 +160,7 @@ def main():
 
     pipe = TrackingPipeline(args.width, args.height, args.levels, args.scale, args.target, args.init_th, args.min_th,
                             frames=args.frames, device=dev, with_ba=not args.no_ba, ba_kf=args.ba_kf, ba_pts=args.ba_pts,
-                            ba_iters=args.ba_iters, seed=rank, ba_split=args.ba_split)
+                            ba_iters=args.ba_iters, seed=rank, ba_split=args.ba_split or (1 if args.frames <= 64 else 3))
     pipe.set_synthetic(distinct=args.distinct, first=rank * args.frames)
 
     state = {"sync_only": False}
