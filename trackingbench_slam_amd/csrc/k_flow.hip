@@ -92,11 +92,9 @@ __device__ __forceinline__ LkW lk_weights(float a, float b) {
 __global__ void __launch_bounds__(64)
 k_lk_track(LkLevels L, const float* __restrict__ prev_pts, const int32_t* __restrict__ counts, int n, float* __restrict__ next_pts,
            uint8_t* __restrict__ status, float* __restrict__ err) {
-    /* 3.7 KB of LDS per point (bytes for pixels, 16-bit pairs for the derivatives): eight wavefronts per SIMD instead of
-     * three and a half with 32-bit entries -- the kernel is bound by the latency of each point's dependent iterations */
-    __shared__ uint8_t Ip[LK_PW * LK_PW];    /* source patch, position (x, y) of the window at [(y + 1) * LK_PW + x + 1] */
-    __shared__ int dXY[LK_DW * LK_DW];       /* Scharr derivatives, |d| <= 4080: dx in the low, dy in the high 16 bits */
-    __shared__ uint8_t Jc[LK_JS * LK_JS];    /* cached region of the second image around the current window */
+    __shared__ int Ip[LK_PW * LK_PW];        /* source patch, position (x, y) of the window at [(y + 1) * LK_PW + x + 1] */
+    __shared__ int dX[LK_DW * LK_DW], dY[LK_DW * LK_DW];
+    __shared__ int Jc[LK_JS * LK_JS]; /* cached region of the second image around the current window */
     const int pair = blockIdx.y, lane = threadIdx.x;
     if ((int)blockIdx.x >= (counts ? min(counts[pair], n) : n)) return;
     const int i = pair * L.pts_pitch + blockIdx.x; /* record index */
@@ -135,13 +133,13 @@ k_lk_track(LkLevels L, const float* __restrict__ prev_pts, const int32_t* __rest
             const int X = ix + xx, Y = iy + yy;
             int gx = 0, gy = 0;
             if (X >= 0 && X < w && Y >= 0 && Y < h) {
-                const uint8_t* c = Ip + (yy + 1) * LK_PW + xx + 1;
+                const int* c = Ip + (yy + 1) * LK_PW + xx + 1;
                 const int a00 = c[-LK_PW - 1], a01 = c[-LK_PW], a02 = c[-LK_PW + 1], a10 = c[-1], a12 = c[1];
                 const int a20 = c[LK_PW - 1], a21 = c[LK_PW], a22 = c[LK_PW + 1];
                 gx = 3 * (a02 - a00) + 10 * (a12 - a10) + 3 * (a22 - a20);
                 gy = 3 * (a20 - a00) + 10 * (a21 - a01) + 3 * (a22 - a02);
             }
-            dXY[t] = (gx & 0xffff) | (gy << 16);
+            dX[t] = gx; dY[t] = gy;
         }
         __syncthreads();
         LkW W = lk_weights(px - (float)ix, py - (float)iy);
@@ -151,12 +149,11 @@ k_lk_track(LkLevels L, const float* __restrict__ prev_pts, const int32_t* __rest
         for (int k = 0; k < LK_PER; k++) {
             Iw[k] = Ix[k] = Iy[k] = 0;
             if (lane + 64 * k < LK_NPX) {
-                const uint8_t* c = Ip + (wy[k] + 1) * LK_PW + wx[k] + 1;
+                const int* c = Ip + (wy[k] + 1) * LK_PW + wx[k] + 1;
                 const int d = wy[k] * LK_DW + wx[k];
-                const int d00 = dXY[d], d01 = dXY[d + 1], d10 = dXY[d + LK_DW], d11 = dXY[d + LK_DW + 1];
-                Iw[k] = lk_descale((int)c[0] * W.w00 + (int)c[1] * W.w01 + (int)c[LK_PW] * W.w10 + (int)c[LK_PW + 1] * W.w11, 9);
-                Ix[k] = lk_descale((int)(short)d00 * W.w00 + (int)(short)d01 * W.w01 + (int)(short)d10 * W.w10 + (int)(short)d11 * W.w11, 14);
-                Iy[k] = lk_descale((d00 >> 16) * W.w00 + (d01 >> 16) * W.w01 + (d10 >> 16) * W.w10 + (d11 >> 16) * W.w11, 14);
+                Iw[k] = lk_descale(c[0] * W.w00 + c[1] * W.w01 + c[LK_PW] * W.w10 + c[LK_PW + 1] * W.w11, 9);
+                Ix[k] = lk_descale(dX[d] * W.w00 + dX[d + 1] * W.w01 + dX[d + LK_DW] * W.w10 + dX[d + LK_DW + 1] * W.w11, 14);
+                Iy[k] = lk_descale(dY[d] * W.w00 + dY[d + 1] * W.w01 + dY[d + LK_DW] * W.w10 + dY[d + LK_DW + 1] * W.w11, 14);
                 A11l += Ix[k] * Ix[k]; A12l += Ix[k] * Iy[k]; A22l += Iy[k] * Iy[k];
             }
         }
@@ -190,14 +187,14 @@ k_lk_track(LkLevels L, const float* __restrict__ prev_pts, const int32_t* __rest
                 }
                 __syncthreads();
             }
-            const uint8_t* Jp = Jc + (jy - cy0) * LK_JS + (jx - cx0);
+            const int* Jp = Jc + (jy - cy0) * LK_JS + (jx - cx0);
             /* per lane the 7 products fit 32 bits (|diff| <= 8160, |Ix| <= 4080); the wave sum needs 64 */
             int a1 = 0, a2 = 0, ab = 0;
 #pragma unroll
             for (int k = 0; k < LK_PER; k++)
                 if (lane + 64 * k < LK_NPX) {
-                    const uint8_t* c = Jp + wy[k] * LK_JS + wx[k];
-                    const int diff = lk_descale((int)c[0] * Wj.w00 + (int)c[1] * Wj.w01 + (int)c[LK_JS] * Wj.w10 + (int)c[LK_JS + 1] * Wj.w11, 9) - Iw[k];
+                    const int* c = Jp + wy[k] * LK_JS + wx[k];
+                    const int diff = lk_descale(c[0] * Wj.w00 + c[1] * Wj.w01 + c[LK_JS] * Wj.w10 + c[LK_JS + 1] * Wj.w11, 9) - Iw[k];
                     a1 += diff * Ix[k]; a2 += diff * Iy[k];
                     ab += diff < 0 ? -diff : diff;
                 }
