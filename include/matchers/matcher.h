@@ -1,7 +1,7 @@
 /* Header shim: the hot-path slice of TRACKING_BENCH::Matcher with the reference's signatures
  * (reference include/matchers/matcher.h:18-80,149-150) on the C ABI (tb_search_by_bf,
- * tb_search_by_violence, tb_search_by_projection, tb_search_by_projection_map). BoW / NN(LSH) /
- * optical-flow / direct-alignment matchers are out of scope (SURVEY.md sections 2 and 8f). */
+ * tb_search_by_violence, tb_search_by_projection, tb_search_by_projection_map, tb_search_by_opflow). The BoW, NN(LSH)
+ * and direct-alignment matchers are out of scope (SURVEY.md sections 2 and 8f). */
 #ifndef TRACKING_BENCH_MATCHER_H
 #define TRACKING_BENCH_MATCHER_H
 #include <memory>

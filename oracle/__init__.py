@@ -28,9 +28,12 @@ MAPPOINT = np.dtype([("pos", "<f4", (3,)), ("normal", "<f4", (3,)), ("min_dist",
 
 
 def build(force=False):
-    so = os.path.join(_HERE, "liboracle.so")
+    # ORACLE_LIB picks another build of the same sources (tests/test_oracle_asan.py: liboracle_asan.so under
+    # LD_PRELOAD=libasan.so); default is the plain -O2 library.
+    name = os.environ.get("ORACLE_LIB", "liboracle.so")
+    so = os.path.join(_HERE, name)
     if force or not os.path.exists(so):
-        subprocess.check_call(["make", "-C", _HERE, "liboracle.so"], stdout=subprocess.DEVNULL)
+        subprocess.check_call(["make", "-C", _HERE, name], stdout=subprocess.DEVNULL)
     return so
 
 

@@ -33,13 +33,37 @@ def test_schur_model():
     assert nb == 171 * 20000 * 16 + 171 * (5000 * 96 + G * (6 * 256 + np_) * 8)
 
 
-def test_pmc_traffic_lookup_scales_with_units():
-    path = os.path.join(bench.ROOT, "profiles", "r01_hbm_traffic_pmc.json")
-    rec = json.load(open(path))["kernels"]
-    assert bench.pmc_traffic("k_ba_schur", 64) == rec["k_ba_schur"]["hbm_bytes_per_launch"]
-    assert bench.pmc_traffic("k_ba_schur", 128) == 2 * rec["k_ba_schur"]["hbm_bytes_per_launch"]
-    assert bench.pmc_traffic("k_resize", 64) == rec["k_resize_lds"]["hbm_bytes_per_launch"]      # profile name of the kernel
+def test_schur_sparse_flops_follow_survey_8d():
+    # sum over points of k^2 * 216 per window and trial; 5000 points with 5 free observations each = 27 MFLOP
+    assert bench.schur_flops_sparse(5000 * 25) == 27.0e6
+    assert bench.extractor_bytes_per_image(1280, 720, 8, 0.8, 2000) == 15426725   # the 15.43 MB 'extractor total' row
+
+
+def test_pmc_traffic_lookup(tmp_path, monkeypatch):
+    # a file without units is a round-1 pass: 64 stereo frames (128 images) / 64 BA windows per launch
+    doc = {"note": "x", "kernels": {"k_ba_schur": {"hbm_bytes_per_launch": 1000}, "k_resize_lds": {"hbm_bytes_per_launch": 640},
+                                    "k_bf_nn": {"hbm_bytes_per_launch": 64}}}
+    (tmp_path / "profiles").mkdir()
+    (tmp_path / "profiles" / "r01_hbm_traffic_pmc.json").write_text(json.dumps(doc))
+    monkeypatch.setattr(bench, "ROOT", str(tmp_path))
+    assert bench.pmc_traffic("k_ba_schur", 64) == 1000
+    assert bench.pmc_traffic("k_ba_schur", 128) == 2000
+    assert bench.pmc_traffic("k_resize", 128) == 640              # profile name of the kernel; units = images
+    assert bench.pmc_traffic("k_bf_nn", 32) == 32                 # units = pairs
     assert bench.pmc_traffic("k_no_such_kernel", 64) is None
-    # other geometries have their own passes or none
+    assert bench.pmc_traffic("k_fast_cells", 64, (640, 480)) is None      # other geometries have their own passes or none
+    d = bench.pmc_traffic("k_ba_schur", 170, detail=True)
+    assert d["scaled"] and d["measured_at_units"] == 64 and d["file"].endswith("r01_hbm_traffic_pmc.json")
+    # a newer pass that states its units wins and is used unscaled at those units
+    doc2 = {"note": "y", "units_per_launch": {"images": 1024, "windows": 170, "pairs": 512},
+            "kernels": {"k_ba_schur": {"hbm_bytes_per_launch": 5000}, "k_fast_cells": {"hbm_bytes_per_launch": 7}}}
+    (tmp_path / "profiles" / "r02a_hbm_traffic_pmc.json").write_text(json.dumps(doc2))
+    d = bench.pmc_traffic("k_ba_schur", 170, detail=True)
+    assert d["bytes"] == 5000 and not d["scaled"]
+    assert bench.pmc_traffic("k_fast_cells", 2048) == 14
+    assert bench.pmc_traffic("k_resize", 128) == 640              # falls back to the older file for kernels the new one lacks
+
+
+def test_committed_pmc_files_parse():
+    assert bench.pmc_traffic("k_ba_schur", 64) > 0
     assert bench.pmc_traffic("k_ba_schur_pairs", 64, (3840, 2160)) > 0
-    assert bench.pmc_traffic("k_fast_cells", 64, (640, 480)) is None

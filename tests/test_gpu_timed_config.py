@@ -1,0 +1,161 @@
+"""GPU parity tests (pytest -m gpu) of the configurations bench.py actually times and of BASELINE.json configs[4]'s full
+shapes -- the two gaps the round-1 review named:
+
+* the timed configuration: with_ba=True, three BA partitions (four HIP streams, three host threads), several steps
+  queued WITHOUT host synchronisation in between, every frame's keypoints / descriptors / matches / pose / outlier
+  flags and every BA window's poses / points against the oracle;
+* configs[4]: an 8000 x 8000 searchByBF on a 3840x2160 stereo pair, and one 50-keyframe / 20 000-point BA window.
+
+Bit-exact for keypoints, descriptors and matches; 1e-6 relative (BASELINE.json's stated tolerance) for poses / points.
+"""
+import numpy as np
+import pytest
+import torch
+
+import oracle
+from trackingbench_slam_amd import capi, synth
+
+pytestmark = pytest.mark.gpu
+K = (718.856, 718.856, 607.1928, 185.2157)
+
+
+def _eq_struct(a, b):
+    assert a.dtype == b.dtype and a.shape == b.shape, (a.shape, b.shape)
+    for f in a.dtype.names:
+        assert np.array_equal(a[f], b[f]), f
+
+
+def _close(a, b, tol=1e-6):
+    assert np.allclose(a, b, rtol=tol, atol=tol * max(1.0, float(np.abs(b).max()))), float(np.abs(a - b).max())
+
+
+def _check_pipeline(p, L, R, seed, oracle_cache):
+    from trackingbench_slam_amd.pipeline import KITTI_K
+    F = p.F
+    for f in range(F):
+        kl, dl, kr, dr, m, T, ninl, outl = p.frame_results(f)
+        if f not in oracle_cache:
+            lvL, sf = oracle.pyramid(L[f], 8, 0.8)
+            lvR, _ = oracle.pyramid(R[f], 8, 0.8)
+            ko, do, _ = oracle.orb_extract(lvL, sf, 2000, 80, 30)
+            kro, dro, _ = oracle.orb_extract(lvR, sf, 2000, 80, 30)
+            mo = oracle.search_by_bf(do, dro, 10.0, 30.0)
+            _, Ti, obs = synth.pose_problem(seed * 1000 + f, p.kp_cap, KITTI_K)
+            n, To, oo, _ = oracle.pose_opt(KITTI_K, Ti, obs[:len(mo)])
+            oracle_cache[f] = (ko, do, kro, dro, mo, n, To, oo)
+        ko, do, kro, dro, mo, n, To, oo = oracle_cache[f]
+        _eq_struct(kl, ko); _eq_struct(kr, kro)
+        assert np.array_equal(dl, do) and np.array_equal(dr, dro)
+        _eq_struct(m, mo)
+        assert ninl == n and np.array_equal(outl[:len(mo)], oo)
+        assert not outl[len(mo):].any()          # flags beyond the problem's rows stay clear from step to step
+        _close(T, To)
+        # the records handed to the exchange step are the same data
+        n0 = int(p.trk_counts[f].item())
+        assert n0 == len(kl)
+        assert np.array_equal(p.trk_kps[f, :n0].cpu().numpy().reshape(-1).view(capi.KEYPOINT), kl)
+        assert np.array_equal(p.trk_desc[f, :n0].cpu().numpy(), dl)
+    w0 = 0
+    for ba, _, _ in p.bas:
+        P = ba.poses.cpu().numpy(); X = ba.pts.cpu().numpy(); st = ba.stats.cpu().numpy()
+        for w in range(ba.W):
+            key = ("ba", w0 + w)
+            if key not in oracle_cache:
+                n = int(ba.host["counts"][w])
+                oracle_cache[key] = oracle.local_ba(K, ba.host["poses"][w], 2, ba.host["pts"][w], ba.host["obs"][w, :n], ba.iters)
+            io, Po, Xo, so = oracle_cache[key]
+            _close(P[w].reshape(-1, 4, 4), Po)
+            _close(X[w], Xo)
+            assert np.isclose(st[w, 2], so[2], rtol=1e-6) and int(st[w, 0]) == io
+        w0 += ba.W
+
+
+def test_timed_configuration_unsynchronised_steps():
+    """bench.py's default shape at a size the oracle finishes in seconds: 1280x720, 12 stereo frames, 10-KF / 5000-point
+    windows, ba_split=3. One step, check; then four more steps back to back with no host synchronisation between them
+    (what the timed loop does), check again: a torch-side operation that is not ordered against the kernel chain
+    (round-1 advice: outlier.zero_() on the null stream) shows up as stale or cleared pose-opt flags."""
+    from trackingbench_slam_amd.pipeline import TrackingPipeline
+    F, seed = 12, 7
+    p = TrackingPipeline(1280, 720, 8, 0.8, 2000, 80.0, 30.0, frames=F, with_ba=True, ba_kf=10, ba_pts=5000, ba_iters=10,
+                         seed=seed, ba_split=3, ba_distinct=6)
+    assert len(p.bas) == 3 and p.main.cuda_stream != 0 and all(st.cuda_stream != 0 for _, st, _ in p.bas)
+    L, R = p.set_synthetic(distinct=F, first=300)
+    cache = {}
+    p.step()
+    _check_pipeline(p, L, R, seed, cache)
+    first_set = p._cur
+    for _ in range(4):
+        p.step()
+    assert p._cur == first_set                   # 5 steps: the records are back in the set checked above
+    _check_pipeline(p, L, R, seed, cache)
+    p.step()                                     # ... and the other set holds the same batch
+    _check_pipeline(p, L, R, seed, cache)
+    p.close()
+
+
+def test_context_refuses_the_null_stream():
+    with pytest.raises(ValueError):
+        capi.Context(0, stream=0)
+    c = capi.Context(0, stream=None)
+    c.close()
+
+
+def test_configs4_bf_8000x8000_on_4k_stereo():
+    """BASELINE.json configs[4]: 3840x2160 stereo, 8000 keypoints per image, searchByBF left<->right (matcher.cpp:168-228)
+    over the two full descriptor sets, host form and batched device form, against the oracle."""
+    ctx = capi.Context(0)
+    Limg, Rimg = synth.frame(51, 3840, 2160, stereo=True)
+    ex = capi.Extractor(ctx, 3840, 2160, 8, 0.8, 2, 8000)
+    ex.set_images_host(np.stack([Limg, Rimg]))
+    ex.build_pyramid(2)
+    ex.orb(2, 8000, 80, 30)
+    kl, dl = ex.results(0, 9000)
+    kr, dr = ex.results(1, 9000)
+    assert len(kl) >= 8000 and len(kr) >= 8000
+    lv, sf = oracle.pyramid(Rimg, 8, 0.8)       # the left image of this geometry is covered by test_gpu_extract
+    kro, dro, _ = oracle.orb_extract(lv, sf, 8000, 80, 30)
+    _eq_struct(kr, kro)
+    assert np.array_equal(dr, dro)
+    mo = oracle.search_by_bf(dl, dr, 10.0, 30.0)
+    _eq_struct(ctx.search_by_bf(dl, dr, 10.0, 30.0), mo)
+    _eq_struct(ctx.bf_match(dl, dr, True), oracle.bf_match(dl, dr, True))
+    assert len(mo) > 100
+    # batched device form on the extractor's resident results (what the pipeline runs)
+    kps_ptr, desc_ptr, counts_ptr, cap = ex.results_dev()
+    import ctypes as C
+    out = torch.zeros((1, cap, 4), dtype=torch.int32, device="cuda")
+    cnt = torch.zeros(1, dtype=torch.int32, device="cuda")
+    torch.cuda.synchronize()
+    ctx.check(capi.lib().tb_search_by_bf_batch_dev(ctx._h, 1, C.c_void_p(desc_ptr), C.c_void_p(counts_ptr),
+                                                   C.c_void_p(desc_ptr + cap * 32), C.c_void_p(counts_ptr + 4),
+                                                   C.c_size_t(cap * 32), C.c_float(10.0), C.c_float(30.0),
+                                                   C.c_void_p(out.data_ptr()), cap, C.c_void_p(cnt.data_ptr())))
+    ctx.synchronize()
+    n = int(cnt[0].item())
+    _eq_struct(out[0, :n].cpu().numpy().view(capi.MATCH).reshape(-1), mo)
+    ex.close()
+    ctx.close()
+
+
+def test_configs4_ba_window_50kf_20000pts():
+    """BASELINE.json configs[4]: one 50-keyframe window with 20 000 points (what `bench.py --ba-kf 50 --ba-pts 20000` runs
+    per frame), host form and batched form, against the FP64 CPU solver."""
+    ctx = capi.Context(0)
+    Pt, Pi, Xt, Xi, obs = synth.ba_problem(41, 50, 20000, K)
+    io, Po, Xo, so = oracle.local_ba(K, Pi, 2, Xi, obs, 10)
+    ig, Pg, Xg, sg = ctx.local_ba(K, Pi, 2, Xi, obs, 10)
+    _close(Pg, Po)
+    _close(Xg, Xo)
+    assert ig == io and np.isclose(sg[2], so[2], rtol=1e-6) and np.isclose(sg[1], so[1], rtol=1e-9) and sg[2] < sg[1]
+    from trackingbench_slam_amd.ba import BatchedLocalBA
+    ba = BatchedLocalBA(ctx, 2, nkf=50, npt=20000, iters=10, seed=2, device=torch.device("cuda", 0), distinct=2)
+    ba.run()
+    torch.cuda.synchronize()
+    for w in range(2):
+        n = int(ba.host["counts"][w])
+        io, Po, Xo, so = oracle.local_ba(K, ba.host["poses"][w], 2, ba.host["pts"][w], ba.host["obs"][w, :n], 10)
+        _close(ba.poses[w].cpu().numpy().reshape(-1, 4, 4), Po)
+        _close(ba.pts[w].cpu().numpy(), Xo)
+        assert np.isclose(float(ba.stats[w, 2]), so[2], rtol=1e-6)
+    ctx.close()

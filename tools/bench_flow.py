@@ -29,7 +29,7 @@ def main():
     import oracle
     torch.cuda.set_device(0)
     dev = torch.device("cuda", 0)
-    ctx = capi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    ctx = capi.Context(0)  # own stream; torch.cuda.synchronize() below is device-wide
     W, H, n, P = args.width, args.height, args.points, args.pairs
     distinct = []
     for i in range(min(4, P)):

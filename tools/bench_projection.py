@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
     args = ap.parse_args()
     torch.cuda.set_device(0)
-    ctx = capi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+    ctx = capi.Context(0)  # own stream; torch.cuda.synchronize() below is device-wide
     distinct = [synth.projection_case(100 + i, n1=args.keys, nmp=args.keys, width=1280, height=720) for i in range(8)]
     cases = [distinct[i % len(distinct)] for i in range(args.pairs)]
     bp = BatchedProjection(ctx, cases, torch.device("cuda", 0), nratio=8.0)

@@ -11,7 +11,7 @@ from trackingbench_slam_amd.ba import BatchedLocalBA  # noqa: E402
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 torch.cuda.set_device(0)
-ctx = capi.Context(0, stream=torch.cuda.current_stream().cuda_stream)
+ctx = capi.Context(0)  # own stream; torch.cuda.synchronize() below is device-wide
 ba = BatchedLocalBA(ctx, W, 10, 5000, 10, 0, torch.device("cuda", 0))
 for _ in range(reps):
     ba.run()

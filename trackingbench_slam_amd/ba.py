@@ -11,7 +11,7 @@ KITTI_K = (718.856, 718.856, 607.1928, 185.2157)
 
 
 class BatchedLocalBA:
-    def __init__(self, ctx, nwindows, nkf=10, npt=5000, iters=10, seed=0, device=None, nfixed=2, distinct=4):
+    def __init__(self, ctx, nwindows, nkf=10, npt=5000, iters=10, seed=0, device=None, nfixed=2, distinct=4, stream=None):
         self.ctx, self.W, self.nkf, self.npt, self.iters, self.nfixed = ctx, int(nwindows), int(nkf), int(npt), int(iters), nfixed
         probs = [synth.ba_problem(seed * 100 + i, nkf, npt, KITTI_K) for i in range(min(distinct, self.W))]
         self.obs_pitch = max(len(p[4]) for p in probs)
@@ -31,10 +31,12 @@ class BatchedLocalBA:
         self.edges = int(cnt.sum())
         # (edge, edge) items of the block-pair lists the large-window Schur kernel walks (more than 10 free keyframes)
         self.pair_items = 0
+        self.sum_k2_free = 0   # sum over points of (observations by free keyframes)^2: SURVEY 8(d)'s sparse Schur flop count / 216
         for w in range(self.W):
             o = obs[w, :cnt[w]]
             e = np.bincount(o["pt"][o["kf"] >= nfixed], minlength=npt).astype(np.int64)
             self.pair_items += int((e * (e + 1) // 2).sum())
+            self.sum_k2_free += int((e * e).sum())
         dev = device
         self.obs = torch.from_numpy(obs.view(np.uint8).reshape(self.W, self.obs_pitch, capi.BA_OBS.itemsize)).to(dev)
         self.counts = torch.from_numpy(cnt).to(dev)
@@ -44,10 +46,20 @@ class BatchedLocalBA:
         self.pts = torch.empty_like(self.pts0)
         self.stats = torch.zeros((self.W, 8), dtype=torch.float64, device=dev)
         self.K = np.ascontiguousarray(KITTI_K, np.float64)
+        # `stream`: the torch stream whose handle the context runs on (the pipeline passes it). Without one the reset
+        # copies go to torch's current stream and are waited for on the host before the kernels are queued -- the
+        # context's own stream is not ordered against torch's streams.
+        self.stream = stream
 
     def run(self):
-        self.poses.copy_(self.poses0)
-        self.pts.copy_(self.pts0)
+        if self.stream is not None:
+            with torch.cuda.stream(self.stream):
+                self.poses.copy_(self.poses0)
+                self.pts.copy_(self.pts0)
+        else:
+            self.poses.copy_(self.poses0)
+            self.pts.copy_(self.pts0)
+            torch.cuda.current_stream(self.poses.device).synchronize()
         self.ctx.check(capi.lib().tb_local_ba_batch_dev(
             self.ctx._h, self.W, self.K.ctypes.data_as(C.c_void_p), self.nkf, self.nfixed, C.c_void_p(self.poses.data_ptr()),
             self.npt, C.c_void_p(self.pts.data_ptr()), C.c_void_p(self.obs.data_ptr()), C.c_void_p(self.counts.data_ptr()),

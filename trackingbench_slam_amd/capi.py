@@ -158,7 +158,17 @@ class Context:
             raise TBError(rc, lib().tb_last_error(self._h).decode() or lib().tb_strerror(rc).decode())
 
     def set_stream(self, stream_ptr):
-        self.check(lib().tb_set_stream(self._h, C.c_void_p(stream_ptr)))
+        """Run the context on an existing HIP stream. None = the context's own (non-blocking) stream. Handle 0 -- HIP's
+        legacy null stream, which is what torch's DEFAULT stream reports -- is refused: the C ABI reads NULL as "own
+        stream", so the caller would believe it is ordered against torch's default stream when it is not. Pass a
+        torch.cuda.Stream() handle and issue the torch-side work under `with torch.cuda.stream(...)`."""
+        if stream_ptr is None:
+            self.check(lib().tb_set_stream(self._h, None))
+            return
+        if int(stream_ptr) == 0:
+            raise ValueError("stream handle 0 (the legacy null stream / torch's default stream) is not accepted: "
+                             "create a torch.cuda.Stream() and pass its .cuda_stream, or pass None")
+        self.check(lib().tb_set_stream(self._h, C.c_void_p(int(stream_ptr))))
 
     def synchronize(self):
         self.check(lib().tb_synchronize(self._h))

@@ -394,11 +394,10 @@ int tbk_octree(tb_extractor* ex, int n, int n_exit) {
         return tb_fail(ctx, TB_EUNSUPPORTED, "per-level quota %d exceeds the quadtree LDS capacity %d", capMax,
                        TB_NODE_CAP_MAX);
     const size_t lds = ot_lds_bytes(capMax);
-    static bool attr_set = false;
-    if (!attr_set) {
+    /* a function attribute belongs to the (function, device) pair: set per call on the context's device whenever the
+     * launch needs more than the default 64 KB (no process-wide "done" flag) */
+    if (lds > 64 * 1024)
         TB_HIP(ctx, hipFuncSetAttribute((const void*)k_octree, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 2048));
-        attr_set = true;
-    }
     dim3 grid(ex->g.nlevels, n);
     /* one workgroup walks all candidates of its level once per divide step: on large images (candidates grow with the
      * pixel count) those loops, not the node tables, set the time, and four times the threads are worth the idle lanes

@@ -15,6 +15,7 @@
 
 /* ------------------------------------------------------------------ errors / context */
 int tb_fail(tb_ctx* ctx, int code, const char* fmt, ...) {
+    TB_ENTER(ctx);
     char buf[512];
     va_list ap;
     va_start(ap, fmt);
@@ -25,6 +26,7 @@ int tb_fail(tb_ctx* ctx, int code, const char* fmt, ...) {
 }
 
 int tb_scratch(tb_ctx* ctx, int slot, size_t bytes, void** out) {
+    TB_ENTER(ctx);
     if (bytes < 256) bytes = 256;
     if (ctx->scratch_cap[slot] < bytes) {
         if (ctx->scratch[slot]) {
@@ -78,6 +80,7 @@ static void prof_drain(tb_ctx* ctx) {
 extern "C" {
 
 int tb_profile_enable(tb_ctx* ctx, int on) {
+    TB_ENTER(ctx);
     if (!ctx) return TB_EINVAL;
     prof_drain(ctx);
     ctx->prof_acc.clear();
@@ -86,6 +89,7 @@ int tb_profile_enable(tb_ctx* ctx, int on) {
 }
 
 int tb_profile_report(tb_ctx* ctx, char* buf, int cap) {
+    TB_ENTER(ctx);
     if (!ctx || !buf || cap < 1) return TB_EINVAL;
     prof_drain(ctx);
     std::string out;
@@ -150,6 +154,7 @@ void tb_destroy(tb_ctx* ctx) {
 const char* tb_last_error(const tb_ctx* ctx) { return ctx ? ctx->err.c_str() : "null context"; }
 
 int tb_set_stream(tb_ctx* ctx, void* hip_stream) {
+    TB_ENTER(ctx);
     if (!ctx) return TB_EINVAL;
     TB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     ctx->stream = hip_stream ? (hipStream_t)hip_stream : ctx->own_stream;
@@ -157,6 +162,7 @@ int tb_set_stream(tb_ctx* ctx, void* hip_stream) {
 }
 
 int tb_synchronize(tb_ctx* ctx) {
+    TB_ENTER(ctx);
     if (!ctx) return TB_EINVAL;
     TB_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return TB_OK;
@@ -257,6 +263,7 @@ void tb_extractor_destroy(tb_extractor* ex) {
 
 int tb_extractor_create(tb_ctx* ctx, int width, int height, int nlevels, const float* sf, const int* widths,
                         const int* heights, int max_images, int max_target, tb_extractor** out) {
+    TB_ENTER(ctx);
     if (!ctx || !out) return TB_EINVAL;
     *out = nullptr;
     if (width < 1 || height < 1 || nlevels < 1 || nlevels > TB_MAX_LEVELS || !sf || max_images < 1 || max_target < 1)
@@ -395,6 +402,7 @@ int tb_extractor_create(tb_ctx* ctx, int width, int height, int nlevels, const f
 }
 
 int tb_extractor_set_images_host(tb_extractor* ex, const uint8_t* images, int n, int stride, size_t pitch) {
+    TB_ENTER((ex ? ex->ctx : nullptr));
     if (!ex || !images || n < 1 || n > ex->max_images || stride < ex->g.width) return TB_EINVAL;
     tb_ctx* ctx = ex->ctx;
     const LevelGeom& L0 = ex->g.lv[0];
@@ -406,6 +414,7 @@ int tb_extractor_set_images_host(tb_extractor* ex, const uint8_t* images, int n,
 }
 
 int tb_extractor_set_images_dev(tb_extractor* ex, const uint8_t* dev_images, int n, int stride, size_t pitch) {
+    TB_ENTER((ex ? ex->ctx : nullptr));
     if (!ex || !dev_images || n < 1 || n > ex->max_images || stride < ex->g.width) return TB_EINVAL;
     ex->g.img0 = dev_images;
     ex->g.img0_stride = stride;
@@ -414,6 +423,7 @@ int tb_extractor_set_images_dev(tb_extractor* ex, const uint8_t* dev_images, int
 }
 
 int tb_extractor_set_levels_host(tb_extractor* ex, int index, const uint8_t* const* levels, const int* strides) {
+    TB_ENTER((ex ? ex->ctx : nullptr));
     if (!ex || !levels || !strides || index < 0 || index >= ex->max_images) return TB_EINVAL;
     tb_ctx* ctx = ex->ctx;
     for (int l = 0; l < ex->g.nlevels; l++) {
@@ -427,6 +437,7 @@ int tb_extractor_set_levels_host(tb_extractor* ex, int index, const uint8_t* con
 }
 
 int tb_extractor_build_pyramid(tb_extractor* ex, int n) {
+    TB_ENTER((ex ? ex->ctx : nullptr));
     if (!ex || n < 1 || n > ex->max_images) return TB_EINVAL;
     for (int l = 1; l < ex->g.nlevels; l++) {
         int rc = tbk_resize_level(ex, l, n);
@@ -436,6 +447,7 @@ int tb_extractor_build_pyramid(tb_extractor* ex, int n) {
 }
 
 int tb_extractor_get_level_host(tb_extractor* ex, int index, int level, uint8_t* out, int out_stride) {
+    TB_ENTER((ex ? ex->ctx : nullptr));
     if (!ex || !out || index < 0 || index >= ex->max_images || level < 0 || level >= ex->g.nlevels) return TB_EINVAL;
     tb_ctx* ctx = ex->ctx;
     const LevelGeom& L = ex->g.lv[level];
@@ -451,6 +463,7 @@ int tb_extractor_get_level_host(tb_extractor* ex, int index, int level, uint8_t*
 
 int tb_extractor_orb(tb_extractor* ex, int n, int target, float init_th, float min_th, int quota_mode,
                      const tb_keypoint* exit_keys, int n_exit) {
+    TB_ENTER((ex ? ex->ctx : nullptr));
     if (!ex || n < 1 || n > ex->max_images || target < 0 || n_exit < 0 || (n_exit > 0 && !exit_keys)) return TB_EINVAL;
     tb_ctx* ctx = ex->ctx;
     PlanGeom& g = ex->g;
@@ -505,6 +518,7 @@ int tb_extractor_orb(tb_extractor* ex, int n, int target, float init_th, float m
 
 int tb_extractor_fastgrid(tb_extractor* ex, int n, const float* inv_sf, int target, float threshold,
                           const uint8_t* occupancy, int n_occupancy) {
+    TB_ENTER((ex ? ex->ctx : nullptr));
     if (!ex || n < 1 || n > ex->max_images || !inv_sf || target < 1) return TB_EINVAL;
     tb_ctx* ctx = ex->ctx;
     for (int l = 0; l < ex->g.nlevels; l++) ex->g.lv[l].inv_sf = inv_sf[l];
@@ -529,6 +543,7 @@ int tb_extractor_fastgrid(tb_extractor* ex, int n, const float* inv_sf, int targ
 }
 
 int tb_extractor_counts_host(tb_extractor* ex, int n, int* counts) {
+    TB_ENTER((ex ? ex->ctx : nullptr));
     if (!ex || !counts || n < 1 || n > ex->max_images) return TB_EINVAL;
     tb_ctx* ctx = ex->ctx;
     TB_HIP(ctx, hipMemcpyAsync(counts, ex->d_counts, (size_t)n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
@@ -537,6 +552,7 @@ int tb_extractor_counts_host(tb_extractor* ex, int n, int* counts) {
 }
 
 int tb_extractor_results_host(tb_extractor* ex, int index, tb_keypoint* kps, uint8_t* desc, int cap, int* count) {
+    TB_ENTER((ex ? ex->ctx : nullptr));
     if (!ex || !count || index < 0 || index >= ex->max_images) return TB_EINVAL;
     tb_ctx* ctx = ex->ctx;
     int32_t c = 0;
@@ -556,6 +572,7 @@ int tb_extractor_results_host(tb_extractor* ex, int index, tb_keypoint* kps, uin
 
 int tb_extractor_results_dev(tb_extractor* ex, const tb_keypoint** kps, const uint8_t** desc, const int32_t** counts,
                              int* kp_capacity) {
+    TB_ENTER((ex ? ex->ctx : nullptr));
     if (!ex) return TB_EINVAL;
     if (kps) *kps = ex->d_kps;
     if (desc) *desc = ex->d_desc;
@@ -580,6 +597,7 @@ __global__ void k_copy_results(const tb_keypoint* __restrict__ skp, const uint8_
 }
 
 int tb_extractor_copy_results_dev(tb_extractor* ex, int n, tb_keypoint* kps, uint8_t* desc, int32_t* counts, int cap) {
+    TB_ENTER((ex ? ex->ctx : nullptr));
     if (!ex || n < 1 || n > ex->max_images || !kps || !desc || !counts || cap < 1) return TB_EINVAL;
     tb_ctx* ctx = ex->ctx;
     const int rows = std::min(cap, ex->g.selCap);
@@ -592,6 +610,7 @@ int tb_extractor_copy_results_dev(tb_extractor* ex, int n, tb_keypoint* kps, uin
 }
 
 int tb_extractor_candidates_host(tb_extractor* ex, int index, int level, tb_corner* out, int cap, int* count) {
+    TB_ENTER((ex ? ex->ctx : nullptr));
     if (!ex || !count || index < 0 || index >= ex->max_images || level < 0 || level >= ex->g.nlevels) return TB_EINVAL;
     tb_ctx* ctx = ex->ctx;
     const LevelGeom& L = ex->g.lv[level];
@@ -645,6 +664,7 @@ static int get_plan(tb_ctx* ctx, const char* tag, int nlevels, const float* sf, 
 
 int tb_pyramid(tb_ctx* ctx, const uint8_t* image, int width, int height, int stride, int nlevels, const float* sf,
                uint8_t* const* levels_out, const int* strides_out) {
+    TB_ENTER(ctx);
     if (!ctx || !image || !sf || !levels_out || !strides_out || nlevels < 1 || nlevels > TB_MAX_LEVELS) return TB_EINVAL;
     std::vector<int> ws(nlevels), hs(nlevels);
     tb_pyramid_sizes(width, height, nlevels, sf, ws.data(), hs.data());
@@ -665,6 +685,7 @@ int tb_pyramid(tb_ctx* ctx, const uint8_t* image, int width, int height, int str
 
 int tb_fast_detect(tb_ctx* ctx, const uint8_t* image, int width, int height, int stride, int threshold, int nms,
                    tb_corner* out, int cap, int* count) {
+    TB_ENTER(ctx);
     if (!ctx || !image || !count || width < 0 || height < 0 || width > 4095 || height > 4095) return TB_EINVAL;
     *count = 0;
     if (width < 7 || height < 7) return TB_OK;
@@ -700,6 +721,7 @@ int tb_fast_detect(tb_ctx* ctx, const uint8_t* image, int width, int height, int
 int tb_orb_extract(tb_ctx* ctx, const uint8_t* const* levels, const int* widths, const int* heights, const int* strides,
                    int nlevels, const float* sf, int target, float init_th, float min_th, const tb_keypoint* exit_keys,
                    int n_exit, int use_quotas, int* quotas_inout, tb_keypoint* kps, uint8_t* desc, int cap, int* count) {
+    TB_ENTER(ctx);
     if (!ctx || !levels || !widths || !heights || !strides || !sf || !quotas_inout || !count || nlevels < 1 ||
         nlevels > TB_MAX_LEVELS)
         return TB_EINVAL;
@@ -726,6 +748,7 @@ int tb_orb_extract(tb_ctx* ctx, const uint8_t* const* levels, const int* widths,
 int tb_fastgrid_extract(tb_ctx* ctx, const uint8_t* const* levels, const int* widths, const int* heights, const int* strides,
                         int nlevels, const float* inv_sf, int target, float threshold, const uint8_t* occupancy,
                         int n_occupancy, tb_keypoint* kps, int cap, int* count) {
+    TB_ENTER(ctx);
     if (!ctx || !levels || !widths || !heights || !strides || !inv_sf || !count || nlevels < 1 || nlevels > TB_MAX_LEVELS ||
         target < 1)
         return TB_EINVAL;
@@ -804,17 +827,20 @@ static int bf_host(tb_ctx* ctx, const uint8_t* d1, int n1, const uint8_t* d2, in
 
 int tb_match_bf(tb_ctx* ctx, const uint8_t* d1, int n1, const uint8_t* d2, int n2, int crosscheck, tb_match* out, int cap,
                 int* count) {
+    TB_ENTER(ctx);
     return bf_host(ctx, d1, n1, d2, n2, crosscheck, 0, 0.f, 0.f, out, cap, count);
 }
 
 int tb_search_by_bf(tb_ctx* ctx, const uint8_t* d1, int n1, const uint8_t* d2, int n2, float ratio, float min_th,
                     tb_match* out, int cap, int* count) {
+    TB_ENTER(ctx);
     return bf_host(ctx, d1, n1, d2, n2, 1, 1, ratio, min_th, out, cap, count);
 }
 
 int tb_search_by_bf_batch_dev(tb_ctx* ctx, int npairs, const uint8_t* desc1, const int32_t* counts1, const uint8_t* desc2,
                               const int32_t* counts2, size_t set_pitch, float ratio, float min_th, tb_match* out, int cap,
                               int32_t* out_counts) {
+    TB_ENTER(ctx);
     if (!ctx || npairs < 0 || !desc1 || !desc2 || !counts1 || !counts2 || !out || !out_counts || set_pitch < 32 || cap < 1)
         return TB_EINVAL;
     if (npairs == 0) return TB_OK;
@@ -831,6 +857,7 @@ int tb_search_by_violence(tb_ctx* ctx, const tb_keypoint* k1, const uint8_t* d1,
                           const uint8_t* d2, int n2, int img2_width, int img2_height, int min_level, int max_level,
                           float radius, int th_low, float nratio, int histo_len, int check_orientation, tb_match* out,
                           int cap, int* count) {
+    TB_ENTER(ctx);
     if (!ctx || !count || n1 < 0 || n2 < 0 || histo_len < 1 || img2_width < 1 || img2_height < 1) return TB_EINVAL;
     *count = 0;
     if (n1 == 0) return TB_OK;
@@ -990,6 +1017,7 @@ int tb_search_by_projection(tb_ctx* ctx, const float Tcw1[16], const tb_camera* 
                             const tb_keypoint* k1, const uint8_t* d1, const uint8_t* taken1, int n1, const tb_keypoint* k2,
                             const tb_mappoint* mp2, const uint8_t* mp2_desc, int n2, const float* scale_factors, int nlevels,
                             float nratio, int th_high, int histo_len, int check_orientation, tb_match* out, int cap, int* count) {
+    TB_ENTER(ctx);
     if (!ctx || !count || !Tcw1 || !cam1 || n1 < 0 || n2 < 0 || histo_len < 1 || nlevels < 1 || !scale_factors || img1_width < 1 ||
         img1_height < 1)
         return TB_EINVAL;
@@ -1043,6 +1071,7 @@ int tb_search_by_projection_map(tb_ctx* ctx, const float Tcw1[16], const tb_came
                                 const tb_keypoint* k1, const uint8_t* d1, const uint8_t* taken1, int n1, const tb_mappoint* mps,
                                 const uint8_t* mp_desc, int nmp, const float* scale_factors, int nlevels, float nratio, float radio,
                                 int th_high, tb_match* out, int cap, int* count) {
+    TB_ENTER(ctx);
     if (!ctx || !count || !Tcw1 || !cam1 || n1 < 0 || nmp < 0 || nlevels < 1 || !scale_factors || img1_width < 1 || img1_height < 1)
         return TB_EINVAL;
     *count = 0;
@@ -1071,6 +1100,7 @@ int tb_search_by_projection_map(tb_ctx* ctx, const float Tcw1[16], const tb_came
 /* ---- device-resident lookup grid + batched projection search */
 int tb_frame_grid_batch_dev(tb_ctx* ctx, int nframes, const tb_keypoint* keys, const int32_t* counts, int key_pitch, int img_width,
                             int img_height, int32_t* cell_start, int32_t* cell_items) {
+    TB_ENTER(ctx);
     if (!ctx || nframes < 0 || key_pitch < 1 || img_width < 1 || img_height < 1 || (nframes && (!keys || !counts || !cell_start || !cell_items)))
         return TB_EINVAL;
     return tbk_grid_build_batch(ctx, nframes, keys, counts, key_pitch, img_width, img_height, cell_start, cell_items);
@@ -1082,6 +1112,7 @@ int tb_search_by_projection_batch_dev(tb_ctx* ctx, int npairs, const float* Tcw1
                                       const tb_keypoint* k2, const tb_mappoint* mp2, const uint8_t* mp2_desc, const int32_t* n2,
                                       int pitch2, const float* scale_factors, int nlevels, float nratio, int th_high, int histo_len,
                                       int check_orientation, tb_match* out, int cap, int32_t* out_counts, int32_t* flags) {
+    TB_ENTER(ctx);
     if (!ctx || npairs < 0 || !cam1 || !scale_factors || nlevels < 1 || nlevels > TB_MAX_LEVELS * 2 || histo_len < 1 || histo_len > 1024 ||
         pitch1 < 1 || pitch2 < 1 || cap < 0 || img1_width < 1 || img1_height < 1)
         return TB_EINVAL;
@@ -1102,6 +1133,7 @@ int tb_search_by_projection_map_batch_dev(tb_ctx* ctx, int npairs, const float* 
                                           const tb_mappoint* mps, const uint8_t* mp_desc, const int32_t* nmp, int mp_pitch,
                                           int max_nmp, const float* scale_factors, int nlevels, float nratio, float radio,
                                           int th_high, tb_match* out, int cap, int32_t* out_counts, int32_t* flags) {
+    TB_ENTER(ctx);
     if (!ctx || npairs < 0 || !cam1 || !scale_factors || nlevels < 1 || nlevels > TB_MAX_LEVELS * 2 || pitch1 < 1 || mp_pitch < 0 ||
         max_nmp < 1 || (mp_pitch > 0 && mp_pitch < max_nmp) || cap < 0 || img1_width < 1 || img1_height < 1)
         return TB_EINVAL;
@@ -1121,6 +1153,7 @@ int tb_search_by_violence_batch_dev(tb_ctx* ctx, int npairs, const tb_keypoint* 
                                     const int32_t* cell_start2, const int32_t* cell_items2, int img2_width, int img2_height,
                                     int min_level, int max_level, float radius, int th_low, float nratio, int histo_len,
                                     int check_orientation, tb_match* out, int cap, int32_t* out_counts, int32_t* flags) {
+    TB_ENTER(ctx);
     if (!ctx || npairs < 0 || histo_len < 1 || histo_len > 1024 || pitch1 < 1 || pitch2 < 1 || cap < 0 || img2_width < 1 || img2_height < 1)
         return TB_EINVAL;
     if (npairs == 0) return TB_OK;
@@ -1137,6 +1170,7 @@ int tb_search_by_violence_batch_dev(tb_ctx* ctx, int npairs, const tb_keypoint* 
 int tb_pose_opt_batch_dev(tb_ctx* ctx, int nproblems, const double K[4], const float* Tcw_in, const tb_obs* obs,
                           const int32_t* counts, int obs_pitch, uint8_t* outlier, float* Tcw_out, int32_t* n_inliers,
                           double* stats) {
+    TB_ENTER(ctx);
     if (!ctx || nproblems < 0 || !K || !Tcw_in || !obs || !counts || !outlier || !Tcw_out || !n_inliers || obs_pitch < 1)
         return TB_EINVAL;
     void* derr;
@@ -1147,6 +1181,7 @@ int tb_pose_opt_batch_dev(tb_ctx* ctx, int nproblems, const double K[4], const f
 
 int tb_pose_opt(tb_ctx* ctx, const double K[4], const float Tcw_in[16], const tb_obs* obs, int n, uint8_t* outlier,
                 float Tcw_out[16], int* n_inliers, double* stats) {
+    TB_ENTER(ctx);
     if (!ctx || !K || !Tcw_in || !Tcw_out || !n_inliers || n < 0 || (n && (!obs || !outlier))) return TB_EINVAL;
     const int pitch = std::max(n, 1);
     void *dobs, *dmisc, *dout;
@@ -1182,11 +1217,11 @@ int tb_pose_opt(tb_ctx* ctx, const double K[4], const float Tcw_in[16], const tb
 
 int tb_local_ba_batch_dev(tb_ctx* ctx, int nwindows, const double K[4], int nkf, int nfixed, float* poses, int npt, float* pts,
                           const tb_ba_obs* obs, const int32_t* obs_counts, int obs_pitch, int iters, double* stats) {
+    TB_ENTER(ctx);
     if (!ctx || !K || !poses || !pts || !obs || !obs_counts || nwindows < 0 || nkf < 1 || npt < 1 || obs_pitch < 1 || nfixed < 0 ||
         nfixed > nkf || iters < 0)
         return TB_EINVAL;
     if (nwindows == 0) return TB_OK;
-    TB_HIP(ctx, hipSetDevice(ctx->device)); /* callers may drive a context from their own host thread */
     const size_t wb = tbk_local_ba_work_bytes(nwindows, nkf, nfixed, npt, obs_pitch);
     void* dwork;
     int rc = tb_scratch(ctx, 6, wb, &dwork);
@@ -1196,6 +1231,7 @@ int tb_local_ba_batch_dev(tb_ctx* ctx, int nwindows, const double K[4], int nkf,
 
 int tb_local_ba(tb_ctx* ctx, const double K[4], int nkf, int nfixed, float* poses, int npt, float* pts, const tb_ba_obs* obs,
                 int nobs, int iters, double* stats) {
+    TB_ENTER(ctx);
     if (!ctx || !K || !poses || !pts || !obs || nkf < 1 || npt < 1 || nobs < 1 || nfixed < 0 || nfixed > nkf || iters < 0)
         return TB_EINVAL;
     for (int e = 0; e < nobs; e++)
@@ -1232,6 +1268,7 @@ int tb_local_ba(tb_ctx* ctx, const double K[4], int nkf, int nfixed, float* pose
 
 int tb_clahe_dev(tb_ctx* ctx, const uint8_t* src, int width, int height, int stride, double clip_limit, int tiles_x, int tiles_y,
                  uint8_t* dst, int dst_stride) {
+    TB_ENTER(ctx);
     if (!ctx || !src || !dst || width < 1 || height < 1 || stride < width || dst_stride < width || tiles_x < 1 || tiles_y < 1) return TB_EINVAL;
     void* lut;
     int rc;
@@ -1241,6 +1278,7 @@ int tb_clahe_dev(tb_ctx* ctx, const uint8_t* src, int width, int height, int str
 
 int tb_clahe(tb_ctx* ctx, const uint8_t* src, int width, int height, int stride, double clip_limit, int tiles_x, int tiles_y,
              uint8_t* dst, int dst_stride) {
+    TB_ENTER(ctx);
     if (!ctx || !src || !dst || width < 1 || height < 1 || stride < width || dst_stride < width || tiles_x < 1 || tiles_y < 1) return TB_EINVAL;
     void *ds, *dd;
     int rc;
@@ -1255,6 +1293,7 @@ int tb_clahe(tb_ctx* ctx, const uint8_t* src, int width, int height, int stride,
 
 int tb_optical_flow_pyr_lk_dev(tb_ctx* ctx, const uint8_t* prev, const uint8_t* next, int width, int height, int stride,
                                const float* prev_pts, int n, int win, int max_level, float* next_pts, uint8_t* status, float* err) {
+    TB_ENTER(ctx);
     if (!ctx || !prev || !next || n < 0 || width < 1 || height < 1 || stride < width) return TB_EINVAL;
     if (n && (!prev_pts || !next_pts || !status)) return TB_EINVAL;
     if (max_level < 0 || max_level > 5) return tb_fail(ctx, TB_EUNSUPPORTED, "optical flow: max_level %d (0..5)", max_level);
@@ -1268,6 +1307,7 @@ int tb_optical_flow_pyr_lk_dev(tb_ctx* ctx, const uint8_t* prev, const uint8_t* 
 int tb_optical_flow_pyr_lk_batch_dev(tb_ctx* ctx, int npairs, const uint8_t* prev, const uint8_t* next, int width, int height,
                                      int stride, size_t image_pitch, const float* prev_pts, const int32_t* counts, int pts_pitch,
                                      int win, int max_level, float* next_pts, uint8_t* status, float* err) {
+    TB_ENTER(ctx);
     if (!ctx || npairs < 0 || pts_pitch < 0 || width < 1 || height < 1 || stride < width) return TB_EINVAL;
     if (npairs == 0 || pts_pitch == 0) return TB_OK;
     if (!prev || !next || !prev_pts || !next_pts || !status || image_pitch < (size_t)stride * height) return TB_EINVAL;
@@ -1282,6 +1322,7 @@ int tb_optical_flow_pyr_lk_batch_dev(tb_ctx* ctx, int npairs, const uint8_t* pre
 int tb_optical_flow_pyr_lk(tb_ctx* ctx, const uint8_t* prev, const uint8_t* next, int width, int height, int stride,
                            const float* prev_pts, int n, int win, int max_level, float* next_pts, uint8_t* status, float* err,
                            int* top_level) {
+    TB_ENTER(ctx);
     if (!ctx || !prev || !next || n < 0 || width < 1 || height < 1 || stride < width) return TB_EINVAL;
     if (n && (!prev_pts || !next_pts || !status)) return TB_EINVAL;
     if (max_level < 0 || max_level > 5) return tb_fail(ctx, TB_EUNSUPPORTED, "optical flow: max_level %d (0..5)", max_level);
@@ -1315,6 +1356,7 @@ int tb_optical_flow_pyr_lk(tb_ctx* ctx, const uint8_t* prev, const uint8_t* next
 int tb_search_by_opflow(tb_ctx* ctx, const uint8_t* img1, const uint8_t* img2, int width, int height, int stride,
                         const tb_camera* cam1, const float* keys2_xy, int n, int equalized, int reject, float* cur_points,
                         tb_match* out, int cap, int* count) {
+    TB_ENTER(ctx);
     if (!ctx || !count || !cam1 || n < 0 || cap < 0 || (n && (!cur_points || !keys2_xy)) || (cap && !out)) return TB_EINVAL;
     *count = 0;
     if (reject) return tb_fail(ctx, TB_EUNSUPPORTED, "searchByOPFlow: reject (rejectWithF = cv::findFundamentalMat RANSAC) is not built");
@@ -1349,6 +1391,7 @@ int tb_search_by_opflow_batch_dev(tb_ctx* ctx, int npairs, const uint8_t* img1, 
                                   size_t image_pitch, const tb_camera* cam1, const float* keys2_xy, const int32_t* counts, int pts_pitch,
                                   int equalized, int reject, float* cur_points, uint8_t* status, tb_match* out, int cap,
                                   int32_t* out_counts) {
+    TB_ENTER(ctx);
     if (!ctx || !cam1 || npairs < 0 || pts_pitch < 0 || cap < 0 || width < 1 || height < 1 || stride < width) return TB_EINVAL;
     if (reject) return tb_fail(ctx, TB_EUNSUPPORTED, "searchByOPFlow: reject (rejectWithF = cv::findFundamentalMat RANSAC) is not built");
     if (npairs == 0) return TB_OK;

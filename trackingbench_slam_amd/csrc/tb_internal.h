@@ -47,6 +47,20 @@ int tb_scratch(tb_ctx* ctx, int slot, size_t bytes, void** out);
                            __FILE__, __LINE__);                                               \
     } while (0)
 
+/* First statement of every entry point that takes a context or a plan: the HIP "current device" is per host thread and
+ * the caller may hold contexts on several GPUs (or drive one context from several threads in turn), so every call binds
+ * its thread to the context's device before it launches, copies or allocates. A null context falls through to the
+ * function's own argument check. */
+#define TB_ENTER(ctx)                                                                          \
+    do {                                                                                       \
+        tb_ctx* c_ = (ctx);                                                                    \
+        if (c_) {                                                                              \
+            hipError_t e_ = hipSetDevice(c_->device);                                          \
+            if (e_ != hipSuccess)                                                              \
+                return tb_fail(c_, TB_EDEVICE, "hipSetDevice(%d): %s", c_->device, hipGetErrorString(e_)); \
+        }                                                                                      \
+    } while (0)
+
 /* Geometry of one pyramid level inside a plan (host and device copies are identical). */
 struct LevelGeom {
     int w, h, stride;     /* stride of the slab copy of this level */

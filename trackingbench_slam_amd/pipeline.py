@@ -21,14 +21,19 @@ KITTI_K = (718.856, 718.856, 607.1928, 185.2157)  # hard-coded in the reference,
 class TrackingPipeline:
     def __init__(self, width=1280, height=720, nlevels=8, scale=0.8, target=2000, init_th=80.0, min_th=30.0,
                  frames=16, bf_ratio=10.0, bf_min_th=30.0, device=0, with_ba=True, ba_kf=10, ba_pts=5000, ba_iters=10,
-                 seed=0, ba_split=3):
+                 seed=0, ba_split=3, ba_distinct=4):
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
         self.F = int(frames)
         self.width, self.height, self.nlevels, self.scale = width, height, nlevels, scale
         self.target, self.init_th, self.min_th = target, init_th, min_th
         self.bf_ratio, self.bf_min_th = bf_ratio, bf_min_th
-        self.ctx = capi.Context(device, stream=torch.cuda.current_stream(self.dev).cuda_stream)
+        # The extractor -> matcher -> pose-opt chain gets a torch stream of its own and the context runs on THAT handle:
+        # torch's default stream has handle 0, which tb_set_stream() reads as "the context's own stream" -- torch-side
+        # work (zero_(), the RCCL gather) would then be unordered against the kernels. Everything torch does for this
+        # chain is issued under `with torch.cuda.stream(self.main)`.
+        self.main = torch.cuda.Stream(device=self.dev)
+        self.ctx = capi.Context(device, stream=self.main.cuda_stream)
         self.ex = capi.Extractor(self.ctx, width, height, nlevels, scale, 2 * self.F, target)
         self.kps_ptr, self.desc_ptr, self.counts_ptr, self.kp_cap = self.ex.results_dev()
         F, cap = self.F, self.kp_cap
@@ -72,7 +77,8 @@ class TrackingPipeline:
             for i in range(nsplit):
                 st = torch.cuda.Stream(device=self.dev)
                 cx = capi.Context(device, stream=st.cuda_stream)
-                self.bas.append((BatchedLocalBA(cx, bounds[i + 1] - bounds[i], ba_kf, ba_pts, ba_iters, seed * 16 + i, self.dev), st, cx))
+                self.bas.append((BatchedLocalBA(cx, bounds[i + 1] - bounds[i], ba_kf, ba_pts, ba_iters, seed * 16 + i, self.dev,
+                                                distinct=max(1, -(-int(ba_distinct) // nsplit)), stream=st), st, cx))
             # each partition's driver blocks on its own stream once per call (LM termination is data dependent):
             # one host thread per partition keeps the partitions' kernel chains in flight together
             self._pool = ThreadPoolExecutor(max_workers=nsplit)
@@ -85,6 +91,11 @@ class TrackingPipeline:
     trk_kps = property(lambda self: self._sets[self._cur]["trk_kps"])
     trk_desc = property(lambda self: self._sets[self._cur]["trk_desc"])
     trk_counts = property(lambda self: self._sets[self._cur]["trk_counts"])
+
+    def stream_ctx(self):
+        """Context manager that makes the chain's stream torch's current stream: torch-side work on the records (the RCCL
+        gather, wait() of its handles, host copies) is issued inside it so that it is ordered against the kernels."""
+        return torch.cuda.stream(self.main)
 
     def close(self):
         torch.cuda.synchronize(self.dev)
@@ -110,8 +121,7 @@ class TrackingPipeline:
 
     def _run_ba(self, ba, st):
         torch.cuda.set_device(self.dev)  # the current device is per host thread
-        with torch.cuda.stream(st):
-            ba.run()
+        ba.run()                         # resets its state and queues the LM rounds on `st` (the partition's context stream)
 
     # ---- inputs
     def set_stereo_frames(self, left, right):
@@ -132,7 +142,7 @@ class TrackingPipeline:
     # ---- one pass of the hot path
     def step(self):
         F, ex, ctx, L = self.F, self.ex, self.ctx, capi.lib()
-        main = torch.cuda.current_stream(self.dev)
+        main = self.main
         self._cur ^= 1                           # this batch's records go to the other set
         futures = []
         for ba, st, _ in self.bas:
@@ -160,7 +170,8 @@ class TrackingPipeline:
                                               C.c_size_t(pitch), C.c_float(self.bf_ratio), C.c_float(self.bf_min_th),
                                               C.c_void_p(self.matches.data_ptr()), self.kp_cap,
                                               C.c_void_p(self.match_counts.data_ptr())))
-        self.outlier.zero_()
+        with torch.cuda.stream(self.main):
+            self.outlier.zero_()                 # ordered on the chain's stream, between the matcher and pose-opt
         ctx.check(L.tb_pose_opt_batch_dev(ctx._h, F, self.K.ctypes.data_as(C.c_void_p), C.c_void_p(self.Tin.data_ptr()),
                                           C.c_void_p(self.obs.data_ptr()), C.c_void_p(self.match_counts.data_ptr()),
                                           self.obs_pitch, C.c_void_p(self.outlier.data_ptr()), C.c_void_p(self.Tout.data_ptr()),
