@@ -184,3 +184,75 @@ def test_config_640x480_mono_1000_keypoints(ctx):
         ra.append(d)
     m = ctx.search_by_bf(ra[0], ra[1], 10, 30)
     _eq_struct(m, oracle.search_by_bf(ra[0], ra[1], 10, 30))
+
+
+def _cand_vs_oracle(ctx, img, nl, scale, ith, mth, N=500):
+    """FAST candidates of every level after the cell loop (a4), cell-major raster order, against the oracle."""
+    h, w = img.shape
+    ex = capi.Extractor(ctx, w, h, nl, scale, 1, N)
+    ex.set_images_host(img)
+    ex.build_pyramid(1)
+    ex.orb(1, N, ith, mth)
+    lv, _ = oracle.pyramid(img, nl, scale)
+    total = 0
+    for l in range(nl):
+        exp = oracle.orb_candidates(lv[l], ith, mth)
+        _eq_struct(ex.candidates(0, l), exp)
+        total += len(exp)
+    ex.close()
+    return total
+
+
+@pytest.mark.parametrize("seed,w,h,nl,scale,ith,mth", [(61, 1280, 720, 8, 0.8, 80, 30), (62, 640, 480, 6, 0.8, 20, 7),
+                                                        (63, 333, 241, 4, 0.7, 40, 40), (64, 150, 97, 2, 0.5, 30, 50),
+                                                        (65, 1241, 376, 5, 0.8, 255, 0), (66, 400, 300, 3, 0.8, 0, 0)])
+def test_cell_candidates_block_kernel(ctx, seed, w, h, nl, scale, ith, mth):
+    """k_fast_blocks walks blocks of up to 4 x 2 cells: levels whose cell grid is not a multiple of the block, one-cell
+    levels, equal / inverted / extreme thresholds (retry at minTh only where initTh leaves nothing after the NMS)."""
+    assert _cand_vs_oracle(ctx, synth.frame(seed, w, h), nl, scale, ith, mth) > 0 or ith == 255
+
+
+def test_cell_candidates_dense_images(ctx):
+    """Uniform noise at low thresholds: thousands of corners per block overflow the kernel's record / pixel / corner
+    lists, the block is redone by the any-density path (fb_dense) -- same candidates as the oracle."""
+    rng = np.random.default_rng(7)
+    noise = rng.integers(0, 256, (200, 330), dtype=np.uint8)
+    assert _cand_vs_oracle(ctx, noise, 3, 0.8, 12, 4) > 3000
+    assert _cand_vs_oracle(ctx, noise, 2, 0.8, 3, 1) > 3000
+    # half noise, half smooth: overflowing and ordinary blocks side by side
+    mixed = synth.frame(67, 660, 200)
+    mixed[:, :300] = rng.integers(0, 256, (200, 300), dtype=np.uint8)
+    assert _cand_vs_oracle(ctx, mixed, 3, 0.8, 20, 7) > 3000
+
+
+def test_cell_candidates_forced_dense_path(ctx, kitti_pair, monkeypatch):
+    """TB_FAST_DENSE=1 sends every block down the list-free path: it must reproduce the ordinary path's output."""
+    monkeypatch.setenv("TB_FAST_DENSE", "1")
+    _cand_vs_oracle(ctx, kitti_pair[0], 5, 0.8, 80, 30)
+    _cand_vs_oracle(ctx, synth.frame(68, 640, 480), 8, 0.8, 20, 7)
+    monkeypatch.delenv("TB_FAST_DENSE")
+    _cand_vs_oracle(ctx, kitti_pair[0], 5, 0.8, 80, 30)
+
+
+def test_orb_extract_unaligned_device_frames(ctx):
+    """Caller-owned level-0 frames whose row stride is not a multiple of 16 bytes take the byte-wise tile load."""
+    import torch
+    w, h, stride = 333, 241, 341
+    img = synth.frame(69, w, h)
+    buf = np.zeros((h, stride), np.uint8)
+    buf[:, :w] = img
+    buf[:, w:] = 255                      # padding must never be read as pixels
+    dev = torch.from_numpy(buf).cuda()
+    ex = capi.Extractor(ctx, w, h, 4, 0.8, 1, 500)
+    torch.cuda.synchronize()
+    ex.set_images_dev(dev.data_ptr(), 1, stride, stride * h)
+    ex.build_pyramid(1)
+    ex.orb(1, 500, 40, 10)
+    k, d = ex.results(0, 1000)
+    lv, sf = oracle.pyramid(img, 4, 0.8)
+    ko, do, _ = oracle.orb_extract(lv, sf, 500, 40, 10)
+    _eq_struct(k, ko)
+    assert np.array_equal(d, do)
+    for l in range(4):
+        _eq_struct(ex.candidates(0, l), oracle.orb_candidates(lv[l], 40, 10))
+    ex.close()

@@ -10,7 +10,7 @@ import subprocess
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtb_hip.so")
+LIB_PATH = os.environ.get("TB_HIP_LIB") or os.path.join(_HERE, "libtb_hip.so")   # TB_HIP_LIB: experiment builds
 _LIB = None
 
 KEYPOINT = np.dtype([("x", "<f4"), ("y", "<f4"), ("size", "<f4"), ("angle", "<f4"),

@@ -179,21 +179,59 @@ __device__ __forceinline__ void ft_process(const uint8_t* __restrict__ img, int 
     }
 }
 
-/* ---- cell mode: one WAVEFRONT per 30-px cell, four cells per workgroup, no workgroup barriers.
- * Per wave: ROI rows staged into a private LDS tile (32-bit loads when the level is 4-byte aligned);
- *   stage 1  cardinal test (ring positions 0/4/8/12 hold >= 2 adjacent members of any 9-arc) on every
- *            pixel, two ROI rows per 64-lane pass, survivors ballot-compacted into an LDS list;
- *   stage 2  full 16-position arc test on the list, compaction in place;
- *   stage 3  exact scores of the corners into a private score map;
- *   stage 4  3x3 strict maximum, initTh / minTh choice by wave ballot, emission through one atomic per
- *            wave-pass.  LDS per wave = tile + score map + list (sized by the plan's largest ROI). */
-struct FastCellsArgs {
-    int nCells;        /* cells per image */
-    int tileStride;    /* bytes per LDS tile row (multiple of 4) */
-    int tileRows;
-    int listCap;       /* interior pixels of the largest ROI */
-    int waveBytes;     /* LDS bytes per wave */
-};
+/* ---- cell mode (a4): ONE WORKGROUP PER BLOCK OF CELLS (up to 4 x 2 cells of ~30 px, FastBlock in tb_internal.h).
+ *
+ * The reference runs cv::FAST on every 30-px cell's ROI separately (ORBextractor.cpp:765-797). The cells' SCAN regions
+ * tile the level, their ROIs overlap by 6 px, and three things are per cell: the 3x3 non-max suppression sees only
+ * scores of its own cell's scan region (outside counts 0), the threshold is initTh if that leaves a corner after NMS and
+ * minTh otherwise, and nothing else. So a block of cells is processed as ONE image tile with the cell structure applied
+ * only where it matters:
+ *
+ *   stage 0  the block's ROI (<= 130 x 66 px) -> LDS with 16-byte row-segment loads, once: the pixels P and a
+ *            QUANTISED copy Q = P >> 2 (6 bits per byte).
+ *   stage 1  cardinal pre-test on every scanned pixel, 16 pixels per lane, byte-parallel on Q: with q = P >> 2 and
+ *            t'' = (t + 1) >> 2,  X > V + t  implies  qX - qV >= t''  and  X < V - t  implies  qV - qX >= t''
+ *            (floor((a + b) / 4) >= floor(a / 4) + floor(b / 4)), and both are ONE 32-bit add / subtract for four
+ *            pixels, the verdict in bit 7 of each byte, no carries between bytes:
+ *                bright: (qX + (128 - t'' - qV)) & 0x80        dark: ((128 - t'' + qV) - qX) & 0x80
+ *            A 9-arc holds two adjacent cardinals, so (b0|b8)&(b4|b12) | (d0|d8)&(d4|d12) is necessary; the quantised
+ *            form admits a few more pixels than the exact one and never loses a corner: 18 vector instructions per 4
+ *            pixels instead of 65 for the exact 16-bit SWAR form. Lanes with a hit store one 8-byte record.
+ *   stage 2  Q is dead: its LDS becomes the (zeroed) score map. The records are expanded into a pixel list (wave
+ *            prefix sum on the DPP path) and every listed pixel gets its exact FAST score, two pixels per lane in packed
+ *            16-bit halves, the batches dealt round-robin to the four wavefronts; corners (score >= initTh) go into the
+ *            score map and the corner list.
+ *   stage 3  3x3 strict maximum per corner, neighbours of another cell masked by per-column / per-row cell tables;
+ *            one bit per cell records "a corner survived".
+ *   retry    cells without a survivor are redone at minTh by one wavefront each (exact cardinal test from P, same
+ *            score routine); their pass-1 corners lost the NMS and lose it again (the scores that beat them are
+ *            still in the map), so only the new corners (minTh <= score < initTh) are appended and suppressed.
+ *   emit     every wavefront counts the survivors in its share of the list, reserves their range with one global atomic
+ *            and writes the records.
+ *
+ * LDS: P 10.6 KB + Q / score map 10.6 KB + lists 8.7 KB = 30.2 KB -> five blocks (20 wavefronts) per CU. The pixel and
+ * corner lists are sized for ordinary images (3072 listed pixels, 1360 corners per block: six times / ten times the
+ * average of textured frames); a block that overflows them -- dense noise, thresholds near zero -- is redone by
+ * fb_dense(): scores of all scanned pixels straight into the map, then per cell threshold choice, NMS and emission by
+ * scanning the map. No list, any density, same results (tests force it with TB_FAST_DENSE=1). */
+#define FB_SEGS (FB_S / 16)
+#define FB_NSEG_ALL (FB_SEGS * FB_TH)              /* 680 16-byte segments */
+#define FB_PX (FB_S * FB_TH)                       /* 10880 */
+#define FB_LIST_CAP 3072
+#define FB_REC_CAP FB_NSEG_ALL                     /* one 4-byte record per stage-1 work item: cannot overflow */
+#define FB_CL_CAP (FB_REC_CAP * 2)                 /* the corner list takes over the records' LDS */
+#define FB_OFF_R FB_PX                             /* Q, then the score map */
+#define FB_OFF_LIST (2 * FB_PX)
+#define FB_OFF_REC (FB_OFF_LIST + FB_LIST_CAP * 2)
+#define FB_OFF_CL FB_OFF_REC
+#define FB_OFF_COL (FB_OFF_REC + FB_REC_CAP * 4)
+#define FB_OFF_ROW (FB_OFF_COL + FB_S)
+#define FB_OFF_MISC (FB_OFF_ROW + 80)
+#ifndef FB_PAD_LDS
+#define FB_PAD_LDS 0
+#endif
+#define FB_LDS_BYTES (FB_OFF_MISC + 64 + FB_PAD_LDS)
+#define FB_RETRY_CAP 512                           /* pixels per retry strip (wave-private lists over LIST) */
 
 typedef short ft_s16x2 __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ ft_s16x2 ft_pack(int a, int b) { return (ft_s16x2){(short)a, (short)b}; }
@@ -202,306 +240,516 @@ __device__ __forceinline__ ft_s16x2 ft_max(ft_s16x2 a, ft_s16x2 b) { return __bu
 
 __device__ __forceinline__ void ft_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
-template <int ARC>
-__device__ __forceinline__ bool ft_is_corner_s(const uint8_t* c, int S, int th) {
-    const int v = c[0];
-    const int hi = v + th, lo = v - th;
-    int r[16];
-    r[0] = c[3 * S];      r[1] = c[3 * S + 1];   r[2] = c[2 * S + 2];   r[3] = c[S + 3];
-    r[4] = c[3];          r[5] = c[-S + 3];      r[6] = c[-2 * S + 2];  r[7] = c[-3 * S + 1];
-    r[8] = c[-3 * S];     r[9] = c[-3 * S - 1];  r[10] = c[-2 * S - 2]; r[11] = c[-S - 3];
-    r[12] = c[-3];        r[13] = c[S - 3];      r[14] = c[2 * S - 2];  r[15] = c[3 * S - 1];
-    uint32_t B = 0, D = 0;
+/* exact FAST-9 scores of two pixels (tile pointers pA, pB; row stride FB_S), packed: max over the 16 arcs of min(d) and
+ * of min(-d), d = centre - ring; the min over a 9-arc is a doubling network (2, 4, 8, 8 + 1), every step one
+ * v_pk_min_i16 / v_pk_max_i16 for both pixels. score = result - 1; a pixel is a corner at t iff score >= t. */
+__device__ __forceinline__ ft_s16x2 fb_score2(const uint8_t* pA, const uint8_t* pB) {
+    constexpr int S = FB_S;
+    const ft_s16x2 vv = ft_pack(pA[0], pB[0]);
+    ft_s16x2 d[16];
+    d[0] = vv - ft_pack(pA[3 * S], pB[3 * S]);           d[1] = vv - ft_pack(pA[3 * S + 1], pB[3 * S + 1]);
+    d[2] = vv - ft_pack(pA[2 * S + 2], pB[2 * S + 2]);   d[3] = vv - ft_pack(pA[S + 3], pB[S + 3]);
+    d[4] = vv - ft_pack(pA[3], pB[3]);                   d[5] = vv - ft_pack(pA[-S + 3], pB[-S + 3]);
+    d[6] = vv - ft_pack(pA[-2 * S + 2], pB[-2 * S + 2]); d[7] = vv - ft_pack(pA[-3 * S + 1], pB[-3 * S + 1]);
+    d[8] = vv - ft_pack(pA[-3 * S], pB[-3 * S]);         d[9] = vv - ft_pack(pA[-3 * S - 1], pB[-3 * S - 1]);
+    d[10] = vv - ft_pack(pA[-2 * S - 2], pB[-2 * S - 2]); d[11] = vv - ft_pack(pA[-S - 3], pB[-S - 3]);
+    d[12] = vv - ft_pack(pA[-3], pB[-3]);                d[13] = vv - ft_pack(pA[S - 3], pB[S - 3]);
+    d[14] = vv - ft_pack(pA[2 * S - 2], pB[2 * S - 2]);  d[15] = vv - ft_pack(pA[3 * S - 1], pB[3 * S - 1]);
+    ft_s16x2 lo2[16], hi2[16], lo4[16], hi4[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) { lo2[k] = ft_min(d[k], d[(k + 1) & 15]); hi2[k] = ft_max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+    for (int k = 0; k < 16; k++) { lo4[k] = ft_min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = ft_max(hi2[k], hi2[(k + 2) & 15]); }
+    ft_s16x2 best = (ft_s16x2){0, 0};
 #pragma unroll
     for (int k = 0; k < 16; k++) {
-        B |= (uint32_t)(r[k] > hi) << k;
-        D |= (uint32_t)(r[k] < lo) << k;
+        const ft_s16x2 lo9 = ft_min(ft_min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);   /* min over the 9-arc starting at k */
+        const ft_s16x2 hi9 = ft_max(ft_max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
+        best = ft_max(best, ft_max(lo9, -hi9));
     }
-    B |= B << 16;
-    D |= D << 16;
-    uint32_t xb = B & (B >> 1), xd = D & (D >> 1);
-    xb &= xb >> 2; xd &= xd >> 2;
-    xb &= xb >> 4; xd &= xd >> 4;
-    xb &= B >> 8;  xd &= D >> 8;
-    if (ARC == 10) { xb &= B >> 9; xd &= D >> 9; }
-    return ((xb | xd) & 0xffffu) != 0;
+    return best;
 }
 
-template <int ARC>
-__device__ __forceinline__ int ft_score_s(const uint8_t* c, int S) {
-    const int v = c[0];
-    int d[16];
-    d[0] = v - c[3 * S];      d[1] = v - c[3 * S + 1];   d[2] = v - c[2 * S + 2];   d[3] = v - c[S + 3];
-    d[4] = v - c[3];          d[5] = v - c[-S + 3];      d[6] = v - c[-2 * S + 2];  d[7] = v - c[-3 * S + 1];
-    d[8] = v - c[-3 * S];     d[9] = v - c[-3 * S - 1];  d[10] = v - c[-2 * S - 2]; d[11] = v - c[-S - 3];
-    d[12] = v - c[-3];        d[13] = v - c[S - 3];      d[14] = v - c[2 * S - 2];  d[15] = v - c[3 * S - 1];
-    int best = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++) {
-        int mn = d[k], mx = d[k];
-#pragma unroll
-        for (int i = 1; i < ARC; i++) {
-            mn = min(mn, d[(k + i) & 15]);
-            mx = max(mx, d[(k + i) & 15]);
-        }
-        best = max(best, max(mn, -mx));
-    }
-    return best - 1;
+/* exact cardinal pre-test at threshold th (one pixel per lane; retry and dense paths) */
+__device__ __forceinline__ bool fb_cardinal(const uint8_t* c, int th) {
+    const int v = c[0], hi = v + th, lo = v - th;
+    const int p0 = c[3 * FB_S], p8 = c[-3 * FB_S], p4 = c[3], p12 = c[-3];
+    return (((p0 > hi) | (p8 > hi)) & ((p4 > hi) | (p12 > hi))) | (((p0 < lo) | (p8 < lo)) & ((p4 < lo) | (p12 < lo)));
 }
 
-template <int ST> /* ST = LDS tile row stride in bytes (0 = runtime value): a constant folds every ring offset into the
-                     ds_read immediate field */
-__global__ void __launch_bounds__(256)
-k_fast_cells(PlanGeom g, const uint8_t* __restrict__ slab, const CellDesc* __restrict__ cells,
-             uint32_t* __restrict__ cand, int32_t* __restrict__ candCount, int init_th, int min_th, FastCellsArgs A) {
-    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-    /* wave-uniform values are made scalar so the cell / level descriptors come through the scalar cache */
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int cellId = blockIdx.x * 4 + wave;
-    if (cellId >= A.nCells) return;
-    const int b = blockIdx.y;
-    const CellDesc c = cells[cellId];
-    const LevelGeom& L = g.lv[c.level];
-    int stride;
-    const uint8_t* img = tb_level_ptr(g, slab, b, c.level, &stride);
-    const int S = ST ? ST : A.tileStride;
-    uint8_t* tile = smem + (size_t)wave * A.waveBytes;
-    uint8_t* sc = tile + S * A.tileRows;
-    uint16_t* list = reinterpret_cast<uint16_t*>(sc + S * A.tileRows);
+/* idx -> row of the tile: idx / 160 = (idx >> 5) / 5, exact for idx < 160 * 204 */
+__device__ __forceinline__ int fb_row(int idx) { return ((idx >> 5) * 205) >> 10; }
 
-    /* ---- stage 0: ROI rows -> LDS. LDS column 0 = image column ax0 (x0 rounded down to 4) */
-    const int rw = c.x1 - c.x0, rh = c.y1 - c.y0;
-    const int ax0 = c.x0 & ~3, cx0 = c.x0 - ax0;
-    const int nd = (cx0 + rw + 3) >> 2; /* dwords per row */
-    const bool aligned = ((stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(img) & 3) == 0) && (ax0 + nd * 4 <= stride);
-    if (aligned) {
-        const int per = 64 / nd; /* rows per pass (nd <= 18) */
-        const int rr = lane / nd, dd = lane - rr * nd;
-        const uint8_t* src = img + (size_t)c.y0 * stride + ax0 + 4 * dd;
-        for (int y0 = 0; y0 < rh; y0 += 8 * per) { /* up to 8 row loads in flight per lane before the LDS stores */
-            uint32_t v[8];
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int y = y0 + j * per + rr;
-                v[j] = 0;
-                if (rr < per && y < rh) v[j] = *reinterpret_cast<const uint32_t*>(src + (size_t)y * stride);
-            }
-#pragma unroll
-            for (int j = 0; j < 8; j++) {
-                const int y = y0 + j * per + rr;
-                if (rr < per && y < rh) {
-                    *reinterpret_cast<uint32_t*>(tile + y * S + 4 * dd) = v[j];
-                    *reinterpret_cast<uint32_t*>(sc + y * S + 4 * dd) = 0;
+/* 3x3 strict maximum inside the corner's own cell: neighbours across a cell boundary (and outside the scan region,
+ * where the map is 0 anyway) do not count. colinfo / rowinfo: bits 0-1 cell index, bit 4 first, bit 5 last column /
+ * row of its cell. */
+__device__ __forceinline__ bool fb_nms_keep(const uint8_t* sc, const uint8_t* colinfo, const uint8_t* rowinfo, int idx,
+                                            int* cell) {
+    const int ty = fb_row(idx), tx = idx - ty * FB_S;
+    const int ci = colinfo[tx], ri = rowinfo[ty];
+    *cell = (ri & 3) * FB_MAX_CX + (ci & 3);
+    const int s = sc[idx];
+    const bool L = !(ci & 16), R = !(ci & 32), U = !(ri & 16), D = !(ri & 32);
+    int m = 0;
+    m = max(m, L ? (int)sc[idx - 1] : 0);
+    m = max(m, R ? (int)sc[idx + 1] : 0);
+    m = max(m, U ? (int)sc[idx - FB_S] : 0);
+    m = max(m, D ? (int)sc[idx + FB_S] : 0);
+    m = max(m, (U && L) ? (int)sc[idx - FB_S - 1] : 0);
+    m = max(m, (U && R) ? (int)sc[idx - FB_S + 1] : 0);
+    m = max(m, (D && L) ? (int)sc[idx + FB_S - 1] : 0);
+    m = max(m, (D && R) ? (int)sc[idx + FB_S + 1] : 0);
+    return s > m;
+}
+
+struct FbGeom {                       /* wave-uniform geometry of the block's tile */
+    int ax0, y0;                      /* image column of tile column 0, image row of tile row 0 */
+    int scanX0, scanX1, scanY1;       /* scanned tile columns [scanX0, scanX1), rows [3, scanY1) */
+    int wCell, hCell, ncx, ncy;
+};
+
+__device__ __forceinline__ uint32_t fb_record(const uint8_t* SC, const FbGeom& G, int idx) {
+    const int ty = fb_row(idx), tx = idx - ty * FB_S;
+    return ((uint32_t)SC[idx] << 24) | ((uint32_t)(G.y0 + ty - TB_BORDER) << 12) | (uint32_t)(G.ax0 + tx - TB_BORDER);
+}
+
+/* wave-level emission of the lanes with e set: one returning global atomic, then the records */
+__device__ __forceinline__ void fb_emit_wave(bool e, uint32_t rec, int lane, int* __restrict__ count, uint32_t* __restrict__ out,
+                                             int cap) {
+    const unsigned long long m = __ballot(e);
+    if (!m) return;
+    int wbase = 0;
+    if (lane == 0) wbase = atomicAdd(count, __popcll(m));
+    wbase = __builtin_amdgcn_readfirstlane(wbase);
+    if (e) {
+        const int slot = wbase + __popcll(m & ((1ull << lane) - 1));
+        if (slot < cap) out[slot] = rec;
+    }
+}
+
+/* Any-density path: no lists. Exact scores of ALL scanned pixels at the lower threshold go straight into the (cleared)
+ * map; then, cell by cell (one wavefront each), the reference's two tries: survivors of the NMS at initTh, or, if there
+ * are none, at minTh. The NMS reads true scores: a neighbour below the threshold in force scores below the corner anyway. */
+__device__ __forceinline__ void fb_dense(uint8_t* P, uint8_t* SC, const uint8_t* colinfo, const uint8_t* rowinfo, const FbGeom G,
+                                      int init_th, int min_th, int* __restrict__ count, uint32_t* __restrict__ out, int cap) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int i = tid; i < FB_PX / 16; i += 256) reinterpret_cast<uint4*>(SC)[i] = make_uint4(0, 0, 0, 0);
+    __syncthreads();
+    const int tlow = min(init_th, min_th);
+    const int sw = G.scanX1 - G.scanX0;
+    for (int y = 3 + wave; y < G.scanY1; y += 4)
+        for (int x0 = 0; x0 < sw; x0 += 64) {
+            const int x = x0 + lane;
+            if (x < sw) {
+                const int idx = y * FB_S + G.scanX0 + x;
+                if (fb_cardinal(P + idx, tlow)) {
+                    const ft_s16x2 best = fb_score2(P + idx, P + idx);
+                    const int s = (int)best.x - 1;
+                    if (s >= tlow && s > 0) SC[idx] = (uint8_t)min(s, 255);
                 }
             }
         }
-    } else {
-        for (int y = 0; y < rh; y++)
-            for (int x = lane; x < nd * 4; x += 64) {
-                const int ax = ax0 + x;
-                tile[y * S + x] = (ax >= c.x0 && ax < c.x1) ? img[(size_t)(c.y0 + y) * stride + ax] : 0;
-                sc[y * S + x] = 0;
-            }
+    __syncthreads();
+    for (int cellId = wave; cellId < FB_MAX_CX * FB_MAX_CY; cellId += 4) {
+        const int cx = cellId & (FB_MAX_CX - 1), cy = cellId / FB_MAX_CX;
+        if (cx >= G.ncx || cy >= G.ncy) continue;
+        const int X0 = G.scanX0 + cx * G.wCell, X1 = min(X0 + G.wCell, G.scanX1);
+        const int Y0 = 3 + cy * G.hCell, Y1 = min(Y0 + G.hCell, G.scanY1);
+        int th = init_th;
+        for (int pass = 0; pass < 2; pass++) {
+            bool any = false;
+            for (int y = Y0; y < Y1; y++)
+                for (int x0 = X0; x0 < X1; x0 += 64) {
+                    const int x = x0 + lane, idx = y * FB_S + x;
+                    int cell;
+                    const bool k = x < X1 && SC[idx] >= th && SC[idx] > 0 && fb_nms_keep(SC, colinfo, rowinfo, idx, &cell);
+                    if (pass == 0) any = any || (__ballot(k) != 0);
+                    else fb_emit_wave(k, k ? fb_record(SC, G, idx) : 0u, lane, count, out, cap);
+                }
+            if (pass == 0 && !any) th = min_th;    /* min_th >= init_th finds nothing either: a subset */
+        }
     }
-    ft_lds_fence();
+}
 
-    /* ---- stage 1: cardinal test on every scanned pixel, FOUR pixels per lane, SWAR on 16-bit sub-lanes.
-     * With V the centre, X a ring pixel, t the threshold, per 16-bit lane:
-     *   X > V + t  <=>  bit 9 of  X + (511 - t - V)        (value in [1, 766]: no carry between lanes)
-     *   X < V - t  <=>  bit 9 of  (V + 511 - t) - X        (value in [1, 766]: no borrow)
-     * A 9-arc holds two adjacent cardinals, i.e. one of {0, 8} and one of {4, 12}. */
-    const int sw = rw - 6, sh = rh - 6;
-    /* The cell is tried at init_th first, as the reference does (ORBextractor.cpp:785-797): only where that leaves no
-     * corner after NMS is it redone at min_th. NMS does not depend on the threshold (a neighbour below the threshold
-     * scores below any corner at it), so the first pass is exact -- and on textured frames it sends a quarter of the
-     * pixels into the score stage that a single pass at min_th would (2.6 % of the pixels are corners at 80, 10 % at 30). */
-    int thA = init_th;
-    int nlist = 0, ncorner = 0;
-    auto nms_keep = [&](int idx) -> bool {
-        const int s = sc[idx];
-        return s > 0 && s > sc[idx - 1] && s > sc[idx + 1] && s > sc[idx - S - 1] && s > sc[idx - S] && s > sc[idx - S + 1] &&
-               s > sc[idx + S - 1] && s > sc[idx + S] && s > sc[idx + S + 1];
-    };
-    for (int pass = 0; pass < 2; pass++) {
-    nlist = 0;
-    ncorner = 0;
-    if (sw > 0 && sh > 0) {
-        const int cA = cx0 + 3, cB = cx0 + rw - 3;   /* scanned LDS columns [cA, cB) */
-        const int gA = cA >> 2, ng = ((cB - 1) >> 2) - gA + 1;
-        const int rowsPer = 64 / ng;
-        const int rr = lane / ng, gg = lane - rr * ng;
-        const uint32_t K = (uint32_t)(511 - thA) * 0x00010001u;
-        const uint32_t M = 0x00ff00ffu;
-        const int col0 = 4 * (gA + gg);
-        /* valid pixels of this lane's group */
-        uint32_t vmask = 0;
-#pragma unroll
-        for (int i = 0; i < 4; i++) vmask |= (uint32_t)((col0 + i >= cA) && (col0 + i < cB)) << i;
-        for (int y = 0; y < sh; y += rowsPer) {
-            const int yy = y + rr;
-            uint32_t m = 0;
-            const int base = (3 + yy) * S + col0;
-            if (rr < rowsPer && yy < sh) {
-                const uint32_t C = *reinterpret_cast<const uint32_t*>(tile + base);
-                const uint32_t Lw = *reinterpret_cast<const uint32_t*>(tile + base - 4);
-                const uint32_t Rw = *reinterpret_cast<const uint32_t*>(tile + base + 4);
-                const uint32_t Tt = *reinterpret_cast<const uint32_t*>(tile + base - 3 * S);
-                const uint32_t Bt = *reinterpret_cast<const uint32_t*>(tile + base + 3 * S);
-                const uint32_t X12 = __builtin_amdgcn_alignbyte(C, Lw, 1);
-                const uint32_t X4 = __builtin_amdgcn_alignbyte(Rw, C, 3);
-                const uint32_t VE = C & M, VO = (C >> 8) & M;
-                const uint32_t AE = K - VE, AO = K - VO, CE = K + VE, CO = K + VO;
-                uint32_t x, xe, xo;
-                x = Bt; xe = x & M; xo = (x >> 8) & M;
-                uint32_t b08e = xe + AE, b08o = xo + AO, d08e = CE - xe, d08o = CO - xo;
-                x = Tt; xe = x & M; xo = (x >> 8) & M;
-                b08e |= xe + AE; b08o |= xo + AO; d08e |= CE - xe; d08o |= CO - xo;
-                x = X4; xe = x & M; xo = (x >> 8) & M;
-                uint32_t b4e = xe + AE, b4o = xo + AO, d4e = CE - xe, d4o = CO - xo;
-                x = X12; xe = x & M; xo = (x >> 8) & M;
-                b4e |= xe + AE; b4o |= xo + AO; d4e |= CE - xe; d4o |= CO - xo;
-                const uint32_t re = ((b08e & b4e) | (d08e & d4e)) & 0x02000200u;
-                const uint32_t ro = ((b08o & b4o) | (d08o & d4o)) & 0x02000200u;
-                m = (((re >> 9) & 1u) | (((ro >> 9) & 1u) << 1) | (((re >> 25) & 1u) << 2) | (((ro >> 25) & 1u) << 3)) & vmask;
-            }
-#pragma unroll
-            for (int i = 0; i < 4; i++) {
-                const bool pass = (m >> i) & 1u;
-                const unsigned long long bm = __ballot(pass);
-                if (pass) list[nlist + __popcll(bm & ((1ull << lane) - 1))] = (uint16_t)(base + i);
-                nlist += __popcll(bm);
-            }
-        }
-    }
-    ft_lds_fence();
+#ifdef FB_TIMING   /* debug build (make EXTRA=-DFB_TIMING): per-stage shader clocks of wavefront 0 of every 64th block */
+__device__ unsigned long long fb_times[16];
+#define FB_T(i) do { const unsigned long long t1_ = __builtin_readcyclecounter(); dt_[i] = t1_ - t0_; t0_ = t1_; } while (0)
+extern "C" int tb_debug_fast_times(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(fb_times), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(fb_times), z, sizeof z); }
+    return 0;
+}
+#else
+#define FB_T(i) do { } while (0)
+#endif
 
-    /* ---- stage 2 + 3: exact FAST score of every survivor, TWO survivors per lane in packed 16-bit halves.
-     * score = max over the 16 arcs of min(d) and of min(-d), minus 1, with d = centre - ring; the min over a
-     * 9-arc is a doubling network (2, 4, 8, 8+1), every step one v_pk_min_i16 / v_pk_max_i16 for both pixels.
-     * A survivor is a corner at thA iff score >= thA; corners are compacted in place. */
-    for (int base = 0; base < nlist; base += 128) {
-        const int iA = base + lane, iB = base + 64 + lane;
-        const bool vA = iA < nlist, vB = iB < nlist;
-        const int idxA = vA ? list[iA] : (3 * S + 4), idxB = vB ? list[iB] : (3 * S + 4);
-        const uint8_t* pA = tile + idxA;
-        const uint8_t* pB = tile + idxB;
-        const ft_s16x2 vv = ft_pack(pA[0], pB[0]);
-        ft_s16x2 d[16];
-        d[0] = vv - ft_pack(pA[3 * S], pB[3 * S]);           d[1] = vv - ft_pack(pA[3 * S + 1], pB[3 * S + 1]);
-        d[2] = vv - ft_pack(pA[2 * S + 2], pB[2 * S + 2]);   d[3] = vv - ft_pack(pA[S + 3], pB[S + 3]);
-        d[4] = vv - ft_pack(pA[3], pB[3]);                   d[5] = vv - ft_pack(pA[-S + 3], pB[-S + 3]);
-        d[6] = vv - ft_pack(pA[-2 * S + 2], pB[-2 * S + 2]); d[7] = vv - ft_pack(pA[-3 * S + 1], pB[-3 * S + 1]);
-        d[8] = vv - ft_pack(pA[-3 * S], pB[-3 * S]);         d[9] = vv - ft_pack(pA[-3 * S - 1], pB[-3 * S - 1]);
-        d[10] = vv - ft_pack(pA[-2 * S - 2], pB[-2 * S - 2]); d[11] = vv - ft_pack(pA[-S - 3], pB[-S - 3]);
-        d[12] = vv - ft_pack(pA[-3], pB[-3]);                d[13] = vv - ft_pack(pA[S - 3], pB[S - 3]);
-        d[14] = vv - ft_pack(pA[2 * S - 2], pB[2 * S - 2]);  d[15] = vv - ft_pack(pA[3 * S - 1], pB[3 * S - 1]);
-        ft_s16x2 lo2[16], hi2[16], lo4[16], hi4[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) { lo2[k] = ft_min(d[k], d[(k + 1) & 15]); hi2[k] = ft_max(d[k], d[(k + 1) & 15]); }
-#pragma unroll
-        for (int k = 0; k < 16; k++) { lo4[k] = ft_min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = ft_max(hi2[k], hi2[(k + 2) & 15]); }
-        ft_s16x2 best = (ft_s16x2){0, 0};
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            const ft_s16x2 lo9 = ft_min(ft_min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);   /* min over the 9-arc starting at k */
-            const ft_s16x2 hi9 = ft_max(ft_max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
-            best = ft_max(best, ft_max(lo9, -hi9));
-        }
-        const int sA = (int)best.x - 1, sB = (int)best.y - 1;
-        const bool cA = vA && sA >= thA && sA > 0, cB = vB && sB >= thA && sB > 0;
-        ft_lds_fence(); /* every lane has read its two list entries before the compaction overwrites them */
-        const unsigned long long mA = __ballot(cA);
-        if (cA) { list[ncorner + __popcll(mA & ((1ull << lane) - 1))] = (uint16_t)idxA; sc[idxA] = (uint8_t)min(sA, 255); }
-        ncorner += __popcll(mA);
-        const unsigned long long mB = __ballot(cB);
-        if (cB) { list[ncorner + __popcll(mB & ((1ull << lane) - 1))] = (uint16_t)idxB; sc[idxB] = (uint8_t)min(sB, 255); }
-        ncorner += __popcll(mB);
-        ft_lds_fence();
-    }
+#ifndef FB_MINW
+#define FB_MINW 5
+#endif
+__global__ void __launch_bounds__(256, FB_MINW)   /* five blocks = 20 wavefronts per CU: at most 96 VGPRs */
+k_fast_blocks(PlanGeom g, const uint8_t* __restrict__ slab, const FastBlock* __restrict__ blocks, int nBlocks, int nb8,
+              uint32_t* __restrict__ cand, int32_t* __restrict__ candCount, int init_th, int min_th, int force_dense) {
+    extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+    uint8_t* const P = smem;
+    uint8_t* const Q = smem + FB_OFF_R;      /* stage 0-1 */
+    uint8_t* const SC = smem + FB_OFF_R;     /* stage 2-  */
+    uint16_t* const LIST = reinterpret_cast<uint16_t*>(smem + FB_OFF_LIST);
+    uint32_t* const REC = reinterpret_cast<uint32_t*>(smem + FB_OFF_REC);   /* stage 1-2a */
+    uint16_t* const CL = reinterpret_cast<uint16_t*>(smem + FB_OFF_CL);     /* stage 2b-: same LDS */
+    uint8_t* const colinfo = smem + FB_OFF_COL;
+    uint8_t* const rowinfo = smem + FB_OFF_ROW;
+    int* const misc = reinterpret_cast<int*>(smem + FB_OFF_MISC);
+    /* misc: 0 records, 1 listed pixels, 2 corners, 3 cells with a survivor, 4 overflow */
 
-    /* ---- stage 4: NMS; does this pass leave a corner? (list[] holds the corners at thA, sc[] their scores, 0 elsewhere) */
-    bool any = false;
-    for (int base = 0; base < ncorner; base += 64) {
-        const int i = base + lane;
-        const bool keep = (i < ncorner) && nms_keep(list[i]);
-        any = any || (__ballot(keep) != 0);
-    }
-    if (any || pass == 1 || min_th >= init_th) break;
-    /* nothing at init_th: forget this pass's scores (corners that lost the NMS) and redo the cell at min_th */
-    for (int base = 0; base < ncorner; base += 64) {
-        const int i = base + lane;
-        if (i < ncorner) sc[list[i]] = 0;
-    }
-    ft_lds_fence();
-    thA = min_th;
-    }
-    for (int base = 0; base < ncorner; base += 64) { /* drop the corners that lose the NMS */
-        const int i = base + lane;
-        if (i < ncorner && !nms_keep(list[i])) list[i] = 0xffff; /* only the scores are read across lanes */
-    }
-    ft_lds_fence();
-    uint32_t* out = cand + (size_t)b * g.candPerImage + L.candOff;
-    int* count = candCount + b * TB_MAX_LEVELS + c.level;
-    /* ONE returning atomic per cell (a returning atomic per 64-lane pass cost 30-50 % of this kernel: every
-     * wave stalls on the round trip to a counter shared by the ~900 cells of its level): count the survivors
-     * first, reserve the range, then write */
-    int total = 0;
-    for (int base = 0; base < ncorner; base += 64) {
-        const int i = base + lane;
-        bool e = false;
-        if (i < ncorner) {
-            e = list[i] != 0xffff;
-        }
-        total += __popcll(__ballot(e));
-    }
-    ft_lds_fence();
-    if (total == 0) return;
-    int wbase = 0;
-    if (lane == 0) wbase = atomicAdd(count, total);
-    wbase = __shfl(wbase, 0, TB_WAVE);
-    for (int base = 0; base < ncorner; base += 64) {
-        const int i = base + lane;
-        bool e = false;
-        uint32_t rec = 0;
-        if (i < ncorner) {
-            const int idx = list[i];
-            if (idx != 0xffff) {
-                const int y = idx / S, x = idx - y * S;
-                e = true;
-                rec = ((uint32_t)sc[idx] << 24) | ((uint32_t)(c.y0 + y - TB_BORDER) << 12) | (uint32_t)(ax0 + x - TB_BORDER);
+    /* consecutive workgroup ids go round the 8 XCDs: give every XCD a contiguous run of blocks (neighbouring blocks share
+     * their 6-px overlap and the partial 64-byte lines at their edges through that XCD's L2) */
+    const int bid = (int)(blockIdx.x & 7) * nb8 + (int)(blockIdx.x >> 3);
+    if (bid >= nBlocks) return;
+    const int b = blockIdx.y;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const FastBlock blk = blocks[bid];
+    const LevelGeom& L = g.lv[blk.level];
+    int stride;
+    const uint8_t* img = tb_level_ptr(g, slab, b, blk.level, &stride);
+    const int rw = blk.x1 - blk.x0, rh = blk.y1 - blk.y0;
+    FbGeom G;
+    G.ax0 = blk.x0 & ~15;                                   /* LDS column 0 = image column ax0 */
+    G.y0 = blk.y0;
+    const int cx0 = blk.x0 - G.ax0;
+    const int nseg = (cx0 + rw + 15) >> 4;                  /* 16-byte segments per row that hold ROI pixels */
+    G.wCell = L.wCell; G.hCell = L.hCell; G.ncx = blk.ncx; G.ncy = blk.ncy;
+    G.scanX0 = cx0 + 3; G.scanX1 = cx0 + rw - 3; G.scanY1 = rh - 3;
+    const int wCell = G.wCell, hCell = G.hCell, scanX0 = G.scanX0, scanX1 = G.scanX1, scanY1 = G.scanY1;
+    uint32_t* const out = cand + (size_t)b * g.candPerImage + L.candOff;
+    int* const count = candCount + b * TB_MAX_LEVELS + blk.level;
+    const int candCap = L.candCap;
+#ifdef FB_TIMING
+    unsigned long long t0_ = __builtin_readcyclecounter();
+    unsigned long long dt_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#endif
+
+    /* ---- stage 0 */
+    if (tid < 8) misc[tid] = 0;
+    if (wave == 3) {   /* cell tables: one wavefront, three columns and a row per lane (the other three go straight to the loads) */
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int tx = lane + 64 * j;
+            if (tx < FB_S) {
+                const int rel = tx - scanX0;
+                int info = 0x80;
+                if (rel >= 0 && tx < scanX1) {
+                    const int k = (rel >= wCell) + (rel >= 2 * wCell) + (rel >= 3 * wCell);
+                    info = k | ((rel == k * wCell) ? 16 : 0) | ((rel == (k + 1) * wCell - 1 || tx == scanX1 - 1) ? 32 : 0);
+                }
+                colinfo[tx] = (uint8_t)info;
             }
         }
-        const unsigned long long m = __ballot(e);
-        if (e) {
-            const int slot = wbase + __popcll(m & ((1ull << lane) - 1));
-            if (slot < L.candCap) out[slot] = rec;
+        for (int ty = lane; ty < FB_TH; ty += 64) {
+            const int rel = ty - 3;
+            int info = 0x80;
+            if (rel >= 0 && ty < scanY1) {
+                const int k = (rel >= hCell) ? 1 : 0;
+                info = k | ((rel == k * hCell) ? 16 : 0) | ((rel == (k + 1) * hCell - 1 || ty == scanY1 - 1) ? 32 : 0);
+            }
+            rowinfo[ty] = (uint8_t)info;
         }
-        wbase += __popcll(m);
     }
+    {
+        const bool wide = ((stride & 15) == 0) && ((reinterpret_cast<uintptr_t>(img) & 15) == 0);
+        uint4 v[3];
+        int o[3];
+        int row = (tid * 6554) >> 16, seg = tid - row * FB_SEGS;      /* segment tid: row tid / 10 */
+#pragma unroll
+        for (int k = 0; k < 3; k++) {       /* all row-segment loads in flight before the first LDS store */
+            v[k] = make_uint4(0, 0, 0, 0);
+            o[k] = row * FB_S + 16 * seg;
+            if (row < rh && seg < nseg) {
+                const uint8_t* src = img + (size_t)(blk.y0 + row) * stride + (G.ax0 + 16 * seg);
+                if (wide) {
+                    v[k] = *reinterpret_cast<const uint4*>(src);
+                } else {                    /* caller-owned level 0 with an odd stride: bytes, bounded by the row */
+                    uint32_t w4[4] = {0, 0, 0, 0};
+#pragma unroll 1
+                    for (int j = 0; j < 16; j++)
+                        if (G.ax0 + 16 * seg + j < L.w) w4[j >> 2] |= (uint32_t)src[j] << (8 * (j & 3));
+                    v[k] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                }
+            }
+            row += 25; seg += 6;            /* + 256 segments */
+            if (seg >= FB_SEGS) { seg -= FB_SEGS; row++; }
+        }
+#pragma unroll
+        for (int k = 0; k < 3; k++)
+            if (o[k] < FB_PX) {
+                *reinterpret_cast<uint4*>(P + o[k]) = v[k];
+                const uint32_t M6 = 0x3f3f3f3fu;
+                *reinterpret_cast<uint4*>(Q + o[k]) = make_uint4((v[k].x >> 2) & M6, (v[k].y >> 2) & M6, (v[k].z >> 2) & M6, (v[k].w >> 2) & M6);
+            }
+    }
+    __syncthreads();
+    FB_T(0);
+
+    /* ---- stage 1: quantised cardinal test, 16 pixels per lane */
+    {
+        const int nss = blk.nss, rowsPer = blk.rowsPer;      /* lane map from the host (FastBlock) */
+        const int rr = (lane * (int)blk.invNss) >> 15, ss = lane - rr * nss;
+        const int col16 = 16 * (blk.sA + ss);
+        uint32_t ms[4];                              /* valid-pixel masks of the lane's four dwords, bit 7 of each byte, pre-shifted */
+#pragma unroll
+        for (int d = 0; d < 4; d++) {
+            /* bytes k of dword d cover tile columns col16 + 4 d + k: valid inside [scanX0, scanX1) */
+            const int c0 = col16 + 4 * d;
+            const int lo = min(max(scanX0 - c0, 0), 4), hi = min(max(scanX1 - c0, 0), 4);   /* valid bytes [lo, hi) */
+            const uint32_t below_hi = hi >= 4 ? 0xffffffffu : ((1u << (8 * hi)) - 1u);
+            const uint32_t below_lo = lo >= 4 ? 0xffffffffu : ((1u << (8 * lo)) - 1u);
+            ms[d] = ((below_hi & ~below_lo) & 0x80808080u) >> d;
+        }
+        const int tq = (init_th + 1) >> 2;
+        const uint32_t K = (uint32_t)(128 - tq) * 0x01010101u;
+        const int nPass = blk.nPass;
+        for (int p = wave; p < nPass; p += 4) {
+            const int r = 3 + p * rowsPer + rr;
+            uint32_t Gm = 0;
+            const int base = r * FB_S + col16;
+            if (rr < rowsPer && r < scanY1) {
+                const uint4 C = *reinterpret_cast<const uint4*>(Q + base);
+                const uint4 T = *reinterpret_cast<const uint4*>(Q + base - 3 * FB_S);
+                const uint4 B = *reinterpret_cast<const uint4*>(Q + base + 3 * FB_S);
+                const uint32_t Lw = *reinterpret_cast<const uint32_t*>(Q + base - 4);
+                const uint32_t Rw = *reinterpret_cast<const uint32_t*>(Q + base + 16);
+                const uint32_t c[6] = {Lw, C.x, C.y, C.z, C.w, Rw};
+                const uint32_t t[4] = {T.x, T.y, T.z, T.w};
+                const uint32_t bb[4] = {B.x, B.y, B.z, B.w};
+                uint32_t F[4];
+#pragma unroll
+                for (int d = 0; d < 4; d++) {
+                    const uint32_t X12 = __builtin_amdgcn_alignbyte(c[d + 1], c[d], 1);      /* column - 3 */
+                    const uint32_t X4 = __builtin_amdgcn_alignbyte(c[d + 2], c[d + 1], 3);   /* column + 3 */
+                    const uint32_t A = K - c[d + 1], E = K + c[d + 1];
+                    const uint32_t b08 = (t[d] + A) | (bb[d] + A), b412 = (X4 + A) | (X12 + A);
+                    const uint32_t d08 = (E - t[d]) | (E - bb[d]), d412 = (E - X4) | (E - X12);
+                    F[d] = (b08 & b412) | (d08 & d412);
+                }
+                /* 16 verdicts -> one word: dword d's land in bit 7 - d of every byte */
+                Gm = (F[0] & ms[0]) | ((F[1] >> 1) & ms[1]) | ((F[2] >> 2) & ms[2]) | ((F[3] >> 3) & ms[3]);
+            }
+            const bool hit = Gm != 0;
+            const unsigned long long bm = __ballot(hit);
+            if (bm) {
+                int wbase = 0;
+                if (lane == 0) wbase = atomicAdd(&misc[0], __popcll(bm));
+                wbase = __builtin_amdgcn_readfirstlane(wbase);
+                /* the verdicts sit in bits 4-7 of every byte: the segment number (10 bits) travels in the low nibbles */
+                const uint32_t pos = (uint32_t)(base >> 4);
+                const uint32_t enc = (pos & 0xfu) | ((pos << 4) & 0xf00u) | ((pos << 8) & 0x30000u);
+                if (hit) REC[wbase + __popcll(bm & ((1ull << lane) - 1))] = Gm | enc;
+            }
+        }
+    }
+    __syncthreads();
+    FB_T(1);
+
+    /* ---- stage 2a: Q -> zeroed score map; records -> pixel list */
+    const int nrec = misc[0];
+    bool dense = force_dense != 0;
+    if (!dense) {
+        for (int i = tid; i < FB_PX / 16; i += 256) reinterpret_cast<uint4*>(SC)[i] = make_uint4(0, 0, 0, 0);
+        for (int i0 = 0; i0 < nrec; i0 += 256) {
+            const int i = i0 + tid;
+            uint32_t Gm = 0;
+            int px0 = 0;
+            if (i < nrec) {
+                const uint32_t rec = REC[i];
+                Gm = rec & 0xf0f0f0f0u;
+                px0 = (int)((rec & 0xfu) | ((rec >> 4) & 0xf0u) | ((rec >> 8) & 0x300u)) << 4;
+            }
+            const int c = __popc(Gm);
+            const int incl = tb_wave_incl_scan_dpp(c);
+            const int tot = __builtin_amdgcn_readlane(incl, 63);
+            int wbase = 0;
+            if (lane == 0 && tot) wbase = atomicAdd(&misc[1], tot);
+            wbase = __builtin_amdgcn_readfirstlane(wbase);
+            if (wbase + tot <= FB_LIST_CAP) {
+                int slot = wbase + incl - c;
+                while (Gm) {
+                    const int bit = __ffs((int)Gm) - 1;
+                    Gm &= Gm - 1;
+                    LIST[slot++] = (uint16_t)(px0 + 4 * (7 - (bit & 7)) + (bit >> 3));
+                }
+            }
+        }
+    }
+    __syncthreads();
+    FB_T(2);
+
+    /* ---- stage 2b: exact scores, two pixels per lane, batches of 128 dealt to the wavefronts */
+    const int npx = misc[1];
+    dense = dense || npx > FB_LIST_CAP;
+    if (!dense) {
+        for (int base = 128 * wave; base < npx; base += 512) {
+            const int iA = base + lane, iB = iA + 64;
+            const bool vA = iA < npx, vB = iB < npx;
+            const int idxA = vA ? LIST[iA] : (3 * FB_S + 4), idxB = vB ? LIST[iB] : (3 * FB_S + 4);
+            const ft_s16x2 best = fb_score2(P + idxA, P + idxB);
+            const int sa = (int)best.x - 1, sb = (int)best.y - 1;
+            const bool cA = vA && sa >= init_th && sa > 0, cB = vB && sb >= init_th && sb > 0;
+            const unsigned long long mA = __ballot(cA), mB = __ballot(cB);
+            const int nA = __popcll(mA), nB = __popcll(mB);
+            if (nA + nB) {
+                int wbase = 0;
+                if (lane == 0) wbase = atomicAdd(&misc[2], nA + nB);
+                wbase = __builtin_amdgcn_readfirstlane(wbase);
+                if (wbase + nA + nB <= FB_CL_CAP) {
+                    const unsigned long long below = (1ull << lane) - 1;
+                    if (cA) { CL[wbase + __popcll(mA & below)] = (uint16_t)idxA; SC[idxA] = (uint8_t)min(sa, 255); }
+                    if (cB) { CL[wbase + nA + __popcll(mB & below)] = (uint16_t)idxB; SC[idxB] = (uint8_t)min(sb, 255); }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    FB_T(3);
+
+    /* ---- stage 3: NMS inside the cells; which cells keep a corner at initTh? */
+    const int ncl = misc[2];
+    dense = dense || ncl > FB_CL_CAP;
+    if (!dense) {
+        for (int i0 = 0; i0 < ncl; i0 += 256) {
+            const int i = i0 + tid;
+            int cellbit = 0;
+            if (i < ncl) {
+                int cell;
+                if (fb_nms_keep(SC, colinfo, rowinfo, CL[i], &cell)) cellbit = 1 << cell;
+                else CL[i] = 0xffff;
+            }
+            const int anyw = tb_wave_or_dpp(cellbit);
+            if (lane == 63 && anyw) atomicOr(&misc[3], anyw);
+        }
+    }
+    __syncthreads();
+    FB_T(4);
+
+    /* ---- retry at minTh, one wavefront per cell without a survivor */
+    int nAll = ncl;
+    if (!dense && min_th < init_th) {
+        const uint32_t rowm = (1u << blk.ncx) - 1u;
+        const uint32_t need = (rowm | (blk.ncy > 1 ? rowm << FB_MAX_CX : 0u)) & ~(uint32_t)misc[3];
+        if (need) {
+            uint16_t* const rl = LIST + wave * (FB_RETRY_CAP + 64);       /* the pixel list is dead by now */
+            int k = 0;
+            for (int cellId = 0; cellId < FB_MAX_CX * FB_MAX_CY; cellId++) {
+                if (!((need >> cellId) & 1u)) continue;
+                if ((k++ & 3) != wave) continue;
+                const int cx = cellId & (FB_MAX_CX - 1), cy = cellId / FB_MAX_CX;
+                const int X0 = scanX0 + cx * wCell, X1 = min(X0 + wCell, scanX1);
+                const int Y0 = 3 + cy * hCell, Y1 = min(Y0 + hCell, scanY1);
+                const int rowsStrip = max(FB_RETRY_CAP / max(X1 - X0, 1), 1);
+                for (int ys = Y0; ys < Y1; ys += rowsStrip) {
+                    int n = 0;
+                    const int ye = min(ys + rowsStrip, Y1);
+                    for (int y = ys; y < ye; y++)
+                        for (int xb = X0; xb < X1; xb += 64) {               /* cells are at most 59 px wide: one pass */
+                            const int x = xb + lane, idx = y * FB_S + x;
+                            const bool hit = x < X1 && fb_cardinal(P + idx, min_th);
+                            const unsigned long long bm = __ballot(hit);
+                            if (hit) rl[n + __popcll(bm & ((1ull << lane) - 1))] = (uint16_t)idx;
+                            n += __popcll(bm);
+                        }
+                    ft_lds_fence();
+                    for (int base = 0; base < n; base += 128) {
+                        const int iA = base + lane, iB = iA + 64;
+                        const bool vA = iA < n, vB = iB < n;
+                        const int idxA = vA ? rl[iA] : (3 * FB_S + 4), idxB = vB ? rl[iB] : (3 * FB_S + 4);
+                        const ft_s16x2 best = fb_score2(P + idxA, P + idxB);
+                        const int sa = (int)best.x - 1, sb = (int)best.y - 1;
+                        /* corners at minTh that pass 1 has not listed already */
+                        const bool cA = vA && sa >= min_th && sa > 0 && sa < init_th, cB = vB && sb >= min_th && sb > 0 && sb < init_th;
+                        const unsigned long long mA = __ballot(cA), mB = __ballot(cB);
+                        const int nA = __popcll(mA), nB = __popcll(mB);
+                        if (nA + nB) {
+                            int wbase = 0;
+                            if (lane == 0) wbase = atomicAdd(&misc[2], nA + nB);
+                            wbase = __builtin_amdgcn_readfirstlane(wbase);
+                            if (wbase + nA + nB <= FB_CL_CAP) {
+                                const unsigned long long below = (1ull << lane) - 1;
+                                if (cA) { CL[wbase + __popcll(mA & below)] = (uint16_t)idxA; SC[idxA] = (uint8_t)sa; }
+                                if (cB) { CL[wbase + nA + __popcll(mB & below)] = (uint16_t)idxB; SC[idxB] = (uint8_t)sb; }
+                            }
+                        }
+                    }
+                    ft_lds_fence();
+                }
+            }
+            __syncthreads();
+            nAll = misc[2];
+            dense = nAll > FB_CL_CAP;
+            if (!dense) {
+                for (int i = ncl + tid; i < nAll; i += 256) {
+                    int cell;
+                    if (!fb_nms_keep(SC, colinfo, rowinfo, CL[i], &cell)) CL[i] = 0xffff;
+                }
+            }
+            __syncthreads();
+        }
+    }
+    FB_T(5);
+
+#ifdef FB_TIMING
+    if (dense && tid == 0) { atomicAdd(&fb_times[14], 1ull); atomicMax(&fb_times[15], (unsigned long long)npx); atomicMax(&fb_times[13], (unsigned long long)nrec); atomicMax(&fb_times[7], (unsigned long long)ncl); }
+#endif
+    if (dense) {   /* block-uniform: every operand of the decision came out of LDS behind a barrier */
+        fb_dense(P, SC, colinfo, rowinfo, G, init_th, min_th, count, out, candCap);
+        return;
+    }
+
+    /* ---- emit: every wavefront its share of the list, one global atomic each */
+    {
+        int mine = 0;
+        for (int i0 = 64 * wave; i0 < nAll; i0 += 256) {
+            const int i = i0 + lane;
+            mine += __popcll(__ballot(i < nAll && CL[i] != 0xffff));
+        }
+        if (mine) {
+            int wbase = 0;
+            if (lane == 0) wbase = atomicAdd(count, mine);
+            wbase = __builtin_amdgcn_readfirstlane(wbase);
+            for (int i0 = 64 * wave; i0 < nAll; i0 += 256) {
+                const int i = i0 + lane;
+                const int idx = i < nAll ? CL[i] : 0xffff;
+                const bool e = idx != 0xffff;
+                const unsigned long long m = __ballot(e);
+                if (e) {
+                    const int slot = wbase + __popcll(m & ((1ull << lane) - 1));
+                    if (slot < candCap) out[slot] = fb_record(SC, G, idx);
+                }
+                wbase += __popcll(m);
+            }
+        }
+    }
+    FB_T(6);
+#ifdef FB_TIMING
+    if (tid == 0 && (bid & 63) == 0) {
+        for (int i = 0; i < 7; i++) atomicAdd(&fb_times[i], dt_[i]);
+        atomicAdd(&fb_times[8], 1ull); atomicAdd(&fb_times[9], (unsigned long long)nrec); atomicAdd(&fb_times[10], (unsigned long long)npx);
+        atomicAdd(&fb_times[11], (unsigned long long)ncl); atomicAdd(&fb_times[12], (unsigned long long)(nAll - ncl));
+    }
+#endif
 }
 
 int tbk_fast_cells(tb_extractor* ex, int n, int init_th, int min_th) {
     tb_ctx* ctx = ex->ctx;
     TB_HIP(ctx, hipMemsetAsync(ex->d_candCount, 0, sizeof(int32_t) * TB_MAX_LEVELS * n, ctx->stream));
-    if (ex->nCellsTotal == 0) return TB_OK;
-    FastCellsArgs A;
-    A.nCells = ex->nCellsTotal;
-    A.tileStride = (ex->maxRoiW + 3 + 3 + 4) & ~3; /* ROI + alignment slack, multiple of 4 */
-    A.tileRows = ex->maxRoiH;
-    A.listCap = (ex->maxRoiW - 6) * (ex->maxRoiH - 6);
-    if (A.listCap < 64) A.listCap = 64;
-    dim3 grid((ex->nCellsTotal + 3) / 4, n);
-    void (*kern)(PlanGeom, const uint8_t*, const CellDesc*, uint32_t*, int32_t*, int, int, FastCellsArgs) = k_fast_cells<0>;
-    if (A.tileStride <= 44) { A.tileStride = 44; kern = k_fast_cells<44>; }
-    else if (A.tileStride <= 48) { A.tileStride = 48; kern = k_fast_cells<48>; }
-    else if (A.tileStride <= 56) { A.tileStride = 56; kern = k_fast_cells<56>; }
-    else if (A.tileStride <= 76) { A.tileStride = 76; kern = k_fast_cells<76>; }
-    A.waveBytes = (2 * A.tileStride * A.tileRows + 2 * A.listCap + 15) & ~15;
-    const size_t lds = 4 * (size_t)A.waveBytes;
-    TB_HIP(ctx, hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 1024));
+    if (ex->nBlocksTotal == 0) return TB_OK;
+    const int nb8 = (ex->nBlocksTotal + 7) / 8;
+    dim3 grid(8 * nb8, n);
+    static_assert(FB_LDS_BYTES - FB_PAD_LDS <= 32 * 1024, "five blocks per CU");
+    /* test hook: TB_FAST_DENSE=1 sends every block down the any-density path (same results, no lists) */
+    const char* fd_env = getenv("TB_FAST_DENSE");
+    const int force_dense = (fd_env && fd_env[0] == '1') ? 1 : 0;
     tb_prof_begin(ctx, "k_fast_cells");
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, ctx->stream, ex->g, ex->d_slab, ex->d_cells, ex->d_cand, ex->d_candCount,
-                       init_th, min_th, A);
+    hipLaunchKernelGGL(k_fast_blocks, grid, dim3(256), FB_LDS_BYTES, ctx->stream, ex->g, ex->d_slab, ex->d_blocks, ex->nBlocksTotal,
+                       nb8, ex->d_cand, ex->d_candCount, init_th, min_th, force_dense);
     tb_prof_end(ctx);
     TB_HIP(ctx, hipGetLastError());
     return TB_OK;

@@ -253,7 +253,7 @@ void tb_extractor_destroy(tb_extractor* ex) {
         it = (it->second == ex) ? ex->ctx->plans.erase(it) : std::next(it);
     hipSetDevice(ex->ctx->device);
     hipStreamSynchronize(ex->ctx->stream);
-    hipFree(ex->d_slab); hipFree(ex->d_img0_copy); hipFree(ex->d_cells);
+    hipFree(ex->d_slab); hipFree(ex->d_img0_copy); hipFree(ex->d_blocks);
     for (int l = 0; l < TB_MAX_LEVELS; l++) { hipFree(ex->d_rx[l]); hipFree(ex->d_ry[l]); }
     hipFree(ex->d_cand); hipFree(ex->d_candCount); hipFree(ex->d_knode); hipFree(ex->d_sel); hipFree(ex->d_selCount);
     hipFree(ex->d_kps); hipFree(ex->d_desc); hipFree(ex->d_counts); hipFree(ex->d_exit); hipFree(ex->d_enode);
@@ -292,7 +292,7 @@ int tb_extractor_create(tb_ctx* ctx, int width, int height, int nlevels, const f
     }
     int maxq[TB_MAX_LEVELS] = {0};
     if (nlevels >= 2) tb_orb_quotas(nlevels, sf, max_target, maxq);
-    std::vector<CellDesc> cells;
+    std::vector<FastBlock> blocks;
     size_t off = 0, candOff = 0;
     int selBase = 0;
     for (int l = 0; l < nlevels; l++) {
@@ -312,7 +312,7 @@ int tb_extractor_create(tb_ctx* ctx, int width, int height, int nlevels, const f
         const float fw = (float)(maxBX - minB), fh = (float)(maxBY - minB);
         L.nCols = (int)(fw / 30.f);
         L.nRows = (int)(fh / 30.f);
-        L.cellBase = (int)cells.size();
+        L.cellBase = 0;
         L.nCells = 0;
         L.nIni = 0;
         L.hX = 1.f;
@@ -320,27 +320,48 @@ int tb_extractor_create(tb_ctx* ctx, int width, int height, int nlevels, const f
         if (L.nCols >= 1 && L.nRows >= 1) {
             L.wCell = (int)ceilf(fw / (float)L.nCols);
             L.hCell = (int)ceilf(fh / (float)L.nRows);
+            /* The reference walks the cells one by one (ORBextractor.cpp:765-786) and skips those that start at or
+             * behind maxBorder - 3 (rows) / maxBorder - 6 (columns); what it does not skip but leaves without a scanned
+             * pixel (an ROI under 7 px) yields nothing either. The cells that DO scan are a prefix in both directions,
+             * and their scan regions tile [minB + 3, maxB - 3): count them, then cut the grid into blocks. */
+            int nRowsEff = 0, nColsEff = 0;
             for (int i = 0; i < L.nRows; i++) {
                 const float iniY = (float)minB + (float)i * (float)L.hCell;
-                float maxY = iniY + (float)L.hCell + 6.f;
                 if (iniY >= (float)maxBY - 3.f) continue;
-                if (maxY > (float)maxBY) maxY = (float)maxBY;
-                for (int j = 0; j < L.nCols; j++) {
-                    const float iniX = minB + (float)(j * L.wCell);
-                    float maxX = iniX + (float)L.wCell + 6.f;
-                    if (iniX >= (float)maxBX - 6.f) continue;
-                    if (maxX > (float)maxBX) maxX = (float)maxBX;
-                    CellDesc c;
-                    c.level = (int16_t)l; c.pad = 0;
-                    c.x0 = (int16_t)(int)iniX; c.y0 = (int16_t)(int)iniY;
-                    c.x1 = (int16_t)(int)maxX; c.y1 = (int16_t)(int)maxY;
-                    c.cellIdx = i * L.nCols + j;
-                    cells.push_back(c);
-                    L.nCells++;
-                    ex->maxRoiW = std::max(ex->maxRoiW, (int)(c.x1 - c.x0));
-                    ex->maxRoiH = std::max(ex->maxRoiH, (int)(c.y1 - c.y0));
-                }
+                if ((int)iniY + 3 < maxBY - 3) nRowsEff = i + 1;
             }
+            for (int j = 0; j < L.nCols; j++) {
+                const float iniX = minB + (float)(j * L.wCell);
+                if (iniX >= (float)maxBX - 6.f) continue;
+                if ((int)iniX + 3 < maxBX - 3) nColsEff = j + 1;
+            }
+            if (L.wCell + 6 + 15 > FB_S || L.hCell + 6 > FB_TH)
+                return tb_fail(ctx, TB_EUNSUPPORTED, "level %d: FAST cell %dx%d exceeds the LDS tile", l, L.wCell, L.hCell);
+            int bx = (FB_S - 6 - 15) / L.wCell, by = (FB_TH - 6) / L.hCell;
+            bx = std::min(std::max(bx, 1), FB_MAX_CX);
+            by = std::min(std::max(by, 1), FB_MAX_CY);
+            for (int i0 = 0; i0 < nRowsEff; i0 += by)
+                for (int j0 = 0; j0 < nColsEff; j0 += bx) {
+                    FastBlock b;
+                    b.level = (int16_t)l;
+                    b.ncx = (int16_t)std::min(bx, nColsEff - j0);
+                    b.ncy = (int16_t)std::min(by, nRowsEff - i0);
+                    b.x0 = (int16_t)(minB + j0 * L.wCell);
+                    b.y0 = (int16_t)(minB + i0 * L.hCell);
+                    b.x1 = (int16_t)std::min(minB + (j0 + b.ncx) * L.wCell + 6, maxBX);
+                    b.y1 = (int16_t)std::min(minB + (i0 + b.ncy) * L.hCell + 6, maxBY);
+                    {   /* stage-1 lane map: the tile's column 0 is image column x0 & ~15 */
+                        const int cx0 = b.x0 & 15, rw = b.x1 - b.x0, rh = b.y1 - b.y0;
+                        const int scanX0 = cx0 + 3, scanX1 = cx0 + rw - 3;
+                        b.sA = (int16_t)(scanX0 >> 4);
+                        b.nss = (int16_t)(((scanX1 - 1) >> 4) - b.sA + 1);
+                        b.rowsPer = (int16_t)(64 / b.nss);
+                        b.nPass = (int16_t)((rh - 6 + b.rowsPer - 1) / b.rowsPer);
+                        b.invNss = (uint16_t)((32768 + b.nss - 1) / b.nss);
+                    }
+                    blocks.push_back(b);
+                }
+            L.nCells = nRowsEff * nColsEff;
             /* DistributeOctTree, ORBextractor.cpp:498-500 (nIni < 1 clamped, see k_octree.hip) */
             int nIni = (int)roundf((float)(maxBX - minB) / (maxBY - minB));
             if (nIni < 1) nIni = 1;
@@ -359,14 +380,14 @@ int tb_extractor_create(tb_ctx* ctx, int width, int height, int nlevels, const f
     g.slabBytes = off;
     g.candPerImage = candOff;
     g.selCap = std::max(std::max(selBase, fastgrid_ncell(width, height, max_target)), 64);
-    ex->nCellsTotal = (int)cells.size();
+    ex->nBlocksTotal = (int)blocks.size();
 
     const size_t B = (size_t)max_images;
     TB_HIP(ctx, hipMalloc(&ex->d_slab, B * g.slabBytes));
     TB_HIP(ctx, hipMemsetAsync(ex->d_slab, 0, B * g.slabBytes, ctx->stream));
-    if (!cells.empty()) {
-        TB_HIP(ctx, hipMalloc(&ex->d_cells, cells.size() * sizeof(CellDesc)));
-        TB_HIP(ctx, hipMemcpy(ex->d_cells, cells.data(), cells.size() * sizeof(CellDesc), hipMemcpyHostToDevice));
+    if (!blocks.empty()) {
+        TB_HIP(ctx, hipMalloc(&ex->d_blocks, blocks.size() * sizeof(FastBlock)));
+        TB_HIP(ctx, hipMemcpy(ex->d_blocks, blocks.data(), blocks.size() * sizeof(FastBlock), hipMemcpyHostToDevice));
     }
     for (int l = 1; l < nlevels; l++) {
         std::vector<ResizeX> rx;

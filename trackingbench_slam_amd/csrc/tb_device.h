@@ -30,6 +30,29 @@ __device__ __forceinline__ int tb_wave_incl_scan(int v) {
     return v;
 }
 
+/* inclusive wave scan (sum) on the DPP path: Hillis-Steele inside every row of 16 lanes (row_shr 1, 2, 4, 8; lanes
+ * shifted in from outside the row read 0), then the row totals travel down with row_bcast 15 / 31. Six vector adds, no
+ * LDS round trips; lane 63 ends up with the wave total. */
+__device__ __forceinline__ int tb_wave_incl_scan_dpp(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false); /* row_shr:1 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false); /* row_shr:2 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false); /* row_shr:4 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false); /* row_shr:8 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false); /* row_bcast:15 into rows 1, 3 */
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false); /* row_bcast:31 into rows 2, 3 */
+    return v;
+}
+/* bitwise OR over the wave, result in lane 63 (same network) */
+__device__ __forceinline__ int tb_wave_or_dpp(int v) {
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);
+    v |= __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);
+    return v;
+}
+
 __device__ __forceinline__ int tb_wave_sum(int v) {
 #pragma unroll
     for (int d = TB_WAVE / 2; d > 0; d >>= 1) v += __shfl_xor(v, d, TB_WAVE);

@@ -96,13 +96,22 @@ struct PlanGeom {
     LevelGeom lv[TB_MAX_LEVELS];
 };
 
-/* One FAST work item: a region of one level whose pixels are scored and non-max suppressed. */
-struct CellDesc {
+/* One FAST work item (k_fast_blocks): a block of ncx x ncy adjacent 30-px cells of one level, staged in LDS once.
+ * The ROI is the union of the cells' cv::FAST ROIs (ORBextractor.cpp:765-786): cell (i, j) of the block scans columns
+ * [x0 + 3 + j wCell, min(x0 + 3 + (j + 1) wCell, x1 - 3)) and rows likewise -- the cells' scan regions tile the ROI's. */
+struct FastBlock {
     int16_t level;
-    int16_t pad;
+    int16_t ncx, ncy;       /* cells of this block (<= FB_MAX_CX x FB_MAX_CY) */
+    int16_t sA;             /* stage-1 lane map, fixed per block (host arithmetic, k_fast.hip): first 16-byte tile segment */
     int16_t x0, y0, x1, y1; /* ROI in absolute level coordinates, [x0,x1) x [y0,y1) */
-    int32_t cellIdx;        /* row-major index in the level's grid (ordering key) */
+    int16_t nss, rowsPer;   /*   that holds scanned columns, number of such segments, rows per 64-lane pass = 64 / nss, */
+    int16_t nPass;          /*   passes over the scanned rows, */
+    uint16_t invNss;        /*   ceil(32768 / nss): lane / nss == (lane * invNss) >> 15 for lane < 64 */
 };
+#define FB_S 160            /* LDS row stride of a block tile (bytes, 10 x 16) */
+#define FB_TH 68            /* tile rows */
+#define FB_MAX_CX 4
+#define FB_MAX_CY 2
 
 /* resize tables, built on the host with the oracle-identical double/float arithmetic */
 struct ResizeX { int16_t sx, sx1, a0, a1; };
@@ -120,8 +129,7 @@ struct tb_extractor {
     /* device memory */
     uint8_t* d_slab = nullptr;          /* [max_images][slabBytes] */
     uint8_t* d_img0_copy = nullptr;     /* [max_images][h][stride0] for host-provided frames */
-    CellDesc* d_cells = nullptr; int nCellsTotal = 0;
-    int maxRoiW = 7, maxRoiH = 7;        /* largest FAST cell ROI of the plan */
+    FastBlock* d_blocks = nullptr; int nBlocksTotal = 0;   /* FAST work items of one image, level-major */
     ResizeX* d_rx[TB_MAX_LEVELS]; ResizeY* d_ry[TB_MAX_LEVELS];
     uint32_t* d_cand = nullptr;         /* [max_images][candPerImage] packed score<<24|y<<12|x */
     int32_t* d_candCount = nullptr;     /* [max_images][TB_MAX_LEVELS] */
