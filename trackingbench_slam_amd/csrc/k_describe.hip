@@ -18,15 +18,43 @@
 #include "tb_internal.h"
 #include "tb_device.h"
 
-__constant__ int8_t c_pattern[1024] = {
+/* bit_pattern_31_ (ORBextractor.cpp:90-348) as floats, four per test (x0, y0, x1, y1): one 16-byte load per lane */
+struct DsPattern { float v[1024]; };
+constexpr DsPattern ds_make_pattern() {
+    constexpr int8_t raw[1024] = {
 #include "orb_pattern.inc"
-};
+    };
+    DsPattern p{};
+    for (int i = 0; i < 1024; i++) p.v[i] = (float)raw[i];
+    return p;
+}
+__constant__ __attribute__((aligned(16))) DsPattern c_patternf = ds_make_pattern();
+
+/* IC_Angle disc (umax[] of ORBextractor.cpp:389-404 = 15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3) as byte weights for
+ * v_dot4_u32_u8: row |v| of the disc spans u in [-umax, umax]; byte i of the 32 bytes that start at u = -15 weighs
+ * 1 (sum of intensities) and u + 16 (first moment, biased to stay unsigned) inside the disc, 0 outside. */
+struct DsDisc { uint32_t w1[16][8], wu[16][8]; };
+constexpr DsDisc ds_make_disc() {
+    constexpr int umax[16] = {15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3};
+    DsDisc d{};
+    for (int av = 0; av < 16; av++)
+        for (int i = 0; i < 32; i++) {
+            const int u = i - 15;
+            const bool in = (u >= -umax[av]) && (u <= umax[av]);
+            d.w1[av][i >> 2] |= (uint32_t)(in ? 1 : 0) << (8 * (i & 3));
+            d.wu[av][i >> 2] |= (uint32_t)(in ? (u + 16) : 0) << (8 * (i & 3));
+        }
+    return d;
+}
+__constant__ __attribute__((aligned(16))) DsDisc c_disc = ds_make_disc();
 
 #define DS_P 45      /* source patch edge */
 #define DS_PS 52     /* source patch row stride: 13 dwords (odd) -> one-row-per-lane accesses hit distinct banks */
 #define DS_B 39      /* blurred patch edge */
 #define DS_HS 42     /* h-pass row stride in u16 (21 dwords, odd) */
 #define DS_BS 40     /* blurred patch row stride */
+
+typedef unsigned short ds_u16x2 __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ int ds_reflect(int i, int n) {
     /* BORDER_REFLECT_101; n >= 2 and |overshoot| < n for every level that can hold a keypoint */
@@ -35,16 +63,56 @@ __device__ __forceinline__ int ds_reflect(int i, int n) {
     return i;
 }
 
-__device__ __forceinline__ int ds_byte(const uint32_t* w, int i) { /* byte i of a register array, i compile-time */
-    return (int)((w[i >> 2] >> (8 * (i & 3))) & 0xffu);
+/* four bytes of a register array starting at byte o (compile-time o) */
+__device__ __forceinline__ uint32_t ds_window(const uint32_t* w, int o) {
+    return (o & 3) ? __builtin_amdgcn_alignbyte(w[(o >> 2) + 1], w[o >> 2], o & 3) : w[o >> 2];
 }
 
-/* Instruction budget per keypoint (one wavefront), the quantity this kernel is bound by:
+__device__ __forceinline__ uint32_t ds_udot2(uint32_t a, uint32_t b, uint32_t c) {
+    return __builtin_amdgcn_udot2(__builtin_bit_cast(ds_u16x2, a), __builtin_bit_cast(ds_u16x2, b), c, false);
+}
+
+/* horizontal 7-tap pass of one patch row held in 13 dwords, patch column 0 at byte SH: 39 exact u16 sums
+ * (18,34,49,55,49,34,18; at most 255 * 257 = 65535) as two v_dot4_u32_u8 each */
+template <int SH>
+__device__ __forceinline__ void ds_hrow(const uint32_t* w, unsigned short* out) {
+    constexpr uint32_t K1 = 18u | (34u << 8) | (49u << 16) | (55u << 24), K2 = 49u | (34u << 8) | (18u << 16);
+    uint32_t a[DS_B + 1];
+#pragma unroll
+    for (int c = 0; c < DS_B; c++)
+        a[c] = __builtin_amdgcn_udot4(ds_window(w, c + SH + 4), K2, __builtin_amdgcn_udot4(ds_window(w, c + SH), K1, 0u, false), false);
+    a[DS_B] = 0;
+#pragma unroll
+    for (int c = 0; c < DS_B; c += 2) *reinterpret_cast<uint32_t*>(out + c) = a[c] | (a[c + 1] << 16);
+}
+
+/* vertical 7-tap pass of N outputs of one column: h[i] = u16 sums of rows r0 + i (N + 6 of them), exact 32-bit
+ * accumulation as three v_dot2_u32_u16 and one multiply-add, (acc + 2^15) >> 16 saturated (the kernel sums to 257) */
+template <int N>
+__device__ __forceinline__ void ds_vcol(const uint32_t* h, uint8_t* out, int rows_left) {
+    constexpr uint32_t KA = 18u | (34u << 16), KB = 49u | (55u << 16), KC = 49u | (34u << 16);
+    uint32_t pr[N + 5];
+#pragma unroll
+    for (int i = 0; i < N + 5; i++) pr[i] = h[i] | (h[i + 1] << 16);
+#pragma unroll
+    for (int j = 0; j < N; j++) {
+        uint32_t acc = 18u * h[j + 6] + (1u << 15);
+        acc = ds_udot2(pr[j], KA, acc);
+        acc = ds_udot2(pr[j + 2], KB, acc);
+        acc = ds_udot2(pr[j + 4], KC, acc);
+        if (j < rows_left) out[j * DS_BS] = (uint8_t)min(acc >> 16, 255u);
+    }
+}
+
+/* Instruction budget per keypoint (one wavefront), the quantity this kernel is bound by (~1080 vector instructions in
+ * round 1, blur passes 51 % of them on 45 / 39 of the 64 lanes):
  *   staging   interior keypoints copy 45 rows as 13 aligned dwords each (the sub-dword phase of the patch is
  *             kept as a column shift), border keypoints take the per-byte reflect-101 path;
- *   moments   one lane per disc row pair, bytes unpacked from dword LDS reads;
- *   h-pass    one lane per patch ROW: 13 dword reads, 39 sliding-window outputs, fully unrolled;
- *   v-pass    one lane per patch COLUMN: 45 u16 reads, 39 sliding-window outputs, fully unrolled;
+ *   moments   one lane per disc row: eight 4-byte windows against the disc's weight table, 16 v_dot4_u32_u8;
+ *   h-pass    one lane per patch ROW: 13 dword reads, 39 outputs of two v_dot4_u32_u8 each (4 multiply-adds per
+ *             instruction on the packed bytes), fully unrolled;
+ *   v-pass    the 39 x 39 outputs over ALL lanes: columns 0-31 as two half columns of 20 rows per lane, then columns
+ *             32-38 as eight 5-row pieces; u16 inputs, three v_dot2_u32_u16 + one multiply-add per output;
  *   tests     4 x 64 rotated comparisons -> 4 ballots. */
 __global__ void __launch_bounds__(64)
 k_describe(PlanGeom g, const uint8_t* __restrict__ slab, const uint32_t* __restrict__ sel,
@@ -80,7 +148,7 @@ k_describe(PlanGeom g, const uint8_t* __restrict__ slab, const uint32_t* __restr
                           ((reinterpret_cast<uintptr_t>(img) & 3) == 0) && ((x0 & ~3) + 52 <= stride);
     const int sh = interior ? (x0 & 3) : 0;
     if (interior) {
-        const int rr = lane / 13, dd = lane - rr * 13; /* 4 rows x 13 dwords per pass, lanes 52..63 idle */
+        const int rr = (lane * 5042) >> 16, dd = lane - rr * 13; /* lane / 13: 4 rows x 13 dwords per pass, lanes 52..63 idle */
         const uint8_t* srcp = img + (size_t)y0 * stride + (x0 & ~3) + 4 * dd;
         uint32_t v[12];
 #pragma unroll
@@ -103,67 +171,63 @@ k_describe(PlanGeom g, const uint8_t* __restrict__ slab, const uint32_t* __restr
     }
     __syncthreads();
 
-    /* 2. IC_Angle: integer moments over the radius-15 disc; lane = (row v, half): 62 lanes active */
+    /* 2. IC_Angle: integer moments over the radius-15 disc, lane = disc row v = lane - 15 */
     int m10 = 0, m01 = 0;
-    {
-        const int v = (lane >> 1) - 15, half = lane & 1; /* half 0: u in [-15,-1], half 1: u in [0,15] */
-        if (lane < 62) {
-            const int av = v < 0 ? -v : v;
-            /* umax[] of ORBextractor.cpp:389-404 = 15,15,15,15,14,14,14,13,13,12,11,10,9,8,6,3 */
-            const unsigned long long UM = 0x3689ABCDDEEEFFFFull; /* nibble av = umax[av] */
-            const int um = (int)((UM >> (4 * av)) & 0xf);
-            const uint8_t* row = src + (22 + v) * DS_PS + 22 + sh;
-            int sI = 0, sU = 0;
+    if (lane < 31) {
+        const int v = lane - 15, av = v < 0 ? -v : v;
+        const int o = 7 + sh;                                  /* byte of u = -15 in the row (patch column 22 - 15) */
+        const uint32_t* rw = reinterpret_cast<const uint32_t*>(src + (22 + v) * DS_PS) + (o >> 2);
+        const uint4* t1 = reinterpret_cast<const uint4*>(c_disc.w1[av]);
+        const uint4* tu = reinterpret_cast<const uint4*>(c_disc.wu[av]);
+        const uint4 a0 = t1[0], a1 = t1[1], u0 = tu[0], u1 = tu[1];
+        const uint32_t w1[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+        const uint32_t wu[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+        uint32_t w[9];
 #pragma unroll
-            for (int k = 0; k < 16; k++) {
-                const int u = half ? k : -(k + 1);
-                const int au = half ? k : k + 1;
-                if (au <= um && au <= 15) {
-                    const int I = row[u];
-                    sI += I;
-                    sU += u * I;
-                }
-            }
-            m10 = sU;
-            m01 = v * sI;
+        for (int k = 0; k < 9; k++) w[k] = rw[k];
+        uint32_t sI = 0, sW = 0;
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t X = __builtin_amdgcn_alignbyte(w[k + 1], w[k], (uint32_t)(o & 3));
+            sI = __builtin_amdgcn_udot4(X, w1[k], sI, false);
+            sW = __builtin_amdgcn_udot4(X, wu[k], sW, false);
         }
+        m10 = (int)sW - 16 * (int)sI;    /* sum u I = sum (u + 16) I - 16 sum I */
+        m01 = v * (int)sI;
     }
-    m10 = tb_wave_sum(m10);
-    m01 = tb_wave_sum(m01);
+    m10 = __builtin_amdgcn_readlane(tb_wave_incl_scan_dpp(m10), 63);
+    m01 = __builtin_amdgcn_readlane(tb_wave_incl_scan_dpp(m01), 63);
     const float angle = tbm::fast_atan2((float)m01, (float)m10);
 
     /* 3a. horizontal 7-tap pass, one lane per patch row (exact integers, u16 result) */
     if (lane < DS_P) {
         const uint32_t* rw = reinterpret_cast<const uint32_t*>(src + lane * DS_PS);
-        uint32_t w[13];
+        uint32_t w[14];
 #pragma unroll
         for (int j = 0; j < 13; j++) w[j] = rw[j];
-        /* fold the sub-dword phase away: four code paths with compile-time byte indices */
+        w[13] = 0;
         unsigned short* out = hp + lane * DS_HS;
-#define DS_HROW(SH)                                                                                                  \
-    _Pragma("unroll") for (int c = 0; c < DS_B; c += 2) {                                                            \
-        const int a0 = 18 * (ds_byte(w, c + SH) + ds_byte(w, c + 6 + SH)) + 34 * (ds_byte(w, c + 1 + SH) + ds_byte(w, c + 5 + SH)) + \
-                       49 * (ds_byte(w, c + 2 + SH) + ds_byte(w, c + 4 + SH)) + 55 * ds_byte(w, c + 3 + SH);                          \
-        int a1 = 0;                                                                                                  \
-        if (c + 1 < DS_B)                                                                                            \
-            a1 = 18 * (ds_byte(w, c + 1 + SH) + ds_byte(w, c + 7 + SH)) + 34 * (ds_byte(w, c + 2 + SH) + ds_byte(w, c + 6 + SH)) +   \
-                 49 * (ds_byte(w, c + 3 + SH) + ds_byte(w, c + 5 + SH)) + 55 * ds_byte(w, c + 4 + SH);                                \
-        *reinterpret_cast<uint32_t*>(out + c) = (uint32_t)a0 | ((uint32_t)a1 << 16);                                 \
-    }
-        if (sh == 0) { DS_HROW(0) } else if (sh == 1) { DS_HROW(1) } else if (sh == 2) { DS_HROW(2) } else { DS_HROW(3) }
-#undef DS_HROW
+        /* the sub-dword phase of the patch: four code paths with compile-time byte offsets */
+        if (sh == 0) ds_hrow<0>(w, out); else if (sh == 1) ds_hrow<1>(w, out); else if (sh == 2) ds_hrow<2>(w, out); else ds_hrow<3>(w, out);
     }
     __syncthreads();
-    /* 3b. vertical pass, one lane per patch column */
-    if (lane < DS_B) {
-        int h[DS_P];
+    /* 3b. vertical pass over all 64 lanes */
+    {
+        /* columns 0..31: lane = (column, upper / lower half): rows [0, 20) and [20, 39) */
+        const int c = lane & 31, r0 = 20 * (lane >> 5);
+        uint32_t h[26];
 #pragma unroll
-        for (int r = 0; r < DS_P; r++) h[r] = hp[r * DS_HS + lane];
+        for (int i = 0; i < 26; i++) h[i] = hp[min(r0 + i, DS_P - 1) * DS_HS + c];
+        ds_vcol<20>(h, bl + r0 * DS_BS + c, DS_B - r0);
+    }
+    {
+        /* columns 32..38: lane = (column, one of eight 5-row pieces) */
+        const int cc = lane & 7, r0 = 5 * (lane >> 3);
+        const int c = 32 + min(cc, 6);
+        uint32_t h[11];
 #pragma unroll
-        for (int r = 0; r < DS_B; r++) {
-            const int acc = 18 * (h[r] + h[r + 6]) + 34 * (h[r + 1] + h[r + 5]) + 49 * (h[r + 2] + h[r + 4]) + 55 * h[r + 3];
-            bl[r * DS_BS + lane] = (uint8_t)min((acc + (1 << 15)) >> 16, 255);
-        }
+        for (int i = 0; i < 11; i++) h[i] = hp[min(r0 + i, DS_P - 1) * DS_HS + c];
+        ds_vcol<5>(h, bl + r0 * DS_BS + c, cc < 7 ? DS_B - r0 : 0);
     }
     __syncthreads();
 
@@ -174,11 +238,11 @@ k_describe(PlanGeom g, const uint8_t* __restrict__ slab, const uint32_t* __restr
     const uint8_t* center = bl + 19 * DS_BS + 19;
     const size_t out = (size_t)b * g.selCap + base + idx;
     unsigned long long* d64 = reinterpret_cast<unsigned long long*>(desc + out * 32);
+    const float4* pat = reinterpret_cast<const float4*>(c_patternf.v);
 #pragma unroll
     for (int j = 0; j < 4; j++) {
-        const int t = j * 64 + lane;
-        const float x0f = (float)c_pattern[4 * t], y0f = (float)c_pattern[4 * t + 1];
-        const float x1f = (float)c_pattern[4 * t + 2], y1f = (float)c_pattern[4 * t + 3];
+        const float4 pt = pat[j * 64 + lane];
+        const float x0f = pt.x, y0f = pt.y, x1f = pt.z, y1f = pt.w;
         const int r0 = tbm::cv_round(TB_FADD(TB_FMUL(x0f, bsin), TB_FMUL(y0f, a)));
         const int c0 = tbm::cv_round(TB_FSUB(TB_FMUL(x0f, a), TB_FMUL(y0f, bsin)));
         const int r1 = tbm::cv_round(TB_FADD(TB_FMUL(x1f, bsin), TB_FMUL(y1f, a)));
