@@ -44,3 +44,13 @@ if hasattr(capi.lib(), "tb_debug_fast_times"):
     print("  dense blocks (all, not sampled): %d; max records %d, max pixels %d, max corners %d among them" % (buf[14], buf[13], buf[15], buf[7]))
     print("  blocks %d, per block: records %.1f, pixels %.1f, corners %.1f, retry corners %.1f, retry cells %.3f"
           % (nb, buf[9] / nb, buf[10] / nb, buf[11] / nb, buf[12] / nb, buf[13] / nb))
+
+if hasattr(capi.lib(), "tb_debug_octree_times"):
+    buf = (C.c_ulonglong * 64)()
+    capi.lib().tb_debug_octree_times(buf, 1)
+    p.ex.orb(2 * F, 2000, 80.0, 30.0)
+    torch.cuda.synchronize()
+    capi.lib().tb_debug_octree_times(buf, 1)
+    for l in range(8):
+        nb = max(buf[16 + l], 1)
+        print("  octree level %d: %8.0f clk/block, %6.0f candidates/block, %d blocks" % (l, buf[l] / nb, buf[32 + l] / nb, buf[16 + l]))

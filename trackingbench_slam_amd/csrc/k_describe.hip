@@ -89,7 +89,7 @@ __device__ __forceinline__ void ds_hrow(const uint32_t* w, unsigned short* out) 
 /* vertical 7-tap pass of N outputs of one column: h[i] = u16 sums of rows r0 + i (N + 6 of them), exact 32-bit
  * accumulation as three v_dot2_u32_u16 and one multiply-add, (acc + 2^15) >> 16 saturated (the kernel sums to 257) */
 template <int N>
-__device__ __forceinline__ void ds_vcol(const uint32_t* h, uint8_t* out, int rows_left) {
+__device__ __forceinline__ void ds_vcol(const uint32_t* h, uint8_t* out) {
     constexpr uint32_t KA = 18u | (34u << 16), KB = 49u | (55u << 16), KC = 49u | (34u << 16);
     uint32_t pr[N + 5];
 #pragma unroll
@@ -100,7 +100,7 @@ __device__ __forceinline__ void ds_vcol(const uint32_t* h, uint8_t* out, int row
         acc = ds_udot2(pr[j], KA, acc);
         acc = ds_udot2(pr[j + 2], KB, acc);
         acc = ds_udot2(pr[j + 4], KC, acc);
-        if (j < rows_left) out[j * DS_BS] = (uint8_t)min(acc >> 16, 255u);
+        out[j * DS_BS] = (uint8_t)min(acc >> 16, 255u);   /* rows past the patch land in the spare row of bl[] */
     }
 }
 
@@ -120,7 +120,7 @@ k_describe(PlanGeom g, const uint8_t* __restrict__ slab, const uint32_t* __restr
            int32_t* __restrict__ counts) {
     __shared__ __attribute__((aligned(16))) uint8_t src[DS_P * DS_PS + 16];
     __shared__ __attribute__((aligned(16))) unsigned short hp[DS_P * DS_HS];
-    __shared__ __attribute__((aligned(16))) uint8_t bl[DS_B * DS_BS];
+    __shared__ __attribute__((aligned(16))) uint8_t bl[(DS_B + 1) * DS_BS];   /* + one spare row: the v-pass stores unconditionally */
     const int b = blockIdx.y, slot = blockIdx.x, lane = threadIdx.x;
     const int32_t* sc = selCount + b * TB_MAX_LEVELS;
     /* slot -> (level, index), level-major output base */
@@ -218,7 +218,7 @@ k_describe(PlanGeom g, const uint8_t* __restrict__ slab, const uint32_t* __restr
         uint32_t h[26];
 #pragma unroll
         for (int i = 0; i < 26; i++) h[i] = hp[min(r0 + i, DS_P - 1) * DS_HS + c];
-        ds_vcol<20>(h, bl + r0 * DS_BS + c, DS_B - r0);
+        ds_vcol<20>(h, bl + r0 * DS_BS + c);          /* the lower half's 20th output is row 39: the spare row */
     }
     {
         /* columns 32..38: lane = (column, one of eight 5-row pieces) */
@@ -227,7 +227,7 @@ k_describe(PlanGeom g, const uint8_t* __restrict__ slab, const uint32_t* __restr
         uint32_t h[11];
 #pragma unroll
         for (int i = 0; i < 11; i++) h[i] = hp[min(r0 + i, DS_P - 1) * DS_HS + c];
-        ds_vcol<5>(h, bl + r0 * DS_BS + c, cc < 7 ? DS_B - r0 : 0);
+        ds_vcol<5>(h, bl + r0 * DS_BS + c);           /* lanes with cc == 7 repeat column 38 (same values); rows reach 39 at most */
     }
     __syncthreads();
 
