@@ -1,6 +1,5 @@
 /* Header shim: TRACKING_BENCH::LocalBA with the reference's signatures (reference
- * include/mapping/LocalBA.h:11-25) on the C ABI (tb_pose_opt). AddMapPointsByStereo (LK optical flow)
- * is outside the hot-path scope and throws. */
+ * include/mapping/LocalBA.h:11-25) on the C ABI (tb_pose_opt, tb_add_map_points_by_stereo). */
 #ifndef TRACKING_BENCH_LOCAL_BA_H
 #define TRACKING_BENCH_LOCAL_BA_H
 #include <memory>

@@ -66,9 +66,8 @@ namespace TRACKING_BENCH
                 const std::shared_ptr<Map>& map,
                 const std::shared_ptr<Frame>& F1, float r);
 
-        // Optical flow (reference :96-103, matcher.cpp:724-768). reject (rejectWithF: RANSAC fundamental matrix) is not
-        // built: passing true throws std::invalid_argument -- the reference's caller (LocalBA::AddMapPointsByStereo,
-        // LocalBA.cpp:54) passes it, see INTEGRATION.md.
+        // Optical flow (reference :96-103, matcher.cpp:724-768). reject = true runs rejectWithF (below) before the matches
+        // are listed, as the reference's caller LocalBA::AddMapPointsByStereo (LocalBA.cpp:54) asks.
         std::vector<cv::DMatch> searchByOPFlow(
                 const std::shared_ptr<Frame>& F1,
                 const std::shared_ptr<Frame>& F2,
@@ -76,6 +75,10 @@ namespace TRACKING_BENCH
                 bool equalized,
                 bool reject,
                 bool MapPointOnly = false);
+
+        // reference :155, matcher.cpp:853-881: cv::findFundamentalMat(FM_RANSAC, 1.0, 0.99) clears the flags of the outliers
+        // (a private member there; public here so that a caller can reach it through the class as well)
+        void rejectWithF(std::vector<cv::Point2f>& pts1, const std::vector<cv::Point2f>& pts2, std::vector<uchar>& status);
 
         static int DescriptorDistance(const cv::Mat& a, const cv::Mat& b);
         static void ComputeThreeMaxima(std::vector<int>* histo, const int L, int &ind1, int &ind2, int &ind3);

@@ -212,8 +212,8 @@ int tb_pose_opt_batch_dev(tb_ctx* ctx, int nproblems, const double K[4], const f
  * tracks F2's keys (keys2_xy) from img2 into img1, clears the points that leave F1's frame (cam1->width / height,
  * CameraModel.h:33-39) and returns DMatch(i, i) records (distance FLT_MAX, imgIdx -1, as a default-constructed
  * cv::DMatch). equalized != 0: img1 goes through tb_clahe(3.0, 8 x 8) first (F1->Equalize(), matcher.cpp:736-739).
- * reject (rejectWithF = cv::findFundamentalMat RANSAC, needs cv::RNG and the 7-point solver) is NOT built: non-zero
- * gives TB_EUNSUPPORTED. cur_points: n (x, y) pairs out. */
+ * reject != 0: Matcher::rejectWithF (matcher.cpp:853-881) = cv::findFundamentalMat(FM_RANSAC, 1.0, 0.99) clears the
+ * flags of the epipolar outliers before the matches are listed (tb_reject_with_f below). cur_points: n (x, y) pairs out. */
 /* Frame::Equalize, Frame.cpp:453-458: cv::createCLAHE(clip_limit = 3.0, Size(tiles_x, tiles_y) = 8 x 8)->apply(src, dst)
  * (OpenCV 3.3 routine restated, parity unpinned). Host pointers; dst has the size of src. tb_clahe_dev: device pointers,
  * asynchronous on the context's stream. */
@@ -246,6 +246,33 @@ int tb_optical_flow_pyr_lk_dev(tb_ctx* ctx, const uint8_t* prev, const uint8_t* 
 int tb_optical_flow_pyr_lk_batch_dev(tb_ctx* ctx, int npairs, const uint8_t* prev, const uint8_t* next, int width, int height,
                                      int stride, size_t image_pitch, const float* prev_pts, const int32_t* counts,
                                      int pts_pitch, int win, int max_level, float* next_pts, uint8_t* status, float* err);
+
+/* SURVEY 8(f) row 2, second part / row a16 -- the RANSAC stage and the stereo depths.
+ * tb_find_fundamental_ransac replaces cv::findFundamentalMat(pts1, pts2, cv::FM_RANSAC, thresh, conf, mask) as
+ * Matcher::rejectWithF calls it (matcher.cpp:872): *ok = 1 and mask (n bytes) / F (9 doubles row-major, nullable) / *iters
+ * (nullable: RANSAC iterations run) when a mask comes back, *ok = 0 when OpenCV returns none (fewer than 7 points, no model).
+ * 8..14 points take OpenCV's LMedS branch: TB_EUNSUPPORTED. OpenCV 3.3 routine restated, PARITY UNPINNED: the sampling
+ * (cv::RNG((uint64)-1), getSubset, collinearity retries), error measure, model update and iteration budget follow OpenCV's
+ * structure; the 7-point solver's null space and cubic roots are computed with + - * / sqrt only (oracle/oracle_fund.cpp).
+ * tb_reject_with_f replaces Matcher::rejectWithF(cur_pts, last_pts, status) (matcher.cpp:853-881): n (x, y) pairs each,
+ * status in/out. At most 8 keys, fewer than 7 tracked points or no model: the reference reads an empty vector (UB); here
+ * the flags are left as they are. Host pointers. */
+int tb_find_fundamental_ransac(tb_ctx* ctx, const float* pts1, const float* pts2, int n, double thresh, double conf, uint8_t* mask,
+                               double* F, int* iters, int* ok);
+int tb_reject_with_f(tb_ctx* ctx, const float* cur_pts, const float* last_pts, int n, uint8_t* status);
+/* LocalBA::AddMapPointsByStereo(current_frame, stereo_frame, bf, fx), LocalBA.cpp:46-68: searchByOPFlow(stereo, current,
+ * pts, equalized = true, reject = true), then depth[i] = bf / fabsf(pts[i].x - key[i].x) for the surviving keys i of the
+ * current frame and -1 for the others (fx is unused by the reference; its drawing and imshow are dropped). img_stereo /
+ * img_current: level-0 images; cam_stereo: the stereo frame's camera (width / height for IsInFrame); keys_xy: the current
+ * frame's keys. *n_depth = number of depths set. Host pointers. */
+int tb_add_map_points_by_stereo(tb_ctx* ctx, const uint8_t* img_stereo, const uint8_t* img_current, int width, int height, int stride,
+                                const tb_camera* cam_stereo, const float* keys_xy, int n, float bf, float* depth, int* n_depth);
+/* Batched device form: pair p's images at + p * image_pitch, its keys / tracked points / status / depths at slot
+ * p * pts_pitch (counts[p] valid, counts nullable = pts_pitch each). cam_stereo is a HOST pointer. Asynchronous. */
+int tb_add_map_points_by_stereo_batch_dev(tb_ctx* ctx, int npairs, const uint8_t* img_stereo, const uint8_t* img_current, int width,
+                                          int height, int stride, size_t image_pitch, const tb_camera* cam_stereo, const float* keys_xy,
+                                          const int32_t* counts, int pts_pitch, float bf, float* cur_points, uint8_t* status,
+                                          float* depth);
 
 /* Multi-keyframe local BA -- north-star extension, NO reference counterpart.
  * poses: nkf x 16 (in/out, first nfixed held), pts: npt x 3 (in/out). A point is observed at most once per

@@ -14,9 +14,11 @@
 #define CV_8U 0
 #define CV_8UC1 0
 
+typedef unsigned char uchar;   /* OpenCV's cvdef.h declares it at global scope (the reference writes std::vector<uchar>) */
+
 namespace cv {
 
-typedef unsigned char uchar;
+using ::uchar;
 
 template <typename T> struct Point_ {
     T x, y;

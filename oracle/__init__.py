@@ -345,8 +345,8 @@ def optical_flow_pyr_lk(prev, nxt, prev_pts, win=21, max_level=3):
     return out[:n], status[:n], err[:n], top
 
 
-def search_by_opflow(img1, img2, cam1, keys2_xy, equalized=False):
-    """Matcher::searchByOPFlow(F1, F2, cur_points, equalized, reject=False), matcher.cpp:724-768.
+def search_by_opflow(img1, img2, cam1, keys2_xy, equalized=False, reject=False):
+    """Matcher::searchByOPFlow(F1, F2, cur_points, equalized, reject), matcher.cpp:724-768.
     Returns (cur_points [n,2], matched indices i (queryIdx = trainIdx = i))."""
     img1, img2 = _u8(img1), _u8(img2)
     h, w = img1.shape
@@ -354,8 +354,51 @@ def search_by_opflow(img1, img2, cam1, keys2_xy, equalized=False):
     n = len(pts)
     cur = np.zeros((max(n, 1), 2), np.float32)
     idx = np.zeros(max(n, 1), np.int32)
-    m = _chk(lib().orc_search_by_opflow(_p(img1), _p(img2), w, h, w, _p(cam1), _p(pts), n, int(equalized), _p(cur), _p(idx)))
+    m = _chk(lib().orc_search_by_opflow(_p(img1), _p(img2), w, h, w, _p(cam1), _p(pts), n, int(equalized), int(reject), _p(cur),
+                                        _p(idx)))
     return cur[:n], idx[:m].copy()
+
+
+def find_fundamental_ransac(pts1, pts2, thresh=1.0, conf=0.99):
+    """cv::findFundamentalMat(pts1, pts2, FM_RANSAC, thresh, conf, mask) as Matcher::rejectWithF calls it (matcher.cpp:872),
+    restated (parity unpinned). Returns (ok, mask [n] u8, F [3,3] f64, RANSAC iterations run); ok = 0: no mask comes back."""
+    p1 = np.ascontiguousarray(pts1, np.float32).reshape(-1, 2)
+    p2 = np.ascontiguousarray(pts2, np.float32).reshape(-1, 2)
+    assert len(p1) == len(p2)
+    n = len(p1)
+    mask = np.zeros(max(n, 1), np.uint8)
+    F = np.zeros(9, np.float64)
+    it = C.c_int(0)
+    rc = lib().orc_find_fundamental_ransac(_p(p1), _p(p2), n, C.c_double(thresh), C.c_double(conf), _p(mask), _p(F), C.byref(it))
+    if rc < 0:
+        raise OracleError("find_fundamental_ransac: %d points take OpenCV's LMedS branch (not restated)" % n)
+    return rc, mask[:n], F.reshape(3, 3), it.value
+
+
+def reject_with_f(cur_pts, last_pts, status):
+    """Matcher::rejectWithF(cur_pts, last_pts, status), matcher.cpp:853-881. Returns the updated status flags."""
+    cur = np.ascontiguousarray(cur_pts, np.float32).reshape(-1, 2)
+    last = np.ascontiguousarray(last_pts, np.float32).reshape(-1, 2)
+    st = np.ascontiguousarray(status, np.uint8).copy()
+    assert len(cur) == len(last) == len(st)
+    rc = lib().orc_reject_with_f(_p(cur), _p(last), len(st), _p(st))
+    if rc < 0:
+        raise OracleError("reject_with_f: LMedS branch (8..14 tracked points) not restated")
+    return st
+
+
+def add_map_points_by_stereo(img_stereo, img_current, cam_stereo, keys_xy, bf):
+    """LocalBA::AddMapPointsByStereo(current_frame, stereo_frame, bf, fx), LocalBA.cpp:46-68: depth per key of the current
+    frame (-1 where the tracker, the frame test or the RANSAC stage dropped it)."""
+    a, b = _u8(img_stereo), _u8(img_current)
+    h, w = a.shape
+    pts = np.ascontiguousarray(keys_xy, np.float32).reshape(-1, 2)
+    n = len(pts)
+    depth = np.zeros(max(n, 1), np.float32)
+    m = lib().orc_add_map_points_by_stereo(_p(a), _p(b), w, h, w, _p(cam_stereo), _p(pts), n, C.c_float(bf), _p(depth))
+    if m < 0:
+        raise OracleError("add_map_points_by_stereo: %d" % m)
+    return depth[:n]
 
 
 def clahe(img, clip_limit=3.0, tiles=(8, 8)):

@@ -105,8 +105,20 @@ int orc_optical_flow_pyr_lk(const uint8_t* prev, const uint8_t* next, int w, int
                             int win, int max_level, float* next_pts, uint8_t* status, float* err /* nullable */);
 /* Frame::Equalize (Frame.cpp:453-458) = cv::CLAHE(clip_limit, tiles).apply, restated; parity unpinned */
 int orc_clahe(const uint8_t* src, int w, int h, int stride, double clip_limit, int tiles_x, int tiles_y, uint8_t* dst, int dstride);
+/* returns the number of matches, -1 on error, -2 when reject is asked for with 8..14 tracked points (OpenCV's LMedS branch) */
 int orc_search_by_opflow(const uint8_t* img1, const uint8_t* img2, int w, int h, int stride, const tb_camera* cam1,
-                         const float* keys2_xy, int n, int equalized, float* cur_points, int32_t* match_idx);
+                         const float* keys2_xy, int n, int equalized, int reject, float* cur_points, int32_t* match_idx);
+
+/* ---- oracle_fund.cpp: Matcher::rejectWithF (matcher.cpp:853-881) = cv::findFundamentalMat(FM_RANSAC, 1.0, 0.99), OpenCV 3.3
+ * restated, PARITY UNPINNED (see the file header for what is OpenCV's structure and what is deliberately not), and
+ * LocalBA::AddMapPointsByStereo (LocalBA.cpp:46-68). */
+int orc_find_fundamental_ransac(const float* pts1, const float* pts2, int n, double thresh, double conf, uint8_t* mask,
+                                double* F /* 9, nullable */, int* iters /* nullable */);
+int orc_reject_with_f(const float* cur_pts, const float* last_pts, int n, uint8_t* status);
+/* stereo = F1 (tracked into, equalised), current = F2 (its keys are tracked): depth[i] = bf / |x_tracked - x_key| for the
+ * surviving matches, -1 elsewhere. Returns the number of depths set, -1 on error, -2 as above. */
+int orc_add_map_points_by_stereo(const uint8_t* img_stereo, const uint8_t* img_current, int w, int h, int stride,
+                                 const tb_camera* cam_stereo, const float* keys_xy, int n, float bf, float* depth);
 
 #ifdef __cplusplus
 }

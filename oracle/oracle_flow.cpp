@@ -202,7 +202,7 @@ int orc_optical_flow_pyr_lk(const uint8_t* prev, const uint8_t* next, int w, int
 int orc_clahe(const uint8_t* src, int w, int h, int stride, double clip_limit, int tiles_x, int tiles_y, uint8_t* dst, int dstride);
 
 int orc_search_by_opflow(const uint8_t* img1, const uint8_t* img2, int w, int h, int stride, const tb_camera* cam1,
-                         const float* keys2_xy, int n, int equalized, float* cur_points, int32_t* match_idx) {
+                         const float* keys2_xy, int n, int equalized, int reject, float* cur_points, int32_t* match_idx) {
     std::vector<uint8_t> status(n > 0 ? n : 1), eq;
     if (equalized) { /* matcher.cpp:736-739: img1 = F1->Equalize() */
         eq.resize((size_t)stride * h);
@@ -211,14 +211,23 @@ int orc_search_by_opflow(const uint8_t* img1, const uint8_t* img2, int w, int h,
     }
     std::vector<float> err(n > 0 ? n : 1);
     if (orc_optical_flow_pyr_lk(img2, img1, w, h, stride, keys2_xy, n, 21, 3, cur_points, status.data(), err.data()) < 0) return -1;
-    int m = 0;
     for (int i = 0; i < n; i++) {
         if (!status[i]) continue;
         const float x = cur_points[2 * i], y = cur_points[2 * i + 1];
-        if (!(std::fabs(x) < 2147483648.f) || !(std::fabs(y) < 2147483648.f)) continue; /* cvttss2si -> INT_MIN: not in frame */
-        const int u = (int)x, v = (int)y;
-        if (u >= 0 && u < (int)((float)cam1->width * 1.f) && v >= 0 && v < (int)((float)cam1->height * 1.f)) match_idx[m++] = i;
+        bool in = std::fabs(x) < 2147483648.f && std::fabs(y) < 2147483648.f; /* else cvttss2si -> INT_MIN: not in frame */
+        if (in) {
+            const int u = (int)x, v = (int)y;
+            in = u >= 0 && u < (int)((float)cam1->width * 1.f) && v >= 0 && v < (int)((float)cam1->height * 1.f);
+        }
+        if (!in) status[i] = 0;
     }
+    if (reject) { /* matcher.cpp:751-755: rejectWithF(cur_points, F2->GetCVKeys(), status) */
+        const int rc = orc_reject_with_f(cur_points, keys2_xy, n, status.data());
+        if (rc == -2) return -2;
+    }
+    int m = 0;
+    for (int i = 0; i < n; i++)
+        if (status[i]) match_idx[m++] = i;
     return m;
 }
 

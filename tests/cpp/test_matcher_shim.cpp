@@ -133,14 +133,12 @@ int main(int argc, char** argv)
     }
     for (int i2 = 0; i2 < n2p; i2++) nomp2[i2] = frame2_ptr->GetMapPoint(i2) ? 0 : 1;
 
-    // LocalBA::AddMapPointsByStereo's matcher call (LocalBA.cpp:54) without the stage that is not built (reject =
-    // RANSAC F): the left frame's keys tracked into the CLAHE-equalised right image
-    std::vector<cv::Point2f> flow_pts;
+    // LocalBA::AddMapPointsByStereo's matcher call (LocalBA.cpp:54): the left frame's keys tracked into the CLAHE-equalised
+    // right image, first without, then with the RANSAC stage (reject = true), then the function itself (test_vo.cpp:716)
+    std::vector<cv::Point2f> flow_pts, flow_pts_r;
     auto fmatches = matcher_ptr->searchByOPFlow(frame2_ptr, frame1_ptr, flow_pts, true, false);
-    bool threw = false;
-    try { std::vector<cv::Point2f> tmp; matcher_ptr->searchByOPFlow(frame2_ptr, frame1_ptr, tmp, true, true); }
-    catch (const std::invalid_argument&) { threw = true; }
-    if (!threw) { std::cerr << "searchByOPFlow(reject) must refuse" << std::endl; return 3; }
+    auto rmatches = matcher_ptr->searchByOPFlow(frame2_ptr, frame1_ptr, flow_pts_r, true, true);
+    std::vector<float> depths = localBa.AddMapPointsByStereo(frame1_ptr, frame2_ptr, 386.1448f, 718.856f);
 
     std::ofstream o(argv[4], std::ios::binary);
     put(o, keypoints1.data(), keypoints1.size()); put(o, descriptors1.data, (size_t)descriptors1.rows * 32);
@@ -154,8 +152,10 @@ int main(int argc, char** argv)
     put(o, mp_rec.data(), mp_rec.size()); put(o, mp_desc.data(), mp_desc.size());
     put(o, pmatches.data(), pmatches.size()); put(o, mmatches.data(), mmatches.size());
     put(o, flow_pts.data(), flow_pts.size()); put(o, fmatches.data(), fmatches.size());
+    put(o, rmatches.data(), rmatches.size()); put(o, depths.data(), depths.size());
     std::cout << "kps " << keypoints1.size() << "/" << keypoints2.size() << " added " << added.size() << " bf " << matches.size()
               << " violence " << vmatches.size() << " fast " << fast_kps.size() << " pose inliers " << inliers
-              << " projection " << pmatches.size() << " map projection " << mmatches.size() << " flow " << fmatches.size() << std::endl;
+              << " projection " << pmatches.size() << " map projection " << mmatches.size() << " flow " << fmatches.size()
+              << " flow+ransac " << rmatches.size() << " depths " << depths.size() << std::endl;
     return 0;
 }

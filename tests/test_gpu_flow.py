@@ -66,9 +66,9 @@ def test_search_by_opflow(ctx):
     cur, m = ctx.search_by_opflow(R, L, cam, pts, equalized=True)   # F1's image through Frame::Equalize first
     ocur, oidx = oracle.search_by_opflow(R, L, cam, pts, equalized=True)
     assert np.array_equal(cur.view(np.uint32), ocur.view(np.uint32)) and np.array_equal(m["queryIdx"], oidx)
-    with pytest.raises(capi.TBError) as e:
-        ctx.search_by_opflow(R, L, cam, pts, reject=True)
-    assert e.value.code == capi.TB_EUNSUPPORTED
+    cur, m = ctx.search_by_opflow(R, L, cam, pts, reject=True)       # ... and rejectWithF before the matches are listed
+    ocur, oidx = oracle.search_by_opflow(R, L, cam, pts, reject=True)
+    assert np.array_equal(cur.view(np.uint32), ocur.view(np.uint32)) and np.array_equal(m["queryIdx"], oidx)
     assert len(ctx.search_by_opflow(R, L, cam, np.zeros((0, 2), np.float32))[1]) == 0
 
 
@@ -144,6 +144,106 @@ def test_search_by_opflow_batch_device_resident(ctx, equalized):
         assert np.array_equal(cur[p, :n].view(np.uint32), ocur.view(np.uint32))
         assert oc[p] == len(oidx) and np.array_equal(out[p, :oc[p], 0], oidx) and np.array_equal(out[p, :oc[p], 1], oidx)
         assert np.array_equal(np.nonzero(st[p, :n])[0], oidx)
-    with pytest.raises(capi.TBError):
-        ctx.search_by_opflow_batch_dev(3, F1.data_ptr(), F2.data_ptr(), W, H, W, W * H, cam, dp.data_ptr(), dc.data_ptr(), cap,
-                                       cur.ctypes.data, 0, 0, cap, 0, reject=True)
+
+
+# ---- SURVEY 8(f) row 2, second part / a16: rejectWithF (cv::findFundamentalMat RANSAC restated, parity unpinned) and the
+# stereo depths of LocalBA::AddMapPointsByStereo -- HIP kernel k_ransac_f against oracle/oracle_fund.cpp, bit for bit
+
+def _stereo_pts(n, seed, outliers=0, noise=0.0):
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(20, 1220, n); y = rng.uniform(20, 350, n)
+    d = 386.1448 / rng.uniform(4, 60, n)
+    p1 = np.stack([x, y], 1)
+    p2 = np.stack([x - d, y], 1) + (rng.normal(0, noise, (n, 2)) if noise else 0)
+    if outliers:
+        idx = rng.choice(n, outliers, replace=False)
+        p2[idx] += rng.uniform(6, 70, (outliers, 2)) * rng.choice([-1, 1], (outliers, 2))
+    return p1.astype(np.float32), p2.astype(np.float32)
+
+
+@pytest.mark.parametrize("n,seed,outliers,noise", [(500, 1, 0, 0.0), (400, 2, 60, 0.15), (2000, 3, 700, 0.3), (64, 4, 10, 0.1),
+                                                    (15, 5, 2, 0.05), (1500, 6, 1100, 0.5), (300, 7, 299, 2.0)])
+def test_find_fundamental_ransac_vs_oracle(ctx, n, seed, outliers, noise):
+    """Same mask, same matrix (bit for bit) and same number of RANSAC iterations as the sequential restatement: from one
+    clean sample that ends the loop at once to outlier-dominated sets that run for hundreds of iterations (several
+    64-iteration batches on the device)."""
+    p1, p2 = _stereo_pts(n, seed, outliers, noise)
+    ok, mask, F, it = oracle.find_fundamental_ransac(p1, p2)
+    okg, maskg, Fg, itg = ctx.find_fundamental_ransac(p1, p2)
+    assert okg == ok and itg == it
+    assert np.array_equal(maskg, mask)
+    if ok:
+        assert np.array_equal(Fg.view(np.uint64), F.view(np.uint64))
+
+
+def test_find_fundamental_dispatch(ctx):
+    p1, p2 = _stereo_pts(40, 8)
+    assert ctx.find_fundamental_ransac(p1[:6], p2[:6])[0] == 0
+    ok, mask, F, _ = ctx.find_fundamental_ransac(p1[:7], p2[:7])
+    oko, masko, Fo, _ = oracle.find_fundamental_ransac(p1[:7], p2[:7])
+    assert ok == oko and np.array_equal(mask, masko) and (not ok or np.array_equal(F.view(np.uint64), Fo.view(np.uint64)))
+    with pytest.raises(capi.TBError) as e:
+        ctx.find_fundamental_ransac(p1[:12], p2[:12])
+    assert e.value.code == capi.TB_EUNSUPPORTED
+
+
+def test_reject_with_f_vs_oracle(ctx):
+    p1, p2 = _stereo_pts(900, 9, outliers=250, noise=0.2)
+    status = np.ones(900, np.uint8)
+    status[::5] = 0
+    exp = oracle.reject_with_f(p2, p1, status)
+    got = ctx.reject_with_f(p2, p1, status)
+    assert np.array_equal(got, exp) and not got[::5].any() and 0 < got.sum() < status.sum()
+    s8 = np.ones(8, np.uint8)
+    assert np.array_equal(ctx.reject_with_f(p2[:8], p1[:8], s8), s8)
+
+
+def test_search_by_opflow_reject_and_stereo_depths(ctx, kitti_pair):
+    """Matcher::searchByOPFlow(stereo, current, pts, equalized = true, reject = true) and LocalBA::AddMapPointsByStereo
+    (LocalBA.cpp:46-68) on the reference's own stereo pair: host forms and the batched device form against the oracle."""
+    import torch
+    L, R = kitti_pair
+    lv, sf = oracle.pyramid(L, 5, 0.8)
+    k, _, _ = oracle.orb_extract(lv, sf, 1000, 80, 30)
+    keys = np.ascontiguousarray(np.stack([k["x"], k["y"]], 1)[k["octave"] == 0], np.float32)
+    cam = oracle.camera(718.856, 718.856, 607.1928, 185.2157, 1241, 376)
+    ocur, oidx = oracle.search_by_opflow(R, L, cam, keys, equalized=True, reject=True)
+    cur, m = ctx.search_by_opflow(R, L, cam, keys, equalized=True, reject=True)
+    assert np.array_equal(cur.view(np.uint32), ocur.view(np.uint32))
+    assert len(oidx) > 50 and np.array_equal(m["queryIdx"], oidx) and np.array_equal(m["trainIdx"], oidx)
+    _, oidx0 = oracle.search_by_opflow(R, L, cam, keys, equalized=True, reject=False)
+    assert set(oidx.tolist()) <= set(oidx0.tolist())
+    bf = 386.1448
+    odepth = oracle.add_map_points_by_stereo(R, L, cam, keys, bf)
+    depth, nd = ctx.add_map_points_by_stereo(R, L, cam, keys, bf)
+    assert nd == len(oidx) and np.array_equal(depth.view(np.uint32), odepth.view(np.uint32))
+    # batched device form: three pairs (the KITTI pair, a synthetic pair, the KITTI pair with fewer keys)
+    import ctypes as C
+    h, w = L.shape
+    Ls, Rs = synth.frame(90, w, h, stereo=True)
+    lvs, _ = oracle.pyramid(Ls, 3, 0.8)
+    ks, _, _ = oracle.orb_extract(lvs, sf[:3], 600, 40, 10)
+    keys_s = np.ascontiguousarray(np.stack([ks["x"], ks["y"]], 1)[ks["octave"] == 0], np.float32)
+    cases = [(R, L, keys), (Rs, Ls, keys_s), (R, L, keys[:40])]
+    P = max(len(c[2]) for c in cases)
+    img1 = torch.from_numpy(np.stack([c[0] for c in cases])).cuda()
+    img2 = torch.from_numpy(np.stack([c[1] for c in cases])).cuda()
+    kk = np.zeros((3, P, 2), np.float32); cnt = np.zeros(3, np.int32)
+    for i, c in enumerate(cases):
+        kk[i, :len(c[2])] = c[2]; cnt[i] = len(c[2])
+    d_keys = torch.from_numpy(kk).cuda(); d_cnt = torch.from_numpy(cnt).cuda()
+    d_cur = torch.zeros((3, P, 2), dtype=torch.float32, device="cuda")
+    d_st = torch.zeros((3, P), dtype=torch.uint8, device="cuda")
+    d_depth = torch.zeros((3, P), dtype=torch.float32, device="cuda")
+    torch.cuda.synchronize()
+    camr = np.ascontiguousarray(cam, capi.CAMERA)
+    ctx.check(capi.lib().tb_add_map_points_by_stereo_batch_dev(
+        ctx._h, 3, C.c_void_p(img1.data_ptr()), C.c_void_p(img2.data_ptr()), w, h, w, C.c_size_t(w * h), camr.ctypes.data_as(C.c_void_p),
+        C.c_void_p(d_keys.data_ptr()), C.c_void_p(d_cnt.data_ptr()), P, C.c_float(bf), C.c_void_p(d_cur.data_ptr()),
+        C.c_void_p(d_st.data_ptr()), C.c_void_p(d_depth.data_ptr())))
+    ctx.synchronize()
+    for i, c in enumerate(cases):
+        exp = oracle.add_map_points_by_stereo(c[0], c[1], cam, c[2], bf)
+        got = d_depth[i, :len(c[2])].cpu().numpy()
+        assert np.array_equal(got.view(np.uint32), exp.view(np.uint32)), i
+        assert (d_depth[i, len(c[2]):].cpu().numpy() == -1).all()

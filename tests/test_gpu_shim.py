@@ -47,10 +47,10 @@ def test_reference_style_driver_on_shims(golden, kitti_pair):
         log = subprocess.check_output([EXE, os.path.join(GOLDEN, "kitti00_left_1241x376.pgm"),
                                        os.path.join(GOLDEN, "kitti00_right_1241x376.pgm"), ob, out], timeout=300).decode()
         assert "kps" in log
-        (k1, d1, k2, d2, ka, da, bf, vio, fg, T, outl, ninl, k1now, taken1, nomp2, mp, mpd, pm, mm, fpts, fm) = _read_blocks(
+        (k1, d1, k2, d2, ka, da, bf, vio, fg, T, outl, ninl, k1now, taken1, nomp2, mp, mpd, pm, mm, fpts, fm, rm, depths) = _read_blocks(
             out, [capi.KEYPOINT, np.uint8, capi.KEYPOINT, np.uint8, capi.KEYPOINT, np.uint8, capi.MATCH, capi.MATCH,
                   capi.KEYPOINT, np.float32, np.uint8, np.int32, capi.KEYPOINT, np.uint8, np.uint8, capi.MAPPOINT, np.uint8,
-                  capi.MATCH, capi.MATCH, np.dtype([("x", "<f4"), ("y", "<f4")]), capi.MATCH])
+                  capi.MATCH, capi.MATCH, np.dtype([("x", "<f4"), ("y", "<f4")]), capi.MATCH, capi.MATCH, np.float32])
     assert np.array_equal(k1, golden["c5_kps_left"]) and np.array_equal(d1.reshape(-1, 32), golden["c5_desc_left"])
     assert np.array_equal(k2, golden["c5_kps_right"]) and np.array_equal(d2.reshape(-1, 32), golden["c5_desc_right"])
     assert np.array_equal(ka, golden["c5_addpoints_kps_left"]) and np.array_equal(da.reshape(-1, 32), golden["c5_addpoints_desc_left"])
@@ -77,6 +77,13 @@ def test_reference_style_driver_on_shims(golden, kitti_pair):
     ocur, oidx = oracle.search_by_opflow(imgR, imgL, cam, np.stack([k1now["x"], k1now["y"]], 1), equalized=True)
     assert np.array_equal(np.stack([fpts["x"], fpts["y"]], 1).view(np.uint32), ocur.view(np.uint32))
     assert len(oidx) > 200 and np.array_equal(fm["queryIdx"], oidx) and np.array_equal(fm["trainIdx"], oidx)
+    # ... with the RANSAC stage (reject = true), and LocalBA::AddMapPointsByStereo itself (LocalBA.cpp:46-68)
+    keys = np.stack([k1now["x"], k1now["y"]], 1)
+    rcur, ridx = oracle.search_by_opflow(imgR, imgL, cam, keys, equalized=True, reject=True)
+    assert 100 < len(ridx) <= len(oidx) and np.array_equal(rm["queryIdx"], ridx) and np.array_equal(rm["trainIdx"], ridx)
+    odepth = oracle.add_map_points_by_stereo(imgR, imgL, cam, keys, 386.1448)
+    assert len(depths) == len(k1now) and np.array_equal(depths.view(np.uint32), odepth.view(np.uint32))
+    assert (depths[ridx] > 0).all() and (np.delete(depths, ridx) == -1).all()
 
 
 def test_shim_library_exports_reference_classes():
@@ -86,7 +93,8 @@ def test_shim_library_exports_reference_classes():
     syms = subprocess.check_output(["nm", "-DC", "--defined-only", so]).decode()
     for want in ("TRACKING_BENCH::ORBExtractor::operator()", "TRACKING_BENCH::ORBExtractor::AddPoints",
                  "TRACKING_BENCH::FASTExtractor::operator()", "TRACKING_BENCH::Matcher::searchByBF",
-                 "TRACKING_BENCH::Matcher::searchByViolence", "TRACKING_BENCH::Matcher::searchByOPFlow",
+                 "TRACKING_BENCH::Matcher::searchByViolence", "TRACKING_BENCH::Matcher::searchByOPFlow", "TRACKING_BENCH::Matcher::rejectWithF",
+                 "TRACKING_BENCH::LocalBA::AddMapPointsByStereo",
                  "TRACKING_BENCH::Matcher::DescriptorDistance",
                  "TRACKING_BENCH::Matcher::ComputeThreeMaxima", "TRACKING_BENCH::LocalBA::PoseOptimization",
                  "TRACKING_BENCH::LocalBA::LinearTriangle", "TRACKING_BENCH::Frame::ComputePyramid"):

@@ -1,0 +1,129 @@
+"""CPU tests of the oracle's RANSAC fundamental-matrix stage (oracle/oracle_fund.cpp): Matcher::rejectWithF =
+cv::findFundamentalMat(FM_RANSAC, 1.0, 0.99) restated, PARITY UNPINNED (the reference holds no vector for it, OpenCV is
+not installed). What can be checked without OpenCV are the properties the routine must have."""
+import numpy as np
+import pytest
+
+import oracle
+
+
+def _stereo_points(n, seed, outliers=0, noise=0.0):
+    """Rectified stereo: same rows, disparity bf / z. Returns (left pts, right pts, outlier mask)."""
+    rng = np.random.default_rng(seed)
+    x = rng.uniform(20, 1220, n); y = rng.uniform(20, 350, n)
+    z = rng.uniform(4, 60, n)
+    d = 386.1448 / z
+    p1 = np.stack([x, y], 1)
+    p2 = np.stack([x - d, y], 1)
+    p2 += rng.normal(0, noise, p2.shape) if noise else 0
+    bad = np.zeros(n, bool)
+    if outliers:
+        idx = rng.choice(n, outliers, replace=False)
+        bad[idx] = True
+        p2[idx, 1] += rng.choice([-1, 1], outliers) * rng.uniform(8, 60, outliers)   # off the epipolar line
+    return p1.astype(np.float32), p2.astype(np.float32), bad
+
+
+def _general_points(n, seed, outliers=0):
+    """Two views of random 3-D points with a general relative pose."""
+    rng = np.random.default_rng(seed)
+    X = np.stack([rng.uniform(-6, 6, n), rng.uniform(-3, 3, n), rng.uniform(5, 30, n)], 1)
+    K = np.array([[718.856, 0, 607.19], [0, 718.856, 185.22], [0, 0, 1]])
+    a, b = 0.05, -0.03
+    Ry = np.array([[np.cos(a), 0, np.sin(a)], [0, 1, 0], [-np.sin(a), 0, np.cos(a)]])
+    Rx = np.array([[1, 0, 0], [0, np.cos(b), -np.sin(b)], [0, np.sin(b), np.cos(b)]])
+    R, t = Ry @ Rx, np.array([0.6, -0.1, 0.25])
+    u1 = X @ K.T; u1 = u1[:, :2] / u1[:, 2:]
+    Xc = X @ R.T + t
+    u2 = Xc @ K.T; u2 = u2[:, :2] / u2[:, 2:]
+    bad = np.zeros(n, bool)
+    if outliers:
+        idx = rng.choice(n, outliers, replace=False)
+        bad[idx] = True
+        u2[idx] += rng.uniform(15, 80, (outliers, 2)) * rng.choice([-1, 1], (outliers, 2))
+    tx = np.array([[0, -t[2], t[1]], [t[2], 0, -t[0]], [-t[1], t[0], 0]])
+    Ftrue = np.linalg.inv(K).T @ tx @ R @ np.linalg.inv(K)
+    return u1.astype(np.float32), u2.astype(np.float32), bad, Ftrue
+
+
+def test_exact_stereo_all_inliers_and_early_stop():
+    p1, p2, _ = _stereo_points(500, 1)
+    ok, mask, F, iters = oracle.find_fundamental_ransac(p1, p2)
+    assert ok == 1 and mask.all()
+    # every point an inlier after the first good sample: RANSACUpdateNumIters drops the budget to zero
+    assert iters <= 2
+    # epipolar constraint of the returned matrix, x2^T F x1 = 0 (computeError's convention)
+    h1 = np.c_[p1.astype(np.float64), np.ones(len(p1))]; h2 = np.c_[p2.astype(np.float64), np.ones(len(p2))]
+    assert np.abs(np.einsum("ni,ij,nj->n", h2, F, h1)).max() < 1e-6 * np.abs(F).max() * 1e6
+    assert abs(np.linalg.det(F)) < 1e-9 * np.abs(F).max() ** 3 + 1e-18      # rank 2
+
+
+def test_gross_outliers_are_rejected():
+    for seed, n, nout in ((2, 400, 60), (3, 1000, 300), (4, 64, 10)):
+        p1, p2, bad = _stereo_points(n, seed, outliers=nout, noise=0.15)
+        ok, mask, F, iters = oracle.find_fundamental_ransac(p1, p2)
+        assert ok == 1
+        assert not mask[bad].any()                       # every gross outlier is dropped
+        assert mask[~bad].mean() > 0.85                  # most true matches are kept (0.15 px noise, 1 px threshold, model from 7 points, no refit)
+        assert 1 <= iters <= 1000
+
+
+def test_general_motion_recovers_the_epipolar_geometry():
+    p1, p2, bad, Ft = _general_points(600, 5, outliers=120)
+    ok, mask, F, iters = oracle.find_fundamental_ransac(p1, p2)
+    # a displaced point lands within 1 px of its epipolar line by chance about once in a hundred
+    assert ok == 1 and mask[bad].sum() <= 5 and mask[~bad].mean() > 0.99
+    # same matrix up to scale as the ground truth
+    Fn, Ftn = F / np.linalg.norm(F), Ft / np.linalg.norm(Ft)
+    assert min(np.abs(Fn - Ftn).max(), np.abs(Fn + Ftn).max()) < 2e-3
+
+
+def test_dispatch_by_point_count():
+    p1, p2, _ = _stereo_points(40, 6)
+    assert oracle.find_fundamental_ransac(p1[:6], p2[:6])[0] == 0          # fewer than 7: no mask
+    ok, mask, F, _ = oracle.find_fundamental_ransac(p1[:7], p2[:7])       # exactly 7: the solver, all ones
+    assert ok in (0, 1) and (ok == 0 or mask.all())
+    with pytest.raises(oracle.OracleError):                                # 8..14: OpenCV's LMedS branch, not restated
+        oracle.find_fundamental_ransac(p1[:12], p2[:12])
+    assert oracle.find_fundamental_ransac(p1[:15], p2[:15])[0] == 1
+
+
+def test_deterministic_and_order_dependent_like_a_seeded_rng():
+    p1, p2, bad = _stereo_points(300, 7, outliers=90, noise=0.2)
+    a = oracle.find_fundamental_ransac(p1, p2)
+    b = oracle.find_fundamental_ransac(p1, p2)
+    assert np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2]) and a[3] == b[3]   # cv::RNG((uint64)-1) every call
+
+
+def test_reject_with_f_only_touches_tracked_points():
+    p1, p2, bad = _stereo_points(200, 8, outliers=40, noise=0.1)
+    status = np.ones(200, np.uint8)
+    status[::7] = 0                                   # lost by the tracker: never looked at, never resurrected
+    out = oracle.reject_with_f(p2, p1, status)
+    assert not out[::7].any()
+    live = status.astype(bool)
+    assert not out[live & bad].any() and out[live & ~bad].mean() > 0.85
+    # at most 8 keys: findFundamentalMat is not called (matcher.cpp:870), flags stay
+    s8 = np.ones(8, np.uint8)
+    assert np.array_equal(oracle.reject_with_f(p2[:8], p1[:8], s8), s8)
+
+
+def test_add_map_points_by_stereo_depths():
+    from trackingbench_slam_amd import synth
+    L, R = synth.frame(80, 640, 360, stereo=True)
+    lv, sf = oracle.pyramid(L, 4, 0.8)
+    k, _, _ = oracle.orb_extract(lv, sf, 400, 40, 10)
+    keys = np.stack([k["x"], k["y"]], 1)[k["octave"] == 0]
+    cam = oracle.camera(718.856, 718.856, 320.0, 180.0, 640, 360)
+    bf = 386.1448
+    depth = oracle.add_map_points_by_stereo(R, L, cam, keys, bf)
+    cur, idx = oracle.search_by_opflow(R, L, cam, keys, equalized=True, reject=True)
+    assert len(idx) > 20
+    exp = np.full(len(keys), -1.0, np.float32)
+    exp[idx] = np.float32(bf) / np.abs(cur[idx, 0] - keys[idx, 0])
+    assert np.array_equal(depth, exp)
+    # the synthetic right image is the left one shifted left by 4..64 px: tracked keys move to smaller x
+    assert (cur[idx, 0] < keys[idx, 0]).mean() > 0.9 and (depth[idx] > 0).all()
+    # reject = True can only remove matches
+    _, idx0 = oracle.search_by_opflow(R, L, cam, keys, equalized=True, reject=False)
+    assert set(idx.tolist()) <= set(idx0.tolist())

@@ -40,6 +40,7 @@ EXPORTS = [
     "tb_search_by_projection_batch_dev", "tb_search_by_projection_map_batch_dev",
     "tb_search_by_violence_batch_dev", "tb_pose_opt", "tb_pose_opt_batch_dev", "tb_local_ba", "tb_local_ba_batch_dev",
     "tb_clahe", "tb_clahe_dev", "tb_optical_flow_pyr_lk", "tb_optical_flow_pyr_lk_dev", "tb_optical_flow_pyr_lk_batch_dev", "tb_search_by_opflow", "tb_search_by_opflow_batch_dev",
+    "tb_find_fundamental_ransac", "tb_reject_with_f", "tb_add_map_points_by_stereo", "tb_add_map_points_by_stereo_batch_dev",
 ]
 
 
@@ -343,6 +344,43 @@ class Context:
         self.check(lib().tb_search_by_opflow(self._h, _p(img1), _p(img2), w, h, w, _p(cam1), _p(pts), n, int(equalized),
                                              int(reject), _p(cur), _p(out), len(out), C.byref(cnt)))
         return cur[:n], out[:cnt.value].copy()
+
+    def find_fundamental_ransac(self, pts1, pts2, thresh=1.0, conf=0.99):
+        """cv::findFundamentalMat(pts1, pts2, FM_RANSAC, thresh, conf, mask) (reference matcher.cpp:872).
+        Returns (ok, mask [n] u8, F [3,3] f64, RANSAC iterations run)."""
+        p1 = np.ascontiguousarray(pts1, np.float32).reshape(-1, 2)
+        p2 = np.ascontiguousarray(pts2, np.float32).reshape(-1, 2)
+        assert len(p1) == len(p2)
+        n = len(p1)
+        mask = np.zeros(max(n, 1), np.uint8)
+        F = np.zeros(9, np.float64)
+        it, ok = C.c_int(0), C.c_int(0)
+        self.check(lib().tb_find_fundamental_ransac(self._h, _p(p1), _p(p2), n, C.c_double(thresh), C.c_double(conf), _p(mask), _p(F),
+                                                    C.byref(it), C.byref(ok)))
+        return ok.value, mask[:n], F.reshape(3, 3), it.value
+
+    def reject_with_f(self, cur_pts, last_pts, status):
+        """Matcher::rejectWithF(cur_pts, last_pts, status) (reference matcher.cpp:853-881). Returns the updated flags."""
+        cur = np.ascontiguousarray(cur_pts, np.float32).reshape(-1, 2)
+        last = np.ascontiguousarray(last_pts, np.float32).reshape(-1, 2)
+        st = np.ascontiguousarray(status, np.uint8).copy()
+        assert len(cur) == len(last) == len(st)
+        self.check(lib().tb_reject_with_f(self._h, _p(cur), _p(last), len(st), _p(st)))
+        return st
+
+    def add_map_points_by_stereo(self, img_stereo, img_current, cam_stereo, keys_xy, bf):
+        """LocalBA::AddMapPointsByStereo(current_frame, stereo_frame, bf, fx) (reference LocalBA.cpp:46-68): depth per key."""
+        a = np.ascontiguousarray(img_stereo, np.uint8); b = np.ascontiguousarray(img_current, np.uint8)
+        assert a.ndim == 2 and a.shape == b.shape
+        h, w = a.shape
+        cam = np.ascontiguousarray(cam_stereo, CAMERA)
+        pts = np.ascontiguousarray(keys_xy, np.float32).reshape(-1, 2)
+        n = len(pts)
+        depth = np.zeros(max(n, 1), np.float32)
+        cnt = C.c_int(0)
+        self.check(lib().tb_add_map_points_by_stereo(self._h, _p(a), _p(b), w, h, w, _p(cam), _p(pts), n, C.c_float(bf), _p(depth),
+                                                     C.byref(cnt)))
+        return depth[:n], cnt.value
 
     def search_by_projection(self, Tcw1, cam1, img1_w, img1_h, k1, d1, taken1, k2, mp2, mp2_desc, scale_factors, nratio,
                              th_high=100, histo_len=30, check_orientation=True):

@@ -143,7 +143,7 @@ void tb_destroy(tb_ctx* ctx) {
     hipStreamSynchronize(ctx->stream);
     ctx->plans.clear();
     while (!ctx->live.empty()) tb_extractor_destroy(*ctx->live.begin()); /* plans never outlive their context */
-    for (int i = 0; i < 8; i++)
+    for (int i = 0; i < 12; i++)
         if (ctx->scratch[i]) hipFree(ctx->scratch[i]);
     prof_drain(ctx);
     for (hipEvent_t e : ctx->prof_pool) hipEventDestroy(e);
@@ -1380,7 +1380,6 @@ int tb_search_by_opflow(tb_ctx* ctx, const uint8_t* img1, const uint8_t* img2, i
     TB_ENTER(ctx);
     if (!ctx || !count || !cam1 || n < 0 || cap < 0 || (n && (!cur_points || !keys2_xy)) || (cap && !out)) return TB_EINVAL;
     *count = 0;
-    if (reject) return tb_fail(ctx, TB_EUNSUPPORTED, "searchByOPFlow: reject (rejectWithF = cv::findFundamentalMat RANSAC) is not built");
     std::vector<uint8_t> status((size_t)std::max(n, 1)), eq;
     int rc;
     if (equalized) { /* matcher.cpp:736-739: img1 = F1->Equalize() = CLAHE(3.0, 8 x 8) of F1's level 0 (Frame.cpp:453-458) */
@@ -1391,15 +1390,22 @@ int tb_search_by_opflow(tb_ctx* ctx, const uint8_t* img1, const uint8_t* img2, i
     /* matcher.cpp:744: calcOpticalFlowPyrLK(img2, img1, keys of F2, cur_points, ..., Size(21, 21), 3) */
     rc = tb_optical_flow_pyr_lk(ctx, img2, img1, width, height, stride, keys2_xy, n, 21, 3, cur_points, status.data(), nullptr, nullptr);
     if (rc) return rc;
-    int m = 0;
     for (int i = 0; i < n; i++) {
         if (!status[i]) continue;
         /* :746-748, IsInFrame(Vector2i(cur.x, cur.y)): the conversion truncates; out-of-int-range converts to INT_MIN on
          * x86 and fails the test */
         const float x = cur_points[2 * i], y = cur_points[2 * i + 1];
-        if (!(fabsf(x) < 2147483648.f) || !(fabsf(y) < 2147483648.f)) continue;
-        const int u = (int)x, v = (int)y;
-        if (!(u >= 0 && u < (int)((float)cam1->width * 1.f) && v >= 0 && v < (int)((float)cam1->height * 1.f))) continue;
+        bool in = fabsf(x) < 2147483648.f && fabsf(y) < 2147483648.f;
+        if (in) {
+            const int u = (int)x, v = (int)y;
+            in = u >= 0 && u < (int)((float)cam1->width * 1.f) && v >= 0 && v < (int)((float)cam1->height * 1.f);
+        }
+        if (!in) status[i] = 0;
+    }
+    if (reject && (rc = tb_reject_with_f(ctx, cur_points, keys2_xy, n, status.data()))) return rc; /* matcher.cpp:751-755 */
+    int m = 0;
+    for (int i = 0; i < n; i++) {
+        if (!status[i]) continue;
         if (m >= cap) return tb_fail(ctx, TB_ECAPACITY, "searchByOPFlow: more than %d matches", cap);
         out[m].queryIdx = i; out[m].trainIdx = i; out[m].imgIdx = -1; out[m].distance = 3.402823466e+38f; /* cv::DMatch() */
         m++;
@@ -1414,7 +1420,6 @@ int tb_search_by_opflow_batch_dev(tb_ctx* ctx, int npairs, const uint8_t* img1, 
                                   int32_t* out_counts) {
     TB_ENTER(ctx);
     if (!ctx || !cam1 || npairs < 0 || pts_pitch < 0 || cap < 0 || width < 1 || height < 1 || stride < width) return TB_EINVAL;
-    if (reject) return tb_fail(ctx, TB_EUNSUPPORTED, "searchByOPFlow: reject (rejectWithF = cv::findFundamentalMat RANSAC) is not built");
     if (npairs == 0) return TB_OK;
     if (!img1 || !img2 || !out_counts || image_pitch < (size_t)stride * height) return TB_EINVAL;
     if (pts_pitch && (!keys2_xy || !cur_points || !status || (cap && !out))) return TB_EINVAL;
@@ -1435,7 +1440,116 @@ int tb_search_by_opflow_batch_dev(tb_ctx* ctx, int npairs, const uint8_t* img1, 
                                cur_points, status, nullptr, work, nullptr)))
             return rc;
     }
-    return tbk_flow_accept(ctx, npairs, cur_points, status, counts, pts_pitch, cam1->width, cam1->height, out, cap, out_counts);
+    if ((rc = tbk_flow_accept(ctx, npairs, cur_points, status, counts, pts_pitch, cam1->width, cam1->height, out, cap, out_counts))) return rc;
+    if (reject && pts_pitch) {
+        /* matcher.cpp:751-755: rejectWithF(cur_points, F2->GetCVKeys(), status); then the matches of what is left. Pairs whose
+         * tracked points take OpenCV's LMedS branch (8..14 of them) are left as they are (see tb_reject_with_f). */
+        void *work, *fl;
+        if ((rc = tb_scratch(ctx, 8, tbk_ransac_work_bytes(npairs, pts_pitch), &work))) return rc;
+        if ((rc = tb_scratch(ctx, 9, (size_t)npairs * sizeof(int32_t), &fl))) return rc;
+        if ((rc = tbk_ransac_f(ctx, npairs, cur_points, keys2_xy, status, counts, pts_pitch, 0, 1.0, 0.99, work, (int32_t*)fl, nullptr, nullptr)))
+            return rc;
+        rc = tbk_flow_accept(ctx, npairs, cur_points, status, counts, pts_pitch, cam1->width, cam1->height, out, cap, out_counts);
+    }
+    return rc;
+}
+
+/* Matcher::rejectWithF / cv::findFundamentalMat, host forms: upload, one workgroup, download */
+static int ransac_host(tb_ctx* ctx, const float* p1, const float* p2, int n, uint8_t* status, int mode, double thresh, double conf,
+                       double* F, int* iters, int* flag) {
+    void *d1, *d2, *dst, *work, *misc;
+    int rc;
+    const size_t nb = (size_t)std::max(n, 1) * 2 * sizeof(float);
+    if ((rc = tb_scratch(ctx, 0, nb, &d1)) || (rc = tb_scratch(ctx, 1, nb, &d2)) || (rc = tb_scratch(ctx, 2, (size_t)std::max(n, 1), &dst)) ||
+        (rc = tb_scratch(ctx, 8, tbk_ransac_work_bytes(1, n), &work)) || (rc = tb_scratch(ctx, 9, 256, &misc)))
+        return rc;
+    hipStream_t s = ctx->stream;
+    TB_HIP(ctx, hipMemcpyAsync(d1, p1, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, s));
+    TB_HIP(ctx, hipMemcpyAsync(d2, p2, (size_t)n * 2 * sizeof(float), hipMemcpyHostToDevice, s));
+    TB_HIP(ctx, hipMemcpyAsync(dst, status, (size_t)n, hipMemcpyHostToDevice, s));
+    int32_t* d_flag = (int32_t*)misc;
+    int32_t* d_iters = d_flag + 1;
+    double* d_F = (double*)((char*)misc + 16);
+    TB_HIP(ctx, hipMemsetAsync(misc, 0, 128, s));
+    if ((rc = tbk_ransac_f(ctx, 1, (const float*)d1, (const float*)d2, (uint8_t*)dst, nullptr, n, mode, thresh, conf, work, d_flag, d_F, d_iters)))
+        return rc;
+    int32_t h[2] = {0, 0};
+    double hF[9];
+    TB_HIP(ctx, hipMemcpyAsync(status, dst, (size_t)n, hipMemcpyDeviceToHost, s));
+    TB_HIP(ctx, hipMemcpyAsync(h, misc, sizeof h, hipMemcpyDeviceToHost, s));
+    TB_HIP(ctx, hipMemcpyAsync(hF, d_F, sizeof hF, hipMemcpyDeviceToHost, s));
+    TB_HIP(ctx, hipStreamSynchronize(s));
+    if (flag) *flag = h[0];
+    if (iters) *iters = h[1];
+    if (F) memcpy(F, hF, sizeof hF);
+    return TB_OK;
+}
+
+int tb_find_fundamental_ransac(tb_ctx* ctx, const float* pts1, const float* pts2, int n, double thresh, double conf, uint8_t* mask,
+                               double* F, int* iters, int* ok) {
+    TB_ENTER(ctx);
+    if (!ctx || n < 0 || !ok || (n && (!pts1 || !pts2 || !mask))) return TB_EINVAL;
+    *ok = 0;
+    if (iters) *iters = 0;
+    if (n < 7) return TB_OK;                     /* cv::findFundamentalMat returns an empty matrix and no mask */
+    int flag = 0;
+    memset(mask, 0, (size_t)n);
+    const int rc = ransac_host(ctx, pts1, pts2, n, mask, 1, thresh, conf, F, iters, &flag);
+    if (rc) return rc;
+    if (flag == 3) return tb_fail(ctx, TB_EUNSUPPORTED, "findFundamentalMat: %d points take OpenCV's LMedS branch (not built)", n);
+    *ok = flag == 0 ? 1 : 0;
+    return TB_OK;
+}
+
+int tb_reject_with_f(tb_ctx* ctx, const float* cur_pts, const float* last_pts, int n, uint8_t* status) {
+    TB_ENTER(ctx);
+    if (!ctx || n < 0 || (n && (!cur_pts || !last_pts || !status))) return TB_EINVAL;
+    if (!(n > 8)) return TB_OK;                  /* matcher.cpp:870: findFundamentalMat is not called */
+    int flag = 0;
+    const int rc = ransac_host(ctx, cur_pts, last_pts, n, status, 0, 1.0, 0.99, nullptr, nullptr, &flag);
+    if (rc) return rc;
+    if (flag == 3) return tb_fail(ctx, TB_EUNSUPPORTED, "rejectWithF: 8..14 tracked points take OpenCV's LMedS branch (not built)");
+    return TB_OK;
+}
+
+int tb_add_map_points_by_stereo_batch_dev(tb_ctx* ctx, int npairs, const uint8_t* img_stereo, const uint8_t* img_current, int width,
+                                          int height, int stride, size_t image_pitch, const tb_camera* cam_stereo, const float* keys_xy,
+                                          const int32_t* counts, int pts_pitch, float bf, float* cur_points, uint8_t* status,
+                                          float* depth) {
+    TB_ENTER(ctx);
+    if (!ctx || !cam_stereo || npairs < 0 || pts_pitch < 0) return TB_EINVAL;
+    if (npairs == 0 || pts_pitch == 0) return TB_OK;
+    if (!depth || !cur_points || !status || !keys_xy) return TB_EINVAL;
+    void *m, *mc;
+    int rc;
+    if ((rc = tb_scratch(ctx, 10, (size_t)npairs * pts_pitch * sizeof(tb_match), &m))) return rc;
+    if ((rc = tb_scratch(ctx, 11, (size_t)npairs * sizeof(int32_t), &mc))) return rc;
+    /* LocalBA.cpp:54: matcher->searchByOPFlow(stereo_frame, current_frame, pts, true, true) */
+    if ((rc = tb_search_by_opflow_batch_dev(ctx, npairs, img_stereo, img_current, width, height, stride, image_pitch, cam_stereo, keys_xy,
+                                            counts, pts_pitch, 1, 1, cur_points, status, (tb_match*)m, pts_pitch, (int32_t*)mc)))
+        return rc;
+    return tbk_stereo_depth(ctx, npairs, cur_points, keys_xy, status, counts, pts_pitch, bf, depth);
+}
+
+int tb_add_map_points_by_stereo(tb_ctx* ctx, const uint8_t* img_stereo, const uint8_t* img_current, int width, int height, int stride,
+                                const tb_camera* cam_stereo, const float* keys_xy, int n, float bf, float* depth, int* n_depth) {
+    TB_ENTER(ctx);
+    if (!ctx || !cam_stereo || n < 0 || !n_depth || (n && (!keys_xy || !depth)) || !img_stereo || !img_current) return TB_EINVAL;
+    *n_depth = 0;
+    for (int i = 0; i < n; i++) depth[i] = -1.0f;
+    if (n == 0) return TB_OK;
+    std::vector<float> cur((size_t)2 * n);
+    std::vector<tb_match> mt((size_t)n);
+    int cnt = 0;
+    const int rc = tb_search_by_opflow(ctx, img_stereo, img_current, width, height, stride, cam_stereo, keys_xy, n, 1, 1, cur.data(),
+                                       mt.data(), n, &cnt);
+    if (rc) return rc;
+    for (int k = 0; k < cnt; k++) {  /* LocalBA.cpp:58-65: left_id = trainIdx, right_id = queryIdx (equal) */
+        const int i = mt[k].trainIdx;
+        depth[i] = bf / fabsf(cur[2 * mt[k].queryIdx] - keys_xy[2 * i]);
+    }
+    *n_depth = cnt;
+    return TB_OK;
 }
 
 }  // extern "C"

@@ -30,8 +30,8 @@ struct tb_ctx {
     std::vector<hipEvent_t> prof_pool;
     std::map<std::string, std::pair<long, double>> prof_acc;
     /* grow-only device scratch for the matcher / pose entry points */
-    void* scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_cap[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    void* scratch[12] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_cap[12] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 int tb_fail(tb_ctx* ctx, int code, const char* fmt, ...);
@@ -193,6 +193,12 @@ int tbk_clahe(tb_ctx* ctx, int nimg, const uint8_t* d_src, int w, int h, int str
               int tiles_y, uint8_t* d_dst, int dstride, size_t dpitch, uint8_t* d_lut);
 int tbk_flow_accept(tb_ctx* ctx, int npairs, const float* d_cur, uint8_t* d_status, const int32_t* d_counts, int pts_pitch, int width,
                     int height, tb_match* d_out, int cap, int32_t* d_out_counts);
+/* RANSAC fundamental matrix (k_ransac.hip): mode 0 = Matcher::rejectWithF on the flagged points, 1 = cv::findFundamentalMat on all */
+size_t tbk_ransac_work_bytes(int npairs, int pts_pitch);
+int tbk_ransac_f(tb_ctx* ctx, int npairs, const float* d_pts1, const float* d_pts2, uint8_t* d_status, const int32_t* d_counts,
+                 int pts_pitch, int mode, double thresh, double conf, void* d_work, int32_t* d_flags, double* d_F, int32_t* d_iters);
+int tbk_stereo_depth(tb_ctx* ctx, int npairs, const float* d_cur, const float* d_keys, const uint8_t* d_status, const int32_t* d_counts,
+                     int pts_pitch, float bf, float* d_depth);
 size_t tbk_lk_work_bytes(int w, int h, int max_level, int npairs);
 int tbk_lk_track(tb_ctx* ctx, int npairs, const uint8_t* d_prev, const uint8_t* d_next, int w, int h, int stride, size_t image_pitch,
                  const float* d_prev_pts, const int32_t* d_counts, int n, int pts_pitch, int win, int max_level, float* d_next_pts,

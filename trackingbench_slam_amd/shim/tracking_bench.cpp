@@ -234,11 +234,11 @@ namespace TRACKING_BENCH
         return out;
     }
 
-    /* SURVEY 8(f) row 2, first part: Matcher::searchByOPFlow (reference matcher.cpp:724-768) on tb_search_by_opflow */
+    /* Matcher::searchByOPFlow (reference matcher.cpp:724-768) on tb_search_by_opflow; reject = true runs
+     * Matcher::rejectWithF (cv::findFundamentalMat RANSAC restated, parity unpinned) on the device as well */
     std::vector<cv::DMatch> Matcher::searchByOPFlow(const std::shared_ptr<Frame>& F1, const std::shared_ptr<Frame>& F2,
                                                     std::vector<cv::Point2f>& cur_points, bool equalized, bool reject, bool MapPointOnly)
     {
-        if (reject) throw std::invalid_argument("Matcher::searchByOPFlow: reject (rejectWithF, RANSAC fundamental matrix) is not built");
         (void)MapPointOnly; /* the reference ignores it as well */
         cv::Mat img1 = F1->GetImage(), img2 = F2->GetImage();
         if (img1.cols != img2.cols || img1.rows != img2.rows) throw std::invalid_argument("Matcher::searchByOPFlow: image sizes differ");
@@ -251,12 +251,22 @@ namespace TRACKING_BENCH
         cam.width = F1->GetCameraModel()->Width(); cam.height = F1->GetCameraModel()->Height();
         std::vector<cv::DMatch> out(std::max<size_t>(k2.size(), 1));
         int n = 0;
-        check(tb_search_by_opflow(shim_ctx(), img1.data, img2.data, img1.cols, img1.rows, (int)img1.step, &cam, xy.data(), (int)k2.size(), equalized ? 1 : 0, 0,
+        check(tb_search_by_opflow(shim_ctx(), img1.data, img2.data, img1.cols, img1.rows, (int)img1.step, &cam, xy.data(), (int)k2.size(), equalized ? 1 : 0, reject ? 1 : 0,
                                   cur.data(), reinterpret_cast<tb_match*>(out.data()), (int)out.size(), &n), "Matcher::searchByOPFlow");
         cur_points.resize(k2.size());
         for (size_t i = 0; i < k2.size(); i++) cur_points[i] = cv::Point2f(cur[2 * i], cur[2 * i + 1]);
         out.resize(n);
         return out;
+    }
+
+    /* Matcher::rejectWithF (reference matcher.cpp:853-881) on tb_reject_with_f */
+    void Matcher::rejectWithF(std::vector<cv::Point2f>& cur_pts, const std::vector<cv::Point2f>& last_pts, std::vector<uchar>& status)
+    {
+        const size_t n = status.size();
+        if (cur_pts.size() < n || last_pts.size() < n) throw std::out_of_range("Matcher::rejectWithF: fewer points than status flags");
+        std::vector<float> a(2 * std::max<size_t>(n, 1)), b(2 * std::max<size_t>(n, 1));
+        for (size_t i = 0; i < n; i++) { a[2 * i] = cur_pts[i].x; a[2 * i + 1] = cur_pts[i].y; b[2 * i] = last_pts[i].x; b[2 * i + 1] = last_pts[i].y; }
+        check(tb_reject_with_f(shim_ctx(), a.data(), b.data(), (int)n, status.data()), "Matcher::rejectWithF");
     }
 
     /* the projection matchers (reference matcher.cpp:406-617) on tb_search_by_projection[_map] */
@@ -389,9 +399,28 @@ namespace TRACKING_BENCH
         return inliers;
     }
 
-    std::vector<float> LocalBA::AddMapPointsByStereo(const std::shared_ptr<Frame>&, const std::shared_ptr<Frame>&, float, float)
+    /* LocalBA::AddMapPointsByStereo (reference LocalBA.cpp:46-68) on tb_add_map_points_by_stereo: the current frame's keys
+     * tracked into the equalised stereo image, epipolar outliers rejected, depth = bf / |dx|. fx is unused there too; the
+     * reference's drawing / imshow (:56-67) is dropped. */
+    std::vector<float> LocalBA::AddMapPointsByStereo(const std::shared_ptr<Frame>& current_frame, const std::shared_ptr<Frame>& stereo_frame,
+                                                     const float bf, const float fx)
     {
-        throw std::logic_error("LocalBA::AddMapPointsByStereo (LK optical flow) is outside the hot-path scope (SURVEY.md a16)");
+        (void)fx;
+        cv::Mat img_s = stereo_frame->GetImage(), img_c = current_frame->GetImage();
+        if (img_s.cols != img_c.cols || img_s.rows != img_c.rows) throw std::invalid_argument("LocalBA::AddMapPointsByStereo: image sizes differ");
+        std::vector<tb_keypoint> k;
+        frame_keys(current_frame, k);
+        const size_t N = k.size();
+        std::vector<float> xy(2 * std::max<size_t>(N, 1)), depth(std::max<size_t>(N, 1), -1.0f);
+        for (size_t i = 0; i < N; i++) { xy[2 * i] = k[i].x; xy[2 * i + 1] = k[i].y; }
+        tb_camera cam;
+        std::memset(&cam, 0, sizeof cam);
+        cam.width = stereo_frame->GetCameraModel()->Width(); cam.height = stereo_frame->GetCameraModel()->Height();
+        int nd = 0;
+        check(tb_add_map_points_by_stereo(shim_ctx(), img_s.data, img_c.data, img_s.cols, img_s.rows, (int)img_s.step, &cam, xy.data(), (int)N, bf,
+                                          depth.data(), &nd), "LocalBA::AddMapPointsByStereo");
+        depth.resize(N);
+        return depth;
     }
 
     Eigen::Vector3f LocalBA::LinearTriangle(const Eigen::Vector2f& p0, const Eigen::Vector2f& p1, const Eigen::Matrix4f& Tcw0,
