@@ -3,7 +3,7 @@
  *   LocalBA::AddMapPointsByStereo's depth step (src/mapping/LocalBA.cpp:54-66): depth = bf / |x_tracked - x_key|
  *
  * cv::findFundamentalMat is OpenCV 3.3 (calib3d/fundam.cpp, ptsetreg.cpp), not part of the reference tree: restated,
- * PARITY UNPINNED. oracle/oracle_fund.cpp says line by line what is OpenCV's structure (cv::RNG((uint64)-1) sampling with
+ * PARITY UNPINNED. The CPU restatement (oracle_fund.cpp, test infrastructure) says line by line what is OpenCV's structure (cv::RNG((uint64)-1) sampling with
  * getSubset's duplicate redraws and collinearity retries, up to three 7-point models per sample, symmetric epipolar
  * distance against (float)(threshold^2), "first strictly better" model update, RANSACUpdateNumIters) and which two numerical
  * routines are deliberately not (null space by Gauss-Jordan instead of a Jacobi SVD with random completion, cubic roots
