@@ -115,7 +115,7 @@ def pmc_traffic(kernel, units, geometry=None, detail=False):
             with open(path) as f:
                 doc = json.load(f)
             rec = doc["kernels"]
-            key = kernel if kernel in rec else {"k_resize": "k_resize_lds"}.get(kernel, kernel)
+            key = kernel if kernel in rec else {"k_resize": "k_resize_lds", "k_fast_cells": "k_fast_blocks"}.get(kernel, kernel)   # profile names
             if key not in rec:
                 continue
             # round-1 files carry no units: they were taken at 64 stereo frames (128 images) / 64 windows per launch

@@ -1,5 +1,6 @@
 #!/usr/bin/env python3
-"""Driver for rocprofv3 passes over the local-BA kernels: W windows of the bench size, a few runs."""
+"""Driver for rocprofv3 passes and quick timing of the local-BA kernels: W windows of the bench size (10 keyframes, 5000
+points, 10 LM iterations), a few runs, per-kernel HIP-event times. Usage: python tools/prof_ba.py [windows] [reps] [distinct]"""
 import os
 import sys
 
@@ -10,10 +11,18 @@ from trackingbench_slam_amd.ba import BatchedLocalBA  # noqa: E402
 
 W = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+distinct = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 torch.cuda.set_device(0)
-ctx = capi.Context(0)  # own stream; torch.cuda.synchronize() below is device-wide
-ba = BatchedLocalBA(ctx, W, 10, 5000, 10, 0, torch.device("cuda", 0))
+ctx = capi.Context(0)  # own stream; BatchedLocalBA waits for its reset copies on the host
+ba = BatchedLocalBA(ctx, W, 10, 5000, 10, 0, torch.device("cuda", 0), distinct=distinct)
+ba.run()
+torch.cuda.synchronize()
+ctx.profile_enable(True)
 for _ in range(reps):
     ba.run()
 torch.cuda.synchronize()
+rep = ctx.profile_report()
+for k, (c, ms) in sorted(rep.items()):
+    print("%-16s %4d launches  %9.4f ms / run" % (k, c // reps, ms / reps))
+print("chain %.4f ms / run (%d windows)" % (sum(ms for _, ms in rep.values()) / reps, W))
 print("done", ba.stats[0].tolist())

@@ -375,10 +375,48 @@ k_ba_points(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
 }
 
 /* ---- B: keyframe pass: Hpp (21 unique) + bp (6) per free keyframe, chunked tree reductions */
+/* Sum of 27 per-thread doubles over the 256 threads of a workgroup, result in threads 0..26 (value = thread index).
+ * A butterfly of wave shuffles costs 12 LDS permutes and 6 adds PER VALUE (64-bit values travel as two dwords): 324
+ * permutes per wavefront, more than the keyframe pass spends on its edges. Here every lane stores its values once, 14 at a
+ * time ([value][lane], row stride 65 doubles: conflict-free both ways), four lanes per value add 16 partials each in lane
+ * order, one lane adds the four quarter sums, and threads 0..26 add the four wavefronts' sums: ~110 LDS / add slots per
+ * wavefront, every sum of fixed shape. sh: 4 * (14 * 65 + 64) + 4 * 27 doubles. */
+#define BA_KFR_LDS (4 * (14 * 65 + 64) + 4 * 27)
+__device__ __forceinline__ double ba_block_sum27(const double (&v)[27], double* sh) {
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    double* T = sh + wave * (14 * 65 + 64);       /* this wavefront's transpose tile */
+    double* Qs = T + 14 * 65;                     /* its 56 quarter sums */
+    double* red = sh + 4 * (14 * 65 + 64);        /* [4][27] wavefront sums */
+#pragma unroll
+    for (int g = 0; g < 2; g++) {
+        const int nv = g == 0 ? 14 : 13;
+#pragma unroll
+        for (int i = 0; i < 14; i++)
+            if (i < nv) T[i * 65 + lane] = v[14 * g + i];
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        const int q = lane / 14, i = lane - 14 * q;    /* lanes 0..55: quarter q of value i */
+        if (lane < 56 && i < nv) {
+            const double* src = T + i * 65 + 16 * q;
+            double s = src[0];
+#pragma unroll
+            for (int k = 1; k < 16; k++) s += src[k];
+            Qs[lane] = s;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+        if (lane < nv) red[wave * 27 + 14 * g + lane] = (Qs[lane] + Qs[14 + lane]) + (Qs[28 + lane] + Qs[42 + lane]);
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
+    }
+    __syncthreads();
+    double r = 0;
+    if (tid < 27) r = (red[tid] + red[27 + tid]) + (red[54 + tid] + red[81 + tid]);
+    __syncthreads();
+    return r;
+}
+
 __global__ void __launch_bounds__(BA_T)
 k_ba_kf(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw, const int* __restrict__ iw,
         const BaState* __restrict__ states) {
-    __shared__ double red[4 * 27];
+    __shared__ double red[BA_KFR_LDS];
     const int w = blockIdx.z, kf = d.nfixed + blockIdx.y, tid = threadIdx.x;
     const BaState st = states[w];
     if (st.status || !st.need_lin) return;
@@ -430,13 +468,8 @@ k_ba_kf(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw,
                 for (int c = a; c < 6; c++) acc[a * 6 - (a * (a - 1)) / 2 + (c - a)] += ww * (Jp[a] * Jp[c] + Jp[6 + a] * Jp[6 + c]);
             }
         }
-        po_block_sum<27>(acc, red);
-        if (tid == 0) { /* static indices only: a lane-indexed read of acc[] would push it to scratch */
-            double* o = D + d.oPartKF + ((size_t)blockIdx.y * d.kfChunks + chunk) * 27;
-#pragma unroll
-            for (int i = 0; i < 27; i++) o[i] = acc[i];
-        }
-        __syncthreads();
+        const double tot = ba_block_sum27(acc, red);
+        if (tid < 27) D[d.oPartKF + ((size_t)blockIdx.y * d.kfChunks + chunk) * 27 + tid] = tot;
     }
 }
 
