@@ -26,3 +26,16 @@ for k, (c, ms) in sorted(rep.items()):
     print("%-16s %4d launches  %9.4f ms / run" % (k, c // reps, ms / reps))
 print("chain %.4f ms / run (%d windows)" % (sum(ms for _, ms in rep.values()) / reps, W))
 print("done", ba.stats[0].tolist())
+
+import ctypes as C
+if hasattr(capi.lib(), "tb_debug_ba_times"):
+    buf = (C.c_ulonglong * 16)()
+    capi.lib().tb_debug_ba_times(buf, 1)
+    ba.run(); torch.cuda.synchronize()
+    capi.lib().tb_debug_ba_times(buf, 1)
+    ngr = max(buf[6], 1)
+    names = ["stage + linearise", "preload issue", "rhs", "mfma", "clear", "between groups"]
+    tot = sum(buf[i] for i in range(6))
+    for i, nm in enumerate(names):
+        print("  %-18s %8.0f clk/group  %5.1f%%" % (nm, buf[i] / ngr, 100.0 * buf[i] / max(tot, 1)))
+    print("  groups sampled %d, points per group %.2f" % (ngr, buf[7] / ngr))

@@ -37,6 +37,8 @@
 #define BA_KFCH 1024          /* edges per keyframe-pass chunk */
 #define BA_KFBLK 4            /* workgroups per keyframe in the keyframe pass */
 #define BA_BIG_MAXF 64        /* free keyframes of a large window (6 bits of the free-edge key) */
+#define BA_GP 14              /* points per Schur group at most (k_ba_schur_g) */
+#define BA_GRP_MAXPT 32768    /* windows up to this many points get a group table (one byte of LDS per point in the setup) */
 
 struct BaState {
     double lambda, ni, currentChi, chi0, scale_p, rho;
@@ -56,6 +58,8 @@ struct BaDims {
     unsigned long long wstride, oT, oP, oHll, oBl, oHq, oHpp, oBp, oXp, oPartKF, oPartP, oPartS;
     /* per-window offsets, in ints, into the int workspace */
     unsigned long long istride, oPtStart, oPtFree, oKfStart, oKfEdges, oFreeKP;
+    unsigned long long oGrp;     /* ints: point groups of the Schur kernel (grp[0..ng], ng at [npt + 1]); grouped != 0 if built */
+    int grouped, pad1;
 };
 
 typedef double ba_d4 __attribute__((ext_vector_type(4)));
@@ -261,6 +265,30 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
             });
         for (int p = max((nobs > 0 ? obs[nobs - 1].pt : -1) + 1, 0) + tid; p <= d.npt; p += BA_T) I[d.oPtFree + p] = nfreeE;
         __syncthreads();
+        if (d.grouped) {
+            /* point groups of k_ba_schur_g: maximal runs of whole points with at most BA_GP points and 64 free-keyframe
+             * edges (one lane per edge), greedy from point 0. Every thread finds where a group that starts at its point
+             * would end (15 independent loads), one thread then walks the chain through LDS (~npt / 12 steps). */
+            __shared__ unsigned char span[BA_GRP_MAXPT];
+            __threadfence_block();
+            for (int p = tid; p < d.npt; p += BA_T) {
+                int pf[BA_GP + 1];
+#pragma unroll
+                for (int i = 0; i <= BA_GP; i++) pf[i] = I[d.oPtFree + min(p + i, d.npt)];
+                int n = 1;
+#pragma unroll
+                for (int i = 2; i <= BA_GP; i++)
+                    if (n == i - 1 && p + i <= d.npt && pf[i] - pf[0] <= 64) n = i;
+                span[p] = (unsigned char)n;
+            }
+            __syncthreads();
+            if (tid == 0) {
+                int g = 0;
+                for (int p = 0; p < d.npt; p += span[p]) I[d.oGrp + g++] = p;
+                I[d.oGrp + g] = d.npt;
+                I[d.oGrp + d.npt + 1] = g;
+            }
+        }
         return;
     }
     if (tid == 0) {
@@ -714,6 +742,213 @@ k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ 
         __syncthreads();
     }
     double* out = D + d.oPartS + (size_t)g * 64 * 64;
+    for (int i = tid; i < 64 * 64; i += BA_T) {
+        const int r = i >> 6, c = i & 63, rt = r >> 4, ct = c >> 4;
+        if (rt < R && (ct <= rt || (c == d.np && r < d.np))) out[i] = sum[i];
+    }
+}
+
+/* ---- D, grouped form (round 2). The chunk kernel above spends as long in its FP64 VECTOR phase as in its MFMA phase:
+ * the two run on the same units and add up (18 MFMAs x 64 clocks + ~1500 clocks of linearisation per 4-point chunk and
+ * SIMD: 212 k chunks x 2650 clocks / 1024 SIMDs = the measured 229 us per 170-window launch), and the vector phase runs on
+ * the ~16 live lanes (one per free-keyframe edge) of 64. Here a wavefront takes a GROUP of whole points with up to 64
+ * free-keyframe edges (k_ba_setup's greedy table: at most BA_GP points): ONE linearisation pass at ~70 % live lanes
+ * fills a 48 x 44 tile, then the k-steps of the MFMA phase walk its columns. Records are prefetched one group ahead per
+ * register set (an edge record and three point-record doubles per lane); the point records go through LDS, where the
+ * edges of a point and the rhs pass (lane = row, U^T bl as LDS broadcasts) read them. */
+#define BA_GLD 45                       /* tile row stride in doubles: 3 BA_GP = 42 columns, padded to 44 by the k-steps, + 1 */
+#define BA_GHI (BA_GP * BA_REC)         /* 168 doubles of point records */
+#define BA_GWAVE_LDS_R(R) (16 * (R) * BA_GLD + 192 + 4)
+struct BaPreG {
+    int key;          /* lane < edges of the group: pt << 6 | free keyframe index, else -1 */
+    float u, v, w;
+    double r0, r1, r2;/* doubles lane, 64 + lane, 128 + lane of the group's point records */
+    int cp0, cnp;     /* the group whose records the set holds: first point, number of points */
+    int p0, p1, e0, e1; /* the group this set fetches NEXT: points [p0, p1), compact edges [e0, e1) */
+};
+
+#ifdef BA_TIMING   /* debug build: shader clocks of the grouped Schur kernel's phases (wavefront 0 of every block) */
+__device__ unsigned long long ba_times[16];
+extern "C" int tb_debug_ba_times(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ba_times), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(ba_times), z, sizeof z); }
+    return 0;
+}
+#define BA_TK(i) do { const unsigned long long t1_ = __builtin_readcyclecounter(); tk_[i] += t1_ - t0_; t0_ = t1_; } while (0)
+#else
+#define BA_TK(i) do { } while (0)
+#endif
+
+template <int R>
+__global__ void __launch_bounds__(BA_T, 2)
+k_ba_schur_g(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw, const int* __restrict__ iw,
+             BaState* __restrict__ states) {
+    extern __shared__ __attribute__((aligned(16))) double lds[];
+    __shared__ double sRtf[10 * 12];
+    const int w = blockIdx.y, g0 = blockIdx.x, tid = threadIdx.x;
+    const BaState st = states[w];
+    if (st.status) return;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    constexpr int ROWS = 16 * R, WAVE_LDS = BA_GWAVE_LDS_R(R);
+    double* Zl = lds + (size_t)wave * WAVE_LDS;    /* [ROWS][BA_GLD] */
+    double* Hi = Zl + ROWS * BA_GLD;               /* [BA_GP][BA_REC], then a sink */
+    double* D = dw + (size_t)w * d.wstride;
+    const int* I = iw + (size_t)w * d.istride;
+    for (int k = tid; k < d.nfree; k += BA_T) ba_pose_to_Rt(D + d.oT + ((size_t)st.cur * d.nkf + d.nfixed + k) * 7, sRtf + k * 12);
+    ba_d4 acc[BA_MAXT][BA_MAXT];
+#pragma unroll
+    for (int r = 0; r < BA_MAXT; r++)
+#pragma unroll
+        for (int c = 0; c < BA_MAXT; c++) acc[r][c] = (ba_d4){0, 0, 0, 0};
+    for (int i = lane; i < ROWS * BA_GLD; i += 64) Zl[i] = 0;
+    __syncthreads();
+    const double delta = (double)sqrtf(5.991f);
+    const int ng = I[d.oGrp + d.npt + 1];
+    const int stride = d.G * 4, pf = 2 * stride;
+    const int lastG = ng - 1, lastE = d.obs_pitch - 1;
+    const double* Hq = D + d.oHq;
+    const int4* KP = reinterpret_cast<const int4*>(I + d.oFreeKP);
+    const unsigned lastQ = (unsigned)d.npt * BA_REC - 1u;
+    auto range = [&](BaPreG& X, int g) {
+        const int gc = min(g, lastG);
+        X.p0 = I[d.oGrp + gc];
+        X.p1 = (g <= lastG) ? I[d.oGrp + gc + 1] : X.p0;      /* past the end: an empty group */
+        X.e0 = I[d.oPtFree + X.p0];
+        X.e1 = I[d.oPtFree + X.p1];
+    };
+    auto preload = [&](BaPreG& X, int g) {   /* X.p0.. = range of group g (fetched one fill earlier); then the range of g + pf */
+        const int4 r = KP[(unsigned)min(X.e0 + lane, lastE)];
+        X.key = (lane < X.e1 - X.e0) ? r.x : -1;
+        X.u = __int_as_float(r.y); X.v = __int_as_float(r.z); X.w = __int_as_float(r.w);
+        const unsigned qb = (unsigned)X.p0 * BA_REC + (unsigned)lane;
+        X.r0 = Hq[min(qb, lastQ)];
+        X.r1 = Hq[min(qb + 64u, lastQ)];
+        X.r2 = Hq[min(qb + 128u, lastQ)];
+        X.cp0 = X.p0;
+        X.cnp = X.p1 - X.p0;
+        range(X, g + pf);
+    };
+    const int kofs = lane >> 4, l15 = lane & 15;
+    double rhs = 0;
+#ifdef BA_TIMING
+    unsigned long long tk_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0_ = __builtin_readcyclecounter();
+#endif
+    auto group = [&](BaPreG& X, int g) {
+        const int p0 = X.cp0, npts = X.cnp;
+        BA_TK(5);
+        Hi[lane] = X.r0;
+        Hi[64 + lane] = X.r1;
+        Hi[128 + lane] = X.r2;                    /* doubles 168..191: spare */
+        ba_wave_lds_fence();
+        const bool live = X.key >= 0;
+        const int pl = live ? (X.key >> 6) - p0 : 0, kf = live ? (X.key & 63) : 0;
+        const int zoff = (6 * kf) * BA_GLD + 3 * pl;
+        if (live) {
+            const double* q = Hi + pl * BA_REC;
+            const double u00 = q[0], u01 = q[1], u02 = q[2], u11 = q[3], u12 = q[4], u22 = q[5];
+            const double Xp[3] = {q[9], q[10], q[11]};
+            BaLin L;
+            double Jp[12];
+            ba_linearize(sRtf + kf * 12, Xp, X.u, X.v, X.w, d.fx, d.fy, d.cx, d.cy, delta, L);
+            ba_jac_pose_iz(L.pc, L.invz, d.fx, d.fy, Jp);
+            double JU[6];
+#pragma unroll
+            for (int r = 0; r < 2; r++) {
+                JU[3 * r] = L.Jl[3 * r] * u00;
+                JU[3 * r + 1] = L.Jl[3 * r] * u01 + L.Jl[3 * r + 1] * u11;
+                JU[3 * r + 2] = L.Jl[3 * r] * u02 + L.Jl[3 * r + 1] * u12 + L.Jl[3 * r + 2] * u22;
+            }
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+                const double p0w = L.ww * Jp[a], p1w = L.ww * Jp[6 + a];
+                double* z = Zl + zoff + a * BA_GLD;
+                z[0] = p0w * JU[0] + p1w * JU[3];
+                z[1] = p0w * JU[1] + p1w * JU[4];
+                z[2] = p0w * JU[2] + p1w * JU[5];
+            }
+        }
+        ba_wave_lds_fence();
+        BA_TK(0);
+        /* the set is free: the range of its next group came in one fill ago -- issue that group's loads now */
+        preload(X, g + pf);
+        BA_TK(1);
+        /* reduced right-hand side: lane = row of Z, U^T bl of the group's points as LDS broadcasts (measured: unrolling this
+         * loop -- four points per step, or all 14 -- costs registers and time; the FP64 pipe is shared with the MFMAs of the
+         * SIMD's other wavefront either way) */
+        {
+            const double* zr = Zl + min(lane, ROWS - 1) * BA_GLD;
+            for (int pnt = 0; pnt < npts; pnt++) {
+                const double* b = Hi + pnt * BA_REC + 6;
+                rhs = fma(zr[3 * pnt], b[0], rhs);
+                rhs = fma(zr[3 * pnt + 1], b[1], rhs);
+                rhs = fma(zr[3 * pnt + 2], b[2], rhs);
+            }
+        }
+        BA_TK(2);
+        /* k-steps over the tile's columns (a hand-pipelined form -- operand rows of step ks + 1 read during the MFMAs of
+         * step ks -- measured 4 % slower) */
+        const int nks = (3 * npts + 3) >> 2;
+        for (int ks = 0; ks < nks; ks++) {
+            double av[BA_MAXT];
+#pragma unroll
+            for (int t = 0; t < BA_MAXT; t++) av[t] = (t < R) ? Zl[(16 * t + l15) * BA_GLD + 4 * ks + kofs] : 0.0;
+#pragma unroll
+            for (int r = 0; r < BA_MAXT; r++)
+#pragma unroll
+                for (int cc = 0; cc < BA_MAXT; cc++)
+                    if (r < R && cc <= r)
+                        acc[r][cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[r], av[cc], acc[r][cc], 0, 0, 0);
+        }
+        BA_TK(3);
+        ba_wave_lds_fence();
+        if (live) {
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+                double* z = Zl + zoff + a * BA_GLD;
+                z[0] = z[1] = z[2] = 0;
+            }
+        }
+        ba_wave_lds_fence();
+        BA_TK(4);
+#ifdef BA_TIMING
+        tk_[6] += 1; tk_[7] += (unsigned long long)npts;
+#endif
+    };
+    if (ng > 0) {
+        BaPreG A, B;
+        int g = g0 * 4 + wave;
+        range(A, g);
+        range(B, g + stride);
+        preload(A, g);
+        preload(B, g + stride);
+        for (; g + stride < ng; g += 2 * stride) {
+            group(A, g);
+            group(B, g + stride);
+        }
+        if (g < ng) group(A, g);
+    }
+#ifdef BA_TIMING
+    if (tid == 0 && (w & 15) == 0) for (int i = 0; i < 8; i++) atomicAdd(&ba_times[i], tk_[i]);
+#endif
+    __syncthreads();
+    double* sum = lds;
+    for (int wv = 0; wv < 4; wv++) {
+        if (wave == wv) {
+#pragma unroll
+            for (int r = 0; r < BA_MAXT; r++)
+#pragma unroll
+                for (int c = 0; c < BA_MAXT; c++)
+                    if (r < R && c <= r)
+                        for (int q = 0; q < 4; q++) {
+                            const int idx = (16 * r + (lane >> 4) + 4 * q) * 64 + 16 * c + (lane & 15);
+                            sum[idx] = (wv == 0) ? acc[r][c][q] : sum[idx] + acc[r][c][q];
+                        }
+            ba_wave_lds_fence();
+            if (lane < d.np) sum[lane * 64 + d.np] = (wv == 0) ? rhs : sum[lane * 64 + d.np] + rhs;
+        }
+        __syncthreads();
+    }
+    double* out = D + d.oPartS + (size_t)g0 * 64 * 64;
     for (int i = tid; i < 64 * 64; i += BA_T) {
         const int r = i >> 6, c = i & 63, rt = r >> 4, ct = c >> 4;
         if (rt < R && (ct <= rt || (c == d.np && r < d.np))) out[i] = sum[i];
@@ -1370,6 +1605,8 @@ static void ba_dims(BaDims& d, int W, const double K[4], int nkf, int nfixed, in
     d.oKfStart = itake(nkf + 1);
     d.oKfEdges = itake(obs_pitch);
     d.oFreeKP = itake(4ull * obs_pitch);
+    d.grouped = (!d.big && npt <= BA_GRP_MAXPT) ? 1 : 0;
+    d.oGrp = itake(d.grouped ? (unsigned long long)npt + 2 : 0);
     d.oPairStart = itake(d.big ? d.npairs + 1 : 0);
     d.oPairCnt = itake(d.big ? d.npairs : 0);
     d.oPairItems = itake(d.big ? 2 * d.maxItems : 0);
@@ -1454,10 +1691,16 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
             tb_prof_begin(ctx, "k_ba_schur");
             {
                 const int R = (d.np + 15) >> 4;
-                void (*ks)(BaDims, const tb_ba_obs*, double*, const int*, BaState*) =
-                    R == 1 ? k_ba_schur<1> : R == 2 ? k_ba_schur<2> : R == 3 ? k_ba_schur<3> : k_ba_schur<4>;
-                TB_HIP(ctx, hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-                hipLaunchKernelGGL(ks, dim3(d.G, W), dim3(BA_T), lds, s, d, d_obs, dw, iw, states);
+                typedef void (*schur_t)(BaDims, const tb_ba_obs*, double*, const int*, BaState*);
+                /* whole-point groups of up to 64 edges (k_ba_schur_g) wherever the setup built the group table;
+                 * TB_BA_SCHUR=chunk keeps the 4-point chunk kernel (A/B measurements) */
+                const char* sel = getenv("TB_BA_SCHUR");
+                const bool grouped = d.grouped && !(sel && sel[0] == 'c');
+                const schur_t ks = grouped ? (R == 1 ? (schur_t)k_ba_schur_g<1> : R == 2 ? (schur_t)k_ba_schur_g<2> : R == 3 ? (schur_t)k_ba_schur_g<3> : (schur_t)k_ba_schur_g<4>)
+                                           : (R == 1 ? (schur_t)k_ba_schur<1> : R == 2 ? (schur_t)k_ba_schur<2> : R == 3 ? (schur_t)k_ba_schur<3> : (schur_t)k_ba_schur<4>);
+                const size_t lds_k = grouped ? std::max<size_t>(4 * (size_t)BA_GWAVE_LDS_R(R), (size_t)16 * R * 64) * sizeof(double) : lds;
+                TB_HIP(ctx, hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k));
+                hipLaunchKernelGGL(ks, dim3(d.G, W), dim3(BA_T), lds_k, s, d, d_obs, dw, iw, states);
             }
             tb_prof_end(ctx);
             tb_prof_begin(ctx, "k_ba_solve");
