@@ -1,7 +1,7 @@
 /* Header shim: the hot-path slice of TRACKING_BENCH::Matcher with the reference's signatures
  * (reference include/matchers/matcher.h:18-80,149-150) on the C ABI (tb_search_by_bf,
- * tb_search_by_violence, tb_search_by_projection, tb_search_by_projection_map, tb_search_by_opflow). The BoW, NN(LSH)
- * and direct-alignment matchers are out of scope (SURVEY.md sections 2 and 8f). */
+ * tb_search_by_violence, tb_search_by_bow, tb_search_by_projection, tb_search_by_projection_map, tb_search_by_opflow).
+ * The NN(LSH) and direct-alignment matchers are out of scope (SURVEY.md sections 2 and 8f). */
 #ifndef TRACKING_BENCH_MATCHER_H
 #define TRACKING_BENCH_MATCHER_H
 #include <memory>
@@ -65,6 +65,13 @@ namespace TRACKING_BENCH
         std::vector<cv::DMatch> searchByProjection(
                 const std::shared_ptr<Map>& map,
                 const std::shared_ptr<Frame>& F1, float r);
+
+        // reference :91-94, matcher.cpp:619-721: matches inside the vocabulary nodes the two frames share
+        // (F->GetFeatureVector() filled by the caller / ComputeBoW)
+        std::vector<cv::DMatch> searchByBow(
+                const std::shared_ptr<Frame>& F1,
+                const std::shared_ptr<Frame>& F2,
+                bool MapPointOnly = false);
 
         // Optical flow (reference :96-103, matcher.cpp:724-768). reject = true runs rejectWithF (below) before the matches
         // are listed, as the reference's caller LocalBA::AddMapPointsByStereo (LocalBA.cpp:54) asks.

@@ -125,6 +125,18 @@ int tb_search_by_violence(tb_ctx* ctx, const tb_keypoint* k1, const uint8_t* d1,
                           int min_level, int max_level, float radius, int th_low, float nratio,
                           int histo_len, int check_orientation, tb_match* out, int cap, int* count);
 
+/* SURVEY 8(f) row 4 -- Matcher::searchByBow(F1, F2, MapPointOnly), matcher.cpp:619-721. The frames' DBoW2 feature vectors
+ * (Frame::GetFeatureVector(), a std::map<NodeId, std::vector<unsigned>> filled by voc->transform(.., 4), Frame.cpp:269)
+ * are INPUTS: nodesX = node ids in ascending order (the map's order), startX[nnX + 1] / itemsX = the nodes' feature index
+ * lists as CSR, in insertion order. DBoW2 and its vocabulary stay outside this library (the reference tree ships no
+ * vocabulary file). has_mp2 (nullable, n2 bytes): F2->GetMapPoint(i) != nullptr, read when map_point_only is set.
+ * th_low / nratio / histo_len / check_orientation = the Matcher's TH_LOW / nRatio / HISTO_LENGTH / checkOrientation.
+ * Matches: queryIdx = F1 key, trainIdx = F2 key, imgIdx = -1, distance = Hamming, in the reference's order. */
+int tb_search_by_bow(tb_ctx* ctx, const tb_keypoint* k1, const uint8_t* d1, int n1, const uint32_t* nodes1, const int32_t* start1,
+                     const uint32_t* items1, int nn1, const tb_keypoint* k2, const uint8_t* d2, int n2, const uint8_t* has_mp2,
+                     const uint32_t* nodes2, const int32_t* start2, const uint32_t* items2, int nn2, int map_point_only, int th_low,
+                     float nratio, int histo_len, int check_orientation, tb_match* out, int cap, int* count);
+
 /* SURVEY 8(f) row 1 -- Matcher::searchByProjection(F1, F2), matcher.cpp:406-531 (+ Frame::GetFeaturesInArea,
  * Frame.cpp:202-255; PinholeCamera::World2Cam, CameraModel.cpp:63-93; CameraModel::IsInFrame, CameraModel.h:33-39).
  * F1 = current frame: pose Tcw1 (row-major 4x4), camera, level-0 image size (lookup-grid factors), keys k1,

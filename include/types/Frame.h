@@ -86,6 +86,8 @@ namespace TRACKING_BENCH
         std::vector<std::shared_ptr<Feature>>& GetKeys(){return mvKeys;}
         std::shared_ptr<Feature>& GetKey(size_t id){return mvKeys.at(id);}
         cv::Mat GetDescriptors() const{return mDescriptors;}
+        // reference Frame.h:98 (filled by ComputeBoW, Frame.cpp:266-271; here the caller fills it, the vocabulary is not part of the path)
+        DBoW2::FeatureVector& GetFeatureVector(){return mFeatVec;}
         bool GetOutlier(size_t id){return mvbOutlier.at(id) != 0;}
         void SetOutlier(size_t id, bool state){mvbOutlier.at(id)=state;}
         std::vector<float> inline GetScaleSigmaSquares() { return mvLevelSigma2; }
@@ -110,6 +112,7 @@ namespace TRACKING_BENCH
         Eigen::Vector3f mOw;
         std::vector<std::shared_ptr<Feature>> mvKeys;
         cv::Mat mDescriptors;
+        DBoW2::FeatureVector mFeatVec;
         std::vector<std::shared_ptr<MapPoint>> mvpMapPoints;
         std::shared_ptr<CameraModel> mpCamera = nullptr;
         int nLevels;

@@ -254,6 +254,33 @@ def search_by_violence(k1, d1, k2, d2, img2_w, img2_h, min_level=0, max_level=1,
     return out[:n].copy()
 
 
+def _fv(fv):
+    """DBoW2 feature vector {node id: [feature indices]} -> (nodes u32 ascending, start i32, items u32)."""
+    nodes = np.array(sorted(fv), np.uint32)
+    start = np.zeros(len(nodes) + 1, np.int32)
+    items = []
+    for i, nd in enumerate(nodes):
+        items.extend(int(x) for x in fv[int(nd)])
+        start[i + 1] = len(items)
+    return nodes, start, np.array(items, np.uint32)
+
+
+def search_by_bow(k1, d1, fv1, k2, d2, fv2, has_mp2=None, map_point_only=False, th_low=50, nratio=0.0, histo_len=30,
+                  check_orientation=True):
+    """Matcher::searchByBow(F1, F2, MapPointOnly), matcher.cpp:619-721; fv1 / fv2: the frames' DBoW2 feature vectors as
+    dicts {node id: [feature indices]}."""
+    k1 = np.ascontiguousarray(k1, KEYPOINT); k2 = np.ascontiguousarray(k2, KEYPOINT)
+    d1, d2 = _desc(d1), _desc(d2)
+    n1a, s1a, i1a = _fv(fv1)
+    n2a, s2a, i2a = _fv(fv2)
+    hm = None if has_mp2 is None else np.ascontiguousarray(has_mp2, np.uint8)
+    out = np.zeros(max(len(i1a), 1), MATCH)
+    n = _chk(lib().orc_search_by_bow(_p(k1), _p(d1), len(k1), _p(n1a), _p(s1a), _p(i1a), len(n1a), _p(k2), _p(d2), len(k2), _p(hm),
+                                     _p(n2a), _p(s2a), _p(i2a), len(n2a), int(map_point_only), int(th_low), C.c_float(nratio),
+                                     int(histo_len), int(check_orientation), _p(out), len(out)))
+    return out[:n].copy()
+
+
 def camera(fx, fy, cx, cy, width, height, dist=None):
     """tb_camera record (PinholeCamera of the reference); dist = (k1, k2, p1, p2, k3) or None."""
     c = np.zeros(1, CAMERA)

@@ -71,6 +71,13 @@ int orc_search_by_violence(const tb_keypoint* k1, const uint8_t* d1, int n1,
                            int th_low, float nratio, int histo_len, int check_orientation,
                            tb_match* out, int cap);
 
+/* SURVEY 8(f) row 4 -- Matcher::searchByBow, matcher.cpp:619-721; the frames' DBoW2 feature vectors are inputs (node ids
+ * ascending, CSR feature lists); has_mp2 (nullable): F2->GetMapPoint(i) != nullptr, read when map_point_only */
+int orc_search_by_bow(const tb_keypoint* k1, const uint8_t* d1, int n1, const uint32_t* nodes1, const int32_t* start1,
+                      const uint32_t* items1, int nn1, const tb_keypoint* k2, const uint8_t* d2, int n2, const uint8_t* has_mp2,
+                      const uint32_t* nodes2, const int32_t* start2, const uint32_t* items2, int nn2, int map_point_only,
+                      int th_low, float nratio, int histo_len, int check_orientation, tb_match* out, int cap);
+
 /* SURVEY 8(f) row 1 -- Matcher::searchByProjection(F1, F2), matcher.cpp:406-531 (PARITY UNPINNED, see the .cpp).
  * mp2 / mp2_desc are aligned with F2's keys (bad != 0: no usable map point); taken1[i] != 0: F1's key i already
  * has a map point with observations; img1_w/h = level-0 size of F1 (grid factors). */

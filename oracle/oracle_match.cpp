@@ -412,4 +412,74 @@ int orc_search_by_projection_map(const float Tcw1[16], const tb_camera* cam1, in
     return (int)matches.size();
 }
 
+/* SURVEY 8(f) row 4 -- Matcher::searchByBow(F1, F2, MapPointOnly), matcher.cpp:619-721. The frames' DBoW2 feature
+ * vectors (Frame::GetFeatureVector(): std::map<NodeId, std::vector<unsigned>>, filled by voc->transform(.., 4),
+ * Frame.cpp:269) are INPUTS here: node ids ascending (the map's order), the nodes' feature lists as CSR (start[nn + 1],
+ * items in insertion order). DBoW2 and its vocabulary are not part of this path (the tree holds no vocabulary file).
+ * Walk of the two sorted node lists as in :637-698 (the lower_bound jumps = skipping smaller ids); per feature of F1 in a
+ * shared node: best / second-best Hamming distance over F2's features of that node (:645-669), accepted if
+ * best < TH_LOW and best < nRatio * second (:671-673); rotation histogram with factor 1 / HISTO_LENGTH and
+ * round(rot * factor) (:677-686, as written there), the three fullest bins kept, in bin order (:701-717). */
+int orc_search_by_bow(const tb_keypoint* k1, const uint8_t* d1, int n1, const uint32_t* nodes1, const int32_t* start1,
+                      const uint32_t* items1, int nn1, const tb_keypoint* k2, const uint8_t* d2, int n2, const uint8_t* has_mp2,
+                      const uint32_t* nodes2, const int32_t* start2, const uint32_t* items2, int nn2, int map_point_only,
+                      int th_low, float nratio, int histo_len, int check_orientation, tb_match* out, int cap) {
+    if (n1 < 0 || n2 < 0 || nn1 < 0 || nn2 < 0 || histo_len < 1) return TB_EINVAL;
+    std::vector<tb_match> matches;
+    std::vector<std::vector<int>> rotHist((size_t)histo_len);
+    const float factor = 1.0f / (float)histo_len;
+    int a = 0, b = 0;
+    while (a < nn1 && b < nn2) {
+        if (nodes1[a] == nodes2[b]) {
+            for (int p1 = start1[a]; p1 < start1[a + 1]; p1++) {
+                const int idx1 = (int)items1[p1];
+                if (idx1 < 0 || idx1 >= n1) return TB_EINVAL;
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (int p2 = start2[b]; p2 < start2[b + 1]; p2++) {
+                    const int idx2 = (int)items2[p2];
+                    if (idx2 < 0 || idx2 >= n2) return TB_EINVAL;
+                    if (map_point_only && !(has_mp2 && has_mp2[idx2])) continue;
+                    const int dist = orc_descriptor_distance(d1 + 32 * (size_t)idx1, d2 + 32 * (size_t)idx2);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 < th_low && bestIdx2 >= 0) {   /* bestIdx2 < 0 (TH_LOW > 256): the reference indexes key -1 */
+                    if ((float)bestDist1 < nratio * (float)bestDist2) {
+                        tb_match m = {idx1, bestIdx2, -1, (float)bestDist1};
+                        matches.push_back(m);
+                        if (check_orientation) {
+                            float rot = k1[idx1].angle - k2[bestIdx2].angle;
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = (int)std::round(rot * factor);
+                            if (bin == histo_len) bin = 0;
+                            if (bin < 0 || bin >= histo_len) return TB_EUNSUPPORTED;   /* the reference asserts */
+                            rotHist[bin].push_back((int)matches.size() - 1);
+                        }
+                    }
+                }
+            }
+            a++; b++;
+        } else if (nodes1[a] < nodes2[b]) {
+            while (a < nn1 && nodes1[a] < nodes2[b]) a++;      /* lower_bound(f2it->first) */
+        } else {
+            while (b < nn2 && nodes2[b] < nodes1[a]) b++;
+        }
+    }
+    std::vector<tb_match> good;
+    if (check_orientation) {
+        std::vector<int> sizes((size_t)histo_len);
+        for (int i = 0; i < histo_len; i++) sizes[i] = (int)rotHist[i].size();
+        int ind[3] = {-1, -1, -1};
+        orc_three_maxima(sizes.data(), histo_len, &ind[0], &ind[1], &ind[2]);
+        for (int i = 0; i < histo_len; i++)
+            if (i == ind[0] || i == ind[1] || i == ind[2])
+                for (int item : rotHist[i]) good.push_back(matches[item]);
+    } else {
+        good.swap(matches);
+    }
+    if ((int)good.size() > cap) return TB_ECAPACITY;
+    for (size_t i = 0; i < good.size(); i++) out[i] = good[i];
+    return (int)good.size();
+}
+
 }  // extern "C"

@@ -140,6 +140,15 @@ int main(int argc, char** argv)
     auto rmatches = matcher_ptr->searchByOPFlow(frame2_ptr, frame1_ptr, flow_pts_r, true, true);
     std::vector<float> depths = localBa.AddMapPointsByStereo(frame1_ptr, frame2_ptr, 386.1448f, 718.856f);
 
+    // Matcher::searchByBow (matcher.cpp:619-721): the vocabulary is not part of the path, so the frames' feature vectors
+    // are filled here -- node = a hash of two descriptor bytes, the same rule tests/test_gpu_shim.py applies
+    for (int i = 0; i < descriptors1.rows; i++)
+        frame1_ptr->GetFeatureVector().addFeature((unsigned)(descriptors1.ptr(i)[3] ^ descriptors1.ptr(i)[17]) % 64u, (unsigned)i);
+    for (int i = 0; i < descriptors2.rows; i++)
+        frame2_ptr->GetFeatureVector().addFeature((unsigned)(descriptors2.ptr(i)[3] ^ descriptors2.ptr(i)[17]) % 64u, (unsigned)i);
+    matcher_ptr->setViolenceParam(80, 100, 30, true, 0.95f);
+    auto bmatches = matcher_ptr->searchByBow(frame1_ptr, frame2_ptr);
+
     std::ofstream o(argv[4], std::ios::binary);
     put(o, keypoints1.data(), keypoints1.size()); put(o, descriptors1.data, (size_t)descriptors1.rows * 32);
     put(o, keypoints2.data(), keypoints2.size()); put(o, descriptors2.data, (size_t)descriptors2.rows * 32);
@@ -153,9 +162,10 @@ int main(int argc, char** argv)
     put(o, pmatches.data(), pmatches.size()); put(o, mmatches.data(), mmatches.size());
     put(o, flow_pts.data(), flow_pts.size()); put(o, fmatches.data(), fmatches.size());
     put(o, rmatches.data(), rmatches.size()); put(o, depths.data(), depths.size());
+    put(o, bmatches.data(), bmatches.size());
     std::cout << "kps " << keypoints1.size() << "/" << keypoints2.size() << " added " << added.size() << " bf " << matches.size()
               << " violence " << vmatches.size() << " fast " << fast_kps.size() << " pose inliers " << inliers
               << " projection " << pmatches.size() << " map projection " << mmatches.size() << " flow " << fmatches.size()
-              << " flow+ransac " << rmatches.size() << " depths " << depths.size() << std::endl;
+              << " bow " << bmatches.size() << " flow+ransac " << rmatches.size() << " depths " << depths.size() << std::endl;
     return 0;
 }

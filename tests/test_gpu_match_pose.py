@@ -105,3 +105,58 @@ def test_pose_opt_too_few(ctx):
     assert n == 0 and np.array_equal(T, Ti)
     n, T, outl, st = ctx.pose_opt(K, Ti, obs[:0])
     assert n == 0 and np.array_equal(T, Ti)
+
+
+def _bow_case(seed, n1=1500, n2=1400, nnodes=180, overlap=0.75):
+    """Two frames with descriptors, angles and DBoW2-style feature vectors (node id -> feature indices): a share of F2's
+    features are noisy copies of F1 features filed under the same node, some nodes exist in one frame only."""
+    rng = np.random.default_rng(seed)
+    k1 = np.zeros(n1, capi.KEYPOINT); k2 = np.zeros(n2, capi.KEYPOINT)
+    k1["angle"] = rng.uniform(0, 360, n1).astype(np.float32)
+    d1 = rng.integers(0, 256, (n1, 32), dtype=np.uint8)
+    d2 = rng.integers(0, 256, (n2, 32), dtype=np.uint8)
+    node1 = rng.integers(0, nnodes, n1) * 7 + 3
+    src = rng.integers(0, n1, n2)
+    same = rng.uniform(size=n2) < overlap
+    node2 = np.where(same, node1[src], rng.integers(0, nnodes + 40, n2) * 7 + 3)
+    for i in np.nonzero(same)[0]:
+        d2[i] = d1[src[i]]
+        flips = rng.integers(0, 256, rng.integers(0, 40))
+        for b in flips:
+            d2[i, b >> 3] ^= np.uint8(1 << (b & 7))
+    rot = np.where(rng.uniform(size=n2) < 0.7, 20.0, rng.uniform(0, 360, n2))
+    k2["angle"] = ((k1["angle"][src] - rot + rng.uniform(-4, 4, n2)) % 360).astype(np.float32)
+    fv1, fv2 = {}, {}
+    for i in rng.permutation(n1):
+        fv1.setdefault(int(node1[i]), []).append(int(i))
+    for i in rng.permutation(n2):
+        fv2.setdefault(int(node2[i]), []).append(int(i))
+    has_mp2 = (rng.uniform(size=n2) < 0.6).astype(np.uint8)
+    return k1, d1, fv1, k2, d2, fv2, has_mp2
+
+
+@pytest.mark.parametrize("seed,kw", [(1, dict(th_low=50, nratio=0.9, histo_len=30, check_orientation=True)),
+                                     (2, dict(th_low=80, nratio=0.7, histo_len=30, check_orientation=False)),
+                                     (3, dict(th_low=100, nratio=1.0, histo_len=45, check_orientation=True, map_point_only=True)),
+                                     (4, dict(th_low=257, nratio=2.0, histo_len=30, check_orientation=True))])
+def test_search_by_bow_vs_oracle(ctx, seed, kw):
+    """SURVEY 8f row 4: Matcher::searchByBow (matcher.cpp:619-721) with the frames' feature vectors as inputs."""
+    k1, d1, fv1, k2, d2, fv2, has_mp2 = _bow_case(seed)
+    exp = oracle.search_by_bow(k1, d1, fv1, k2, d2, fv2, has_mp2=has_mp2, **kw)
+    got = ctx.search_by_bow(k1, d1, fv1, k2, d2, fv2, has_mp2=has_mp2, **kw)
+    _eq_struct(got, exp)
+    assert len(exp) > 100
+
+
+def test_search_by_bow_edges(ctx):
+    k1, d1, fv1, k2, d2, fv2, has_mp2 = _bow_case(5, n1=200, n2=150, nnodes=20)
+    kw = dict(th_low=60, nratio=0.9, histo_len=30, check_orientation=True)
+    assert len(ctx.search_by_bow(k1, d1, {}, k2, d2, fv2, **kw)) == 0          # an empty feature vector
+    assert len(ctx.search_by_bow(k1, d1, fv1, k2, d2, {}, **kw)) == 0
+    disjoint = {k + 100000: v for k, v in fv2.items()}                          # no shared node
+    assert len(ctx.search_by_bow(k1, d1, fv1, k2, d2, disjoint, **kw)) == 0
+    none = np.zeros(len(k2), np.uint8)                                          # MapPointOnly without any map point
+    assert len(ctx.search_by_bow(k1, d1, fv1, k2, d2, fv2, has_mp2=none, map_point_only=True, **kw)) == 0
+    with pytest.raises(capi.TBError):                                           # a feature index outside the frame
+        bad = dict(fv1); bad[next(iter(bad))] = [10 ** 6]
+        ctx.search_by_bow(k1, d1, bad, k2, d2, fv2, **kw)

@@ -47,10 +47,10 @@ def test_reference_style_driver_on_shims(golden, kitti_pair):
         log = subprocess.check_output([EXE, os.path.join(GOLDEN, "kitti00_left_1241x376.pgm"),
                                        os.path.join(GOLDEN, "kitti00_right_1241x376.pgm"), ob, out], timeout=300).decode()
         assert "kps" in log
-        (k1, d1, k2, d2, ka, da, bf, vio, fg, T, outl, ninl, k1now, taken1, nomp2, mp, mpd, pm, mm, fpts, fm, rm, depths) = _read_blocks(
+        (k1, d1, k2, d2, ka, da, bf, vio, fg, T, outl, ninl, k1now, taken1, nomp2, mp, mpd, pm, mm, fpts, fm, rm, depths, bm) = _read_blocks(
             out, [capi.KEYPOINT, np.uint8, capi.KEYPOINT, np.uint8, capi.KEYPOINT, np.uint8, capi.MATCH, capi.MATCH,
                   capi.KEYPOINT, np.float32, np.uint8, np.int32, capi.KEYPOINT, np.uint8, np.uint8, capi.MAPPOINT, np.uint8,
-                  capi.MATCH, capi.MATCH, np.dtype([("x", "<f4"), ("y", "<f4")]), capi.MATCH, capi.MATCH, np.float32])
+                  capi.MATCH, capi.MATCH, np.dtype([("x", "<f4"), ("y", "<f4")]), capi.MATCH, capi.MATCH, np.float32, capi.MATCH])
     assert np.array_equal(k1, golden["c5_kps_left"]) and np.array_equal(d1.reshape(-1, 32), golden["c5_desc_left"])
     assert np.array_equal(k2, golden["c5_kps_right"]) and np.array_equal(d2.reshape(-1, 32), golden["c5_desc_right"])
     assert np.array_equal(ka, golden["c5_addpoints_kps_left"]) and np.array_equal(da.reshape(-1, 32), golden["c5_addpoints_desc_left"])
@@ -84,6 +84,15 @@ def test_reference_style_driver_on_shims(golden, kitti_pair):
     odepth = oracle.add_map_points_by_stereo(imgR, imgL, cam, keys, 386.1448)
     assert len(depths) == len(k1now) and np.array_equal(depths.view(np.uint32), odepth.view(np.uint32))
     assert (depths[ridx] > 0).all() and (np.delete(depths, ridx) == -1).all()
+    # Matcher::searchByBow through the class API: feature vectors filled by the driver's hash rule (the vocabulary is outside)
+    D1, D2 = d1.reshape(-1, 32), d2.reshape(-1, 32)
+    fv1, fv2 = {}, {}
+    for i in range(len(D1)):
+        fv1.setdefault(int(D1[i, 3] ^ D1[i, 17]) % 64, []).append(i)
+    for i in range(len(D2)):
+        fv2.setdefault(int(D2[i, 3] ^ D2[i, 17]) % 64, []).append(i)
+    bo = oracle.search_by_bow(k1, D1, fv1, k2, D2, fv2, th_low=80, nratio=0.95, histo_len=30, check_orientation=True)
+    assert len(bo) > 5 and np.array_equal(bm, bo)
 
 
 def test_shim_library_exports_reference_classes():
@@ -93,7 +102,7 @@ def test_shim_library_exports_reference_classes():
     syms = subprocess.check_output(["nm", "-DC", "--defined-only", so]).decode()
     for want in ("TRACKING_BENCH::ORBExtractor::operator()", "TRACKING_BENCH::ORBExtractor::AddPoints",
                  "TRACKING_BENCH::FASTExtractor::operator()", "TRACKING_BENCH::Matcher::searchByBF",
-                 "TRACKING_BENCH::Matcher::searchByViolence", "TRACKING_BENCH::Matcher::searchByOPFlow", "TRACKING_BENCH::Matcher::rejectWithF",
+                 "TRACKING_BENCH::Matcher::searchByViolence", "TRACKING_BENCH::Matcher::searchByOPFlow", "TRACKING_BENCH::Matcher::rejectWithF", "TRACKING_BENCH::Matcher::searchByBow",
                  "TRACKING_BENCH::LocalBA::AddMapPointsByStereo",
                  "TRACKING_BENCH::Matcher::DescriptorDistance",
                  "TRACKING_BENCH::Matcher::ComputeThreeMaxima", "TRACKING_BENCH::LocalBA::PoseOptimization",

@@ -36,7 +36,7 @@ EXPORTS = [
     "tb_extractor_candidates_host", "tb_extractor_copy_results_dev",
     "tb_pyramid", "tb_fast_detect", "tb_orb_extract", "tb_fastgrid_extract",
     "tb_descriptor_distance", "tb_three_maxima", "tb_match_bf", "tb_search_by_bf", "tb_search_by_bf_batch_dev",
-    "tb_search_by_violence", "tb_search_by_projection", "tb_search_by_projection_map", "tb_frame_grid_batch_dev",
+    "tb_search_by_violence", "tb_search_by_bow", "tb_search_by_projection", "tb_search_by_projection_map", "tb_frame_grid_batch_dev",
     "tb_search_by_projection_batch_dev", "tb_search_by_projection_map_batch_dev",
     "tb_search_by_violence_batch_dev", "tb_pose_opt", "tb_pose_opt_batch_dev", "tb_local_ba", "tb_local_ba_batch_dev",
     "tb_clahe", "tb_clahe_dev", "tb_optical_flow_pyr_lk", "tb_optical_flow_pyr_lk_dev", "tb_optical_flow_pyr_lk_batch_dev", "tb_search_by_opflow", "tb_search_by_opflow_batch_dev",
@@ -278,6 +278,32 @@ class Context:
                                                int(img2_h), int(min_level), int(max_level), C.c_float(radius), int(th_low),
                                                C.c_float(nratio), int(histo_len), int(check_orientation), _p(out), len(out),
                                                C.byref(n)))
+        return out[:n.value].copy()
+
+    @staticmethod
+    def _fv(fv):
+        nodes = np.array(sorted(fv), np.uint32)
+        start = np.zeros(len(nodes) + 1, np.int32)
+        items = []
+        for i, nd in enumerate(nodes):
+            items.extend(int(x) for x in fv[int(nd)])
+            start[i + 1] = len(items)
+        return nodes, start, np.array(items, np.uint32)
+
+    def search_by_bow(self, k1, d1, fv1, k2, d2, fv2, has_mp2=None, map_point_only=False, th_low=50, nratio=0.0, histo_len=30,
+                      check_orientation=True):
+        """Matcher::searchByBow(F1, F2, MapPointOnly) (reference matcher.cpp:619-721); fv1 / fv2: the frames' DBoW2 feature
+        vectors as dicts {node id: [feature indices]}."""
+        k1 = np.ascontiguousarray(k1, KEYPOINT); k2 = np.ascontiguousarray(k2, KEYPOINT)
+        d1, d2 = self._desc(d1), self._desc(d2)
+        n1a, s1a, i1a = self._fv(fv1)
+        n2a, s2a, i2a = self._fv(fv2)
+        hm = None if has_mp2 is None else np.ascontiguousarray(has_mp2, np.uint8)
+        out = np.zeros(max(len(i1a), 1), MATCH)
+        n = C.c_int(0)
+        self.check(lib().tb_search_by_bow(self._h, _p(k1), _p(d1), len(k1), _p(n1a), _p(s1a), _p(i1a), len(n1a), _p(k2), _p(d2), len(k2),
+                                          _p(hm), _p(n2a), _p(s2a), _p(i2a), len(n2a), int(map_point_only), int(th_low),
+                                          C.c_float(nratio), int(histo_len), int(check_orientation), _p(out), len(out), C.byref(n)))
         return out[:n.value].copy()
 
     def clahe(self, img, clip_limit=3.0, tiles=(8, 8)):

@@ -809,3 +809,40 @@ int tbk_violence_batch(tb_ctx* ctx, int npairs, const tb_keypoint* d_k1, const u
     TB_HIP(ctx, hipGetLastError());
     return TB_OK;
 }
+
+/* ---- Matcher::searchByBow (matcher.cpp:619-721), the search over shared vocabulary nodes.
+ * One thread per QUERY = one feature of F1 that lies in a node both frames have (the host's walk of the two sorted node
+ * lists, matcher.cpp:637-698, yields the queries in the reference's emission order): best / second-best Hamming
+ * distance over F2's features of that node in list order (:645-669). best[q] = {bestDist1, bestDist2, bestIdx2, 0}.
+ * Bound: gather latency (a node holds a handful of features); no SURVEY 8(d) row. */
+__global__ void __launch_bounds__(256)
+k_bow_search(int nq, const int4* __restrict__ queries /* idx1, start2, end2, 0 */, const uint8_t* __restrict__ d1,
+             const uint8_t* __restrict__ d2, const uint32_t* __restrict__ items2, const uint8_t* __restrict__ has_mp2,
+             int map_point_only, int4* __restrict__ best) {
+    const int q = blockIdx.x * blockDim.x + threadIdx.x;
+    if (q >= nq) return;
+    const int4 qu = queries[q];
+    Desc256 a;
+    const unsigned long long* pa = reinterpret_cast<const unsigned long long*>(d1 + 32 * (size_t)qu.x);
+    a.w[0] = pa[0]; a.w[1] = pa[1]; a.w[2] = pa[2]; a.w[3] = pa[3];
+    int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+    for (int p2 = qu.y; p2 < qu.z; p2++) {
+        const int idx2 = (int)items2[p2];
+        if (map_point_only && !(has_mp2 && has_mp2[idx2])) continue;
+        const int dist = bf_dist(a, reinterpret_cast<const unsigned long long*>(d2 + 32 * (size_t)idx2));
+        if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2; }
+        else if (dist < bestDist2) bestDist2 = dist;
+    }
+    best[q] = make_int4(bestDist1, bestDist2, bestIdx2, 0);
+}
+
+int tbk_bow_search(tb_ctx* ctx, int nq, const void* d_queries, const uint8_t* d_d1, const uint8_t* d_d2, const uint32_t* d_items2,
+                   const uint8_t* d_has_mp2, int map_point_only, void* d_best) {
+    if (nq <= 0) return TB_OK;
+    tb_prof_begin(ctx, "k_bow_search");
+    hipLaunchKernelGGL(k_bow_search, dim3((nq + 255) / 256), dim3(256), 0, ctx->stream, nq, (const int4*)d_queries, d_d1, d_d2, d_items2,
+                       d_has_mp2, map_point_only, (int4*)d_best);
+    tb_prof_end(ctx);
+    TB_HIP(ctx, hipGetLastError());
+    return TB_OK;
+}

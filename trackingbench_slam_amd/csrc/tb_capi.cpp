@@ -963,6 +963,97 @@ int tb_search_by_violence(tb_ctx* ctx, const tb_keypoint* k1, const uint8_t* d1,
     return TB_OK;
 }
 
+/* ---- Matcher::searchByBow (matcher.cpp:619-721). The two frames' DBoW2 feature vectors are inputs. */
+int tb_search_by_bow(tb_ctx* ctx, const tb_keypoint* k1, const uint8_t* d1, int n1, const uint32_t* nodes1, const int32_t* start1,
+                     const uint32_t* items1, int nn1, const tb_keypoint* k2, const uint8_t* d2, int n2, const uint8_t* has_mp2,
+                     const uint32_t* nodes2, const int32_t* start2, const uint32_t* items2, int nn2, int map_point_only, int th_low,
+                     float nratio, int histo_len, int check_orientation, tb_match* out, int cap, int* count) {
+    TB_ENTER(ctx);
+    if (!ctx || !count || n1 < 0 || n2 < 0 || nn1 < 0 || nn2 < 0 || histo_len < 1 || cap < 0) return TB_EINVAL;
+    *count = 0;
+    if ((nn1 && (!nodes1 || !start1)) || (nn2 && (!nodes2 || !start2)) || (n1 && (!k1 || !d1)) || (n2 && (!k2 || !d2))) return TB_EINVAL;
+    /* the walk of the two sorted node lists (matcher.cpp:637-698): one query per feature of F1 in a shared node, in the
+     * reference's emission order */
+    struct Q { int32_t idx1, s2, e2, pad; };
+    std::vector<Q> queries;
+    int a = 0, b = 0;
+    const int tot2 = nn2 ? start2[nn2] : 0;
+    while (a < nn1 && b < nn2) {
+        if (nodes1[a] == nodes2[b]) {
+            if (start2[b] < 0 || start2[b + 1] < start2[b] || start2[b + 1] > tot2 || start1[a + 1] < start1[a]) return tb_fail(ctx, TB_EINVAL, "searchByBow: feature vector offsets");
+            for (int p1 = start1[a]; p1 < start1[a + 1]; p1++) {
+                const int idx1 = (int)items1[p1];
+                if (idx1 < 0 || idx1 >= n1) return tb_fail(ctx, TB_EINVAL, "searchByBow: feature index %d of F1 out of range", idx1);
+                queries.push_back(Q{idx1, start2[b], start2[b + 1], 0});
+            }
+            a++; b++;
+        } else if (nodes1[a] < nodes2[b]) {
+            while (a < nn1 && nodes1[a] < nodes2[b]) a++;
+        } else {
+            while (b < nn2 && nodes2[b] < nodes1[a]) b++;
+        }
+    }
+    for (int i = 0; i < tot2; i++)
+        if ((int)items2[i] < 0 || (int)items2[i] >= n2) return tb_fail(ctx, TB_EINVAL, "searchByBow: feature index %u of F2 out of range", items2[i]);
+    const int nq = (int)queries.size();
+    if (nq == 0) return TB_OK;
+    void *dd1, *dd2, *dit, *dq, *dbest, *dmp;
+    int rc;
+    if ((rc = tb_scratch(ctx, 0, (size_t)n1 * 32, &dd1)) || (rc = tb_scratch(ctx, 1, (size_t)n2 * 32, &dd2)) ||
+        (rc = tb_scratch(ctx, 4, (size_t)std::max(tot2, 1) * 4, &dit)) || (rc = tb_scratch(ctx, 5, (size_t)nq * 16, &dq)) ||
+        (rc = tb_scratch(ctx, 6, (size_t)nq * 16, &dbest)) || (rc = tb_scratch(ctx, 3, (size_t)std::max(n2, 1), &dmp)))
+        return rc;
+    hipStream_t s = ctx->stream;
+    TB_HIP(ctx, hipMemcpyAsync(dd1, d1, (size_t)n1 * 32, hipMemcpyHostToDevice, s));
+    TB_HIP(ctx, hipMemcpyAsync(dd2, d2, (size_t)n2 * 32, hipMemcpyHostToDevice, s));
+    TB_HIP(ctx, hipMemcpyAsync(dit, items2, (size_t)tot2 * 4, hipMemcpyHostToDevice, s));
+    TB_HIP(ctx, hipMemcpyAsync(dq, queries.data(), (size_t)nq * 16, hipMemcpyHostToDevice, s));
+    if (has_mp2) TB_HIP(ctx, hipMemcpyAsync(dmp, has_mp2, (size_t)n2, hipMemcpyHostToDevice, s));
+    TB_HIP(ctx, hipStreamSynchronize(s)); /* queries is a function-lifetime staging buffer */
+    if ((rc = tbk_bow_search(ctx, nq, dq, (const uint8_t*)dd1, (const uint8_t*)dd2, (const uint32_t*)dit, has_mp2 ? (const uint8_t*)dmp : nullptr,
+                             map_point_only, dbest)))
+        return rc;
+    std::vector<int32_t> best((size_t)nq * 4);
+    TB_HIP(ctx, hipMemcpyAsync(best.data(), dbest, best.size() * 4, hipMemcpyDeviceToHost, s));
+    TB_HIP(ctx, hipStreamSynchronize(s));
+    /* acceptance + rotation histogram, matcher.cpp:671-717 (bookkeeping over <= nq survivors) */
+    std::vector<tb_match> matches;
+    std::vector<std::vector<int>> rotHist((size_t)histo_len);
+    const float factor = 1.f / (float)histo_len;
+    for (int q = 0; q < nq; q++) {
+        const int bestDist1 = best[4 * q], bestDist2 = best[4 * q + 1], bestIdx2 = best[4 * q + 2];
+        if (bestDist1 < th_low && bestIdx2 >= 0 && (float)bestDist1 < nratio * (float)bestDist2) {
+            const int idx1 = queries[q].idx1;
+            tb_match m = {idx1, bestIdx2, -1, (float)bestDist1};
+            matches.push_back(m);
+            if (check_orientation) {
+                float rot = k1[idx1].angle - k2[bestIdx2].angle;
+                if (rot < 0) rot += 360.f;
+                int bin = (int)roundf(rot * factor);
+                if (bin == histo_len) bin = 0;
+                if (bin < 0 || bin >= histo_len) return tb_fail(ctx, TB_EUNSUPPORTED, "rotation bin %d outside histogram (reference asserts)", bin);
+                rotHist[bin].push_back((int)matches.size() - 1);
+            }
+        }
+    }
+    std::vector<tb_match> good;
+    if (check_orientation) {
+        std::vector<int> sizes((size_t)histo_len);
+        for (int i = 0; i < histo_len; i++) sizes[i] = (int)rotHist[i].size();
+        int ind[3] = {-1, -1, -1};
+        tb_three_maxima(sizes.data(), histo_len, &ind[0], &ind[1], &ind[2]);
+        for (int i = 0; i < histo_len; i++)
+            if (i == ind[0] || i == ind[1] || i == ind[2])
+                for (int item : rotHist[i]) good.push_back(matches[item]);
+    } else {
+        good.swap(matches);
+    }
+    *count = (int)good.size();
+    if ((int)good.size() > cap) return tb_fail(ctx, TB_ECAPACITY, "matches: %d, capacity %d", (int)good.size(), cap);
+    if (out) std::copy(good.begin(), good.end(), out);
+    return TB_OK;
+}
+
 /* ---- Matcher::searchByProjection, both overloads (matcher.cpp:406-617) */
 namespace {
 struct ProjHost {

@@ -167,6 +167,9 @@ int tbk_violence_batch(tb_ctx* ctx, int npairs, const tb_keypoint* d_k1, const u
                        const int32_t* d_cellItems, int img2_w, int img2_h, int min_level, int max_level, float radius, int th_low,
                        float nratio, int histo_len, int check_orientation, int32_t* d_best, tb_match* d_out, int cap,
                        int32_t* d_out_counts, int32_t* d_flags);
+/* searchByBow's search over shared vocabulary nodes (queries: int4 idx1, start2, end2, 0; best: int4) */
+int tbk_bow_search(tb_ctx* ctx, int nq, const void* d_queries, const uint8_t* d_d1, const uint8_t* d_d2, const uint32_t* d_items2,
+                   const uint8_t* d_has_mp2, int map_point_only, void* d_best);
 /* device-resident lookup grids and the batched searchByProjection(F1, F2) on them */
 int tbk_grid_build_batch(tb_ctx* ctx, int nframes, const tb_keypoint* d_keys, const int32_t* d_counts, int key_pitch, int img_w,
                          int img_h, int32_t* d_cellStart, int32_t* d_cellItems);

@@ -234,6 +234,41 @@ namespace TRACKING_BENCH
         return out;
     }
 
+    /* Matcher::searchByBow (reference matcher.cpp:619-721) on tb_search_by_bow */
+    static void frame_fv(const std::shared_ptr<Frame>& F, std::vector<uint32_t>& nodes, std::vector<int32_t>& start, std::vector<uint32_t>& items)
+    {
+        nodes.clear(); items.clear(); start.assign(1, 0);
+        for (const auto& kv : F->GetFeatureVector())       /* std::map: ascending node ids */
+        {
+            nodes.push_back(kv.first);
+            items.insert(items.end(), kv.second.begin(), kv.second.end());
+            start.push_back((int32_t)items.size());
+        }
+    }
+    std::vector<cv::DMatch> Matcher::searchByBow(const std::shared_ptr<Frame>& F1, const std::shared_ptr<Frame>& F2, bool MapPointOnly)
+    {
+        std::vector<tb_keypoint> k1, k2;
+        std::vector<uint8_t> d1, d2, has2;
+        frame_keys(F1, k1); frame_keys(F2, k2);
+        frame_desc(F1, d1); frame_desc(F2, d2);
+        std::vector<uint32_t> n1, i1, n2, i2;
+        std::vector<int32_t> s1, s2;
+        frame_fv(F1, n1, s1, i1); frame_fv(F2, n2, s2, i2);
+        if (MapPointOnly)
+        {
+            has2.assign(std::max<size_t>(k2.size(), 1), 0);
+            for (size_t i = 0; i < k2.size(); i++) has2[i] = F2->GetMapPoint(i) ? 1 : 0;
+        }
+        std::vector<cv::DMatch> out(std::max<size_t>(i1.size(), 1));
+        int n = 0;
+        check(tb_search_by_bow(shim_ctx(), k1.data(), d1.data(), (int)k1.size(), n1.data(), s1.data(), i1.data(), (int)n1.size(), k2.data(), d2.data(),
+                               (int)k2.size(), MapPointOnly ? has2.data() : nullptr, n2.data(), s2.data(), i2.data(), (int)n2.size(),
+                               MapPointOnly ? 1 : 0, TH_LOW, nRatio, HISTO_LENGTH, checkOrientation ? 1 : 0,
+                               reinterpret_cast<tb_match*>(out.data()), (int)out.size(), &n), "Matcher::searchByBow");
+        out.resize(n);
+        return out;
+    }
+
     /* Matcher::searchByOPFlow (reference matcher.cpp:724-768) on tb_search_by_opflow; reject = true runs
      * Matcher::rejectWithF (cv::findFundamentalMat RANSAC restated, parity unpinned) on the device as well */
     std::vector<cv::DMatch> Matcher::searchByOPFlow(const std::shared_ptr<Frame>& F1, const std::shared_ptr<Frame>& F2,
