@@ -76,6 +76,58 @@ def main():
         if not (fg[3] == fo[3] and np.array_equal(fg[1], fo[1]) and np.array_equal(fg[0].view(np.uint32), fo[0].view(np.uint32)) and
                 np.array_equal(fg[2].view(np.uint32), fo[2].view(np.uint32))):
             fail("optical_flow_pyr_lk", w=w, h=h, npt=npt, ml=ml, status=(int(fg[1].sum()), int(fo[1].sum())))
+        # RANSAC fundamental matrix (rejectWithF), stereo-like point sets with a random share of gross outliers
+        nr_ = int(rng.integers(15, 2500))
+        px = rng.uniform(10, w + 300, nr_); py = rng.uniform(10, h + 100, nr_)
+        p1 = np.stack([px, py], 1).astype(np.float32)
+        p2 = np.stack([px - 386.0 / rng.uniform(4, 60, nr_), py], 1) + rng.normal(0, float(rng.uniform(0, 0.6)), (nr_, 2))
+        nbad = int(rng.integers(0, nr_))
+        bad = rng.choice(nr_, nbad, replace=False)
+        p2[bad] += rng.uniform(3, 90, (nbad, 2)) * rng.choice([-1, 1], (nbad, 2))
+        p2 = p2.astype(np.float32)
+        ro, rg = oracle.find_fundamental_ransac(p1, p2), ctx.find_fundamental_ransac(p1, p2)
+        if not (ro[0] == rg[0] and ro[3] == rg[3] and np.array_equal(ro[1], rg[1]) and (not ro[0] or np.array_equal(ro[2].view(np.uint64), rg[2].view(np.uint64)))):
+            fail("find_fundamental_ransac", n=nr_, nbad=nbad, iters=(rg[3], ro[3]), inliers=(int(rg[1].sum()), int(ro[1].sum())))
+        st = (rng.uniform(size=nr_) < 0.8).astype(np.uint8)
+        if st.sum() >= 15 or st.sum() <= 7:
+            if not np.array_equal(ctx.reject_with_f(p2, p1, st), oracle.reject_with_f(p2, p1, st)):
+                fail("reject_with_f", n=nr_, live=int(st.sum()))
+        if len(k1) >= 40 and it % 2 == 0:   # the whole optical-flow matcher with the RANSAC stage, and the stereo depths
+            cam = oracle.camera(500, 500, w / 2, h / 2, w, h)
+            keys = np.stack([k1["x"], k1["y"]], 1)[k1["octave"] == 0].astype(np.float32)
+            try:
+                eo = oracle.add_map_points_by_stereo(shifted, img, cam, keys, 386.1448)
+            except oracle.OracleError:
+                eo = None                    # 8..14 tracked points: OpenCV's LMedS branch, unsupported on both sides
+            if eo is not None:
+                eg, _ = ctx.add_map_points_by_stereo(shifted, img, cam, keys, 386.1448)
+                if not np.array_equal(eg.view(np.uint32), eo.view(np.uint32)):
+                    fail("add_map_points_by_stereo", w=w, h=h, n=len(keys), set=(int((eg > 0).sum()), int((eo > 0).sum())))
+        # searchByBow on feature vectors made by a descriptor hash
+        if len(k1) and len(k2):
+            mod = int(rng.integers(1, 200))
+            fv1, fv2 = {}, {}
+            for i in range(len(d1)):
+                fv1.setdefault(int(d1[i, 3] ^ d1[i, 17]) % mod, []).append(i)
+            for i in rng.permutation(len(d2)):
+                fv2.setdefault(int(d2[i, 3] ^ d2[i, 17]) % mod + (7 if i % 13 == 0 else 0), []).append(int(i))
+            bw = dict(th_low=int(rng.integers(30, 260)), nratio=float(rng.uniform(0.5, 1.5)), histo_len=int(rng.choice([30, 45])),
+                      check_orientation=bool(rng.integers(0, 2)), map_point_only=bool(rng.integers(0, 2)),
+                      has_mp2=(rng.uniform(size=len(k2)) < 0.7).astype(np.uint8))
+            if not same_rec(ctx.search_by_bow(k1, d1, fv1, k2, d2, fv2, **bw), oracle.search_by_bow(k1, d1, fv1, k2, d2, fv2, **bw)):
+                fail("search_by_bow", n1=len(k1), n2=len(k2), mod=mod)
+        # FAST cell loop on dense images (the block kernel's list-free path): noise, low thresholds
+        if it % 4 == 0:
+            nw, nh = int(rng.integers(70, 400)), int(rng.integers(70, 300))
+            noise = rng.integers(0, 256, (nh, nw), dtype=np.uint8)
+            if rng.integers(0, 2):
+                noise[:, : nw // 2] = synth.frame(int(rng.integers(0, 10 ** 6)), nw, nh)[:, : nw // 2]
+            nlv, nsf = oracle.pyramid(noise, 2, 0.8)
+            t1, t2 = int(rng.integers(0, 30)), int(rng.integers(0, 12))
+            kg, dg, _ = ctx.orb_extract(nlv, nsf, 500, t1, t2)
+            kq, dq, _ = oracle.orb_extract(nlv, nsf, 500, t1, t2)
+            if not (np.array_equal(kg, kq) and np.array_equal(dg, dq)):
+                fail("orb_extract on noise", w=nw, h=nh, t1=t1, t2=t2)
         clip, tiles = float(rng.choice([0.0, 0.5, 2.0, 3.0, 40.0])), (int(rng.integers(1, 10)), int(rng.integers(1, 10)))
         low = (img // int(rng.integers(1, 6)) + int(rng.integers(0, 60))).astype(np.uint8)
         if not np.array_equal(ctx.clahe(low, clip, tiles), oracle.clahe(low, clip, tiles)):
