@@ -25,6 +25,8 @@ def main():
     ap.add_argument("--width", type=int, default=1280)
     ap.add_argument("--height", type=int, default=720)
     ap.add_argument("--cpu-seconds", type=float, default=10.0)
+    ap.add_argument("--stereo", action="store_true",
+                    help="time LocalBA::AddMapPointsByStereo instead (CLAHE + tracker + frame test + RANSAC + depths, batched)")
     args = ap.parse_args()
     import oracle
     torch.cuda.set_device(0)
@@ -46,9 +48,20 @@ def main():
     status = torch.zeros((P, n), dtype=torch.uint8, device=dev)
     err = torch.zeros((P, n), dtype=torch.float32, device=dev)
 
+    depth = torch.zeros((P, n), dtype=torch.float32, device=dev)
+    cam = oracle.camera(718.856, 718.856, W / 2, H / 2, W, H)
+    import ctypes as C
+    camr = np.ascontiguousarray(cam, capi.CAMERA)
+
     def step():
-        ctx.optical_flow_pyr_lk_batch_dev(P, Ls.data_ptr(), Rs.data_ptr(), W, H, W, W * H, pts.data_ptr(), 0, n, out.data_ptr(),
-                                          status.data_ptr(), err.data_ptr())
+        if args.stereo:   # the keys of the LEFT (current) image tracked into the equalised RIGHT (stereo) image
+            ctx.check(capi.lib().tb_add_map_points_by_stereo_batch_dev(
+                ctx._h, P, C.c_void_p(Rs.data_ptr()), C.c_void_p(Ls.data_ptr()), W, H, W, C.c_size_t(W * H), camr.ctypes.data_as(C.c_void_p),
+                C.c_void_p(pts.data_ptr()), None, n, C.c_float(386.1448), C.c_void_p(out.data_ptr()), C.c_void_p(status.data_ptr()),
+                C.c_void_p(depth.data_ptr())))
+        else:
+            ctx.optical_flow_pyr_lk_batch_dev(P, Ls.data_ptr(), Rs.data_ptr(), W, H, W, W * H, pts.data_ptr(), 0, n, out.data_ptr(),
+                                              status.data_ptr(), err.data_ptr())
 
     for _ in range(args.warmup):
         step()
@@ -63,16 +76,24 @@ def main():
     ctx.profile_enable(False)
     # parity spot check of the last step against the oracle (bit for bit)
     L, R, p0 = distinct[0]
-    on, os_, oe, _ = oracle.optical_flow_pyr_lk(L, R, p0)
-    ok = bool(np.array_equal(out[0].cpu().numpy().view(np.uint32), on.view(np.uint32)) and np.array_equal(status[0].cpu().numpy(), os_))
+    if args.stereo:
+        od = oracle.add_map_points_by_stereo(R, L, cam, p0, 386.1448)
+        ok = bool(np.array_equal(depth[0].cpu().numpy().view(np.uint32), od.view(np.uint32)))
+    else:
+        on, os_, oe, _ = oracle.optical_flow_pyr_lk(L, R, p0)
+        ok = bool(np.array_equal(out[0].cpu().numpy().view(np.uint32), on.view(np.uint32)) and np.array_equal(status[0].cpu().numpy(), os_))
     t1 = time.perf_counter(); done = 0
     while time.perf_counter() - t1 < args.cpu_seconds:
         L, R, p0 = distinct[done % len(distinct)]
-        oracle.optical_flow_pyr_lk(L, R, p0)
+        if args.stereo:
+            oracle.add_map_points_by_stereo(R, L, cam, p0, 386.1448)
+        else:
+            oracle.optical_flow_pyr_lk(L, R, p0)
         done += 1
     cpu_el = time.perf_counter() - t1
     name, (calls, ms) = max(prof.items(), key=lambda kv: kv[1][1])
-    res = {"metric": "stereo pairs/sec (pyramidal LK, %d points per pair, device resident)" % n, "value": round(P * args.steps / el, 1),
+    res = {"metric": ("stereo pairs/sec (AddMapPointsByStereo: CLAHE + LK + RANSAC F + depths, %d keys per pair, device resident)" if args.stereo
+                      else "stereo pairs/sec (pyramidal LK, %d points per pair, device resident)") % n, "value": round(P * args.steps / el, 1),
            "unit": "pairs/s", "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(1e3 * el / args.steps, 3),
            "higher_is_better": True, "dtype": "u8 / int32 fixed point (window) + int64 sums + f32 (2x2 solve)", "data": "synthetic",
            "config": {"workload": "%d pairs/step, %dx%d, %d points, window 21, 4 levels, 30 iterations / eps 0.01" % (P, W, H, n),

@@ -37,7 +37,9 @@ struct RsShared {
     int nm[RS_B];                  /* models of iteration h; -1: getSubset failed there */
     int good[RS_B * 3];
     unsigned long long rng;
-    int niters, maxGood, iter, done, found, wsum[8];
+    unsigned long long rngBefore[RS_B];   /* generator state in front of sample h */
+    int idx[RS_B * 7];                    /* drawn indices */
+    int niters, maxGood, iter, done, found, firstBad, wsum[8];
 };
 
 __device__ __forceinline__ unsigned rs_next(unsigned long long& st) {
@@ -266,35 +268,64 @@ k_ransac_f(const float* __restrict__ pts1, const float* __restrict__ pts2, uint8
     while (!S.done) {
         const int iter0 = S.iter;
         const int B = min(RS_B, S.niters - iter0);
-        /* (a) the batch's samples, drawn in order by one lane: getSubset(m1, m2, ms1, ms2, rng, 10000) */
+        /* (a) the batch's samples: getSubset(m1, m2, ms1, ms2, rng, 10000) for B iterations in order. The generator is
+         * serial, the collinearity test of checkSubset is not: one lane draws the index sets as if every sample passed
+         * (7 distinct draws each), all lanes test their sample, and only if one fails -- rare -- that sample is redone
+         * the sequential way (its retries consume draws) and the later ones are drawn again behind it. */
+        auto draw7 = [&](unsigned long long& rng, int* idx) {
+            for (int i = 0; i < 7;) {
+                const int v = (int)(rs_next(rng) % (unsigned)m);
+                bool dup = false;
+                for (int j = 0; j < 7; j++) dup = dup || (j < i && idx[j] == v);
+                if (dup) continue;
+                idx[i++] = v;
+            }
+        };
+        auto gather = [&](int h) {
+            for (int i = 0; i < 7; i++) {
+                const int v = S.idx[h * 7 + i];
+                S.ms1[h * 14 + 2 * i] = p1[2 * v]; S.ms1[h * 14 + 2 * i + 1] = p1[2 * v + 1];
+                S.ms2[h * 14 + 2 * i] = p2[2 * v]; S.ms2[h * 14 + 2 * i + 1] = p2[2 * v + 1];
+            }
+        };
         if (tid == 0) {
             unsigned long long rng = S.rng;
-            for (int h = 0; h < B; h++) {
-                float* a1 = S.ms1 + h * 14;
-                float* a2 = S.ms2 + h * 14;
-                int idx[7];
-                int attempts = 0, i = 0;
+            for (int h = 0; h < B; h++) { S.rngBefore[h] = rng; draw7(rng, S.idx + h * 7); S.nm[h] = 0; }
+            S.rng = rng;
+        }
+        __syncthreads();
+        for (int from = 0; from < B;) {
+            bool bad = false;
+            if (tid >= from && tid < B && S.nm[tid] == 0) {
+                gather(tid);
+                bad = rs_collinear(S.ms1 + tid * 14) || rs_collinear(S.ms2 + tid * 14);
+            }
+            if (tid < 64) {   /* B <= 64: the samples' lanes are wavefront 0 */
+                const unsigned long long bm = __ballot(bad);
+                if (tid == 0) S.firstBad = bm ? (int)__ffsll((long long)bm) - 1 : -1;
+            }
+            __syncthreads();
+            const int fb = S.firstBad;
+            if (fb < 0) break;
+            if (tid == 0) {   /* sample fb the sequential way, from the generator state in front of it */
+                unsigned long long rng = S.rngBefore[fb];
+                int attempts = 0;
+                bool ok = false;
                 for (; attempts < 10000; attempts++) {
-                    for (i = 0; i < 7 && attempts < 10000;) {
-                        int idx_i = 0;
-                        for (;;) {
-                            idx_i = (int)(rs_next(rng) % (unsigned)m);
-                            bool dup = false;
-                            for (int j = 0; j < 7; j++) dup = dup || (j < i && idx[j] == idx_i);
-                            if (!dup) break;
-                        }
-                        for (int j = 0; j < 7; j++) idx[j] = (j == i) ? idx_i : idx[j];
-                        a1[2 * i] = p1[2 * idx_i]; a1[2 * i + 1] = p1[2 * idx_i + 1];
-                        a2[2 * i] = p2[2 * idx_i]; a2[2 * i + 1] = p2[2 * idx_i + 1];
-                        i++;
-                    }
-                    if (i == 7 && (rs_collinear(a1) || rs_collinear(a2))) continue;
+                    draw7(rng, S.idx + fb * 7);
+                    gather(fb);
+                    if (rs_collinear(S.ms1 + fb * 14) || rs_collinear(S.ms2 + fb * 14)) continue;
+                    ok = true;
                     break;
                 }
-                S.nm[h] = (i == 7 && attempts < 10000) ? 0 : -1;
-                if (S.nm[h] < 0) { for (int q = h + 1; q < B; q++) S.nm[q] = -1; break; }
+                S.nm[fb] = ok ? 0 : -1;
+                if (!ok) { for (int q = fb + 1; q < B; q++) S.nm[q] = -1; }
+                else for (int h = fb + 1; h < B; h++) { S.rngBefore[h] = rng; draw7(rng, S.idx + h * 7); S.nm[h] = 0; }
+                S.rng = rng;
             }
-            S.rng = rng;
+            __syncthreads();
+            if (S.nm[fb] < 0) break;
+            from = fb + 1;
         }
         __syncthreads();
         /* (b) one seven-point problem per lane */
