@@ -37,7 +37,9 @@
 #define BA_KFCH 1024          /* edges per keyframe-pass chunk */
 #define BA_KFBLK 4            /* workgroups per keyframe in the keyframe pass */
 #define BA_BIG_MAXF 64        /* free keyframes of a large window (6 bits of the free-edge key) */
-#define BA_GP 14              /* points per Schur group at most (k_ba_schur_g) */
+#ifndef BA_GP
+#define BA_GP 8               /* points per Schur group at most (k_ba_schur_g); see the kernel for how 8 was chosen */
+#endif
 #define BA_GRP_MAXPT 32768    /* windows up to this many points get a group table (one byte of LDS per point in the setup) */
 
 struct BaState {
@@ -752,11 +754,15 @@ k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ 
  * the two run on the same units and add up (18 MFMAs x 64 clocks + ~1500 clocks of linearisation per 4-point chunk and
  * SIMD: 212 k chunks x 2650 clocks / 1024 SIMDs = the measured 229 us per 170-window launch), and the vector phase runs on
  * the ~16 live lanes (one per free-keyframe edge) of 64. Here a wavefront takes a GROUP of whole points with up to 64
- * free-keyframe edges (k_ba_setup's greedy table: at most BA_GP points): ONE linearisation pass at ~70 % live lanes
- * fills a 48 x 44 tile, then the k-steps of the MFMA phase walk its columns. Records are prefetched one group ahead per
+ * free-keyframe edges (k_ba_setup's greedy table: at most BA_GP points): ONE linearisation pass fills a 48-row tile of
+ * 3 BA_GP columns, then the k-steps of the MFMA phase walk its columns. BA_GP = 14 (~46 live lanes, 75 KB of LDS per
+ * workgroup) is the fastest alone -- 6.3 ms per 512 windows against 7.3 for the chunk kernel -- but the SLOWEST inside the
+ * pipeline (24.0 ms per step against 23.7): two such workgroups fill a CU's LDS and the extractor's kernels on the other
+ * streams cannot co-reside. BA_GP = 8 (~26 live lanes, 45 KB) is 6.7 ms alone and the fastest in the step (23.2 ms);
+ * 6 / 10 / 12 measured 24.0 / 23.3 / 23.4. Records are prefetched one group ahead per
  * register set (an edge record and three point-record doubles per lane); the point records go through LDS, where the
  * edges of a point and the rhs pass (lane = row, U^T bl as LDS broadcasts) read them. */
-#define BA_GLD 45                       /* tile row stride in doubles: 3 BA_GP = 42 columns, padded to 44 by the k-steps, + 1 */
+#define BA_GLD ((((3 * BA_GP + 3) / 4) * 4) | 1)   /* tile row stride in doubles: 3 BA_GP columns, padded to whole k-steps, + 1 (odd) */
 #define BA_GHI (BA_GP * BA_REC)         /* 168 doubles of point records */
 #define BA_GWAVE_LDS_R(R) (16 * (R) * BA_GLD + 192 + 4)
 struct BaPreG {
@@ -823,7 +829,7 @@ k_ba_schur_g(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict_
         const unsigned qb = (unsigned)X.p0 * BA_REC + (unsigned)lane;
         X.r0 = Hq[min(qb, lastQ)];
         X.r1 = Hq[min(qb + 64u, lastQ)];
-        X.r2 = Hq[min(qb + 128u, lastQ)];
+        X.r2 = (BA_GP * BA_REC > 128) ? Hq[min(qb + 128u, lastQ)] : 0.0;
         X.cp0 = X.p0;
         X.cnp = X.p1 - X.p0;
         range(X, g + pf);
@@ -838,7 +844,7 @@ k_ba_schur_g(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict_
         BA_TK(5);
         Hi[lane] = X.r0;
         Hi[64 + lane] = X.r1;
-        Hi[128 + lane] = X.r2;                    /* doubles 168..191: spare */
+        if (BA_GP * BA_REC > 128) Hi[128 + lane] = X.r2;   /* the records end at BA_GP * BA_REC; the rest is spare */
         ba_wave_lds_fence();
         const bool live = X.key >= 0;
         const int pl = live ? (X.key >> 6) - p0 : 0, kf = live ? (X.key & 63) : 0;
