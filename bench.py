@@ -115,7 +115,10 @@ def pmc_traffic(kernel, units, geometry=None, detail=False):
             with open(path) as f:
                 doc = json.load(f)
             rec = doc["kernels"]
-            key = kernel if kernel in rec else {"k_resize": "k_resize_lds", "k_fast_cells": "k_fast_blocks"}.get(kernel, kernel)   # profile names
+            key = kernel
+            for alias in (kernel, {"k_resize": "k_resize_lds", "k_fast_cells": "k_fast_blocks", "k_ba_schur": "k_ba_schur_g"}.get(kernel)):
+                if alias in rec:     # the profile carries the kernel's function name, tb_profile_* its stage name
+                    key = alias
             if key not in rec:
                 continue
             # round-1 files carry no units: they were taken at 64 stereo frames (128 images) / 64 windows per launch

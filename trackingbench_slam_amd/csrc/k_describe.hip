@@ -117,11 +117,23 @@ __device__ __forceinline__ void ds_vcol(const uint32_t* h, uint8_t* out) {
 __global__ void __launch_bounds__(64)
 k_describe(PlanGeom g, const uint8_t* __restrict__ slab, const uint32_t* __restrict__ sel,
            const int32_t* __restrict__ selCount, tb_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
-           int32_t* __restrict__ counts) {
+           int32_t* __restrict__ counts, int nImages, int by_image) {
     __shared__ __attribute__((aligned(16))) uint8_t src[DS_P * DS_PS + 16];
     __shared__ __attribute__((aligned(16))) unsigned short hp[DS_P * DS_HS];
     __shared__ __attribute__((aligned(16))) uint8_t bl[(DS_B + 1) * DS_BS];   /* + one spare row: the v-pass stores unconditionally */
-    const int b = blockIdx.y, slot = blockIdx.x, lane = threadIdx.x;
+    /* workgroup -> (image, slot). by_image (batches): a 1-D grid in which XCD k (workgroup id mod 8) takes images k, k + 8,
+     * ... slot by slot, so that all patch gathers of an image go through ONE L2 (its pyramid, 2.5 MB at 1280x720, fits the
+     * 4 MB); otherwise (slot, image) order, every XCD works on every image. */
+    int b, slot;
+    if (by_image) {
+        const unsigned L = blockIdx.x, j = L >> 3, grp = j / (unsigned)g.selCap;
+        slot = (int)(j - grp * (unsigned)g.selCap);
+        b = (int)(grp * 8u + (L & 7u));
+        if (b >= nImages) return;
+    } else {
+        b = blockIdx.y; slot = blockIdx.x;
+    }
+    const int lane = threadIdx.x;
     const int32_t* sc = selCount + b * TB_MAX_LEVELS;
     /* slot -> (level, index), level-major output base */
     int level = 0, base = 0;
@@ -272,10 +284,11 @@ k_describe(PlanGeom g, const uint8_t* __restrict__ slab, const uint32_t* __restr
 
 int tbk_describe(tb_extractor* ex, int n) {
     tb_ctx* ctx = ex->ctx;
-    dim3 grid(ex->g.selCap, n);
+    const int by_image = n >= 64 ? 1 : 0;
+    const dim3 grid = by_image ? dim3((unsigned)ex->g.selCap * 8u * (unsigned)((n + 7) / 8)) : dim3(ex->g.selCap, n);
     tb_prof_begin(ctx, "k_describe");
     hipLaunchKernelGGL(k_describe, grid, dim3(64), 0, ctx->stream, ex->g, ex->d_slab, ex->d_sel, ex->d_selCount,
-                       ex->d_kps, ex->d_desc, ex->d_counts);
+                       ex->d_kps, ex->d_desc, ex->d_counts, n, by_image);
     tb_prof_end(ctx);
     TB_HIP(ctx, hipGetLastError());
     return TB_OK;

@@ -217,7 +217,9 @@ __device__ __forceinline__ void ft_process(const uint8_t* __restrict__ img, int 
 #define FB_SEGS (FB_S / 16)
 #define FB_NSEG_ALL (FB_SEGS * FB_TH)              /* 680 16-byte segments */
 #define FB_PX (FB_S * FB_TH)                       /* 10880 */
+#ifndef FB_LIST_CAP
 #define FB_LIST_CAP 3072
+#endif
 #define FB_REC_CAP FB_NSEG_ALL                     /* one 4-byte record per stage-1 work item: cannot overflow */
 #define FB_CL_CAP (FB_REC_CAP * 2)                 /* the corner list takes over the records' LDS */
 #define FB_OFF_R FB_PX                             /* Q, then the score map */
@@ -387,7 +389,7 @@ extern "C" int tb_debug_fast_times(unsigned long long* out, int reset) {
 #define FB_MINW 5
 #endif
 __global__ void __launch_bounds__(256, FB_MINW)   /* five blocks = 20 wavefronts per CU: at most 96 VGPRs */
-k_fast_blocks(PlanGeom g, const uint8_t* __restrict__ slab, const FastBlock* __restrict__ blocks, int nBlocks,
+k_fast_blocks(PlanGeom g, const uint8_t* __restrict__ slab, const FastBlock* __restrict__ blocks, int nBlocks, int nImages, int by_image,
               uint32_t* __restrict__ cand, int32_t* __restrict__ candCount, int init_th, int min_th, int force_dense) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
     uint8_t* const P = smem;
@@ -401,14 +403,26 @@ k_fast_blocks(PlanGeom g, const uint8_t* __restrict__ slab, const FastBlock* __r
     int* const misc = reinterpret_cast<int*>(smem + FB_OFF_MISC);
     /* misc: 0 records, 1 listed pixels, 2 corners, 3 cells with a survivor, 4 overflow */
 
-    /* Block b of an image is workgroup b: consecutive workgroups go round the 8 XCDs, so every XCD sees every level.
-     * (Measured: giving each XCD a CONTIGUOUS run of an image's blocks, so that neighbours share their overlap through one
-     * L2, cost 17 % -- 4.62 against 3.95 ms per 1024 images: the runs hold different pyramid levels, the small levels'
-     * blocks are lighter, and the XCD that always gets them idles. Round-robin chunks of 4 or 12 blocks are no better
-     * than plain order.) */
-    const int bid = (int)blockIdx.x;
+    /* Workgroup -> (image, block). Consecutive workgroup ids go round the 8 XCDs, each with its own L2.
+     *   by_image = 0 (few images): workgroup (x, y) = block x of image y, every XCD sees every level of every image.
+     *   by_image = 1 (batches): a 1-D grid in which XCD k works through images k, k + 8, ... block by block -- an image's
+     *     blocks share their 6-px overlaps and the partial 64-byte lines at their edges through ONE L2, and every XCD
+     *     gets whole images, i.e. the same mix of levels.
+     * Measured per 1024 images of 1280x720: an XCD-contiguous run of each image's blocks (round-2 first attempt) 4.62 ms at
+     * 1.03x the algorithmic HBM bytes -- the runs hold different pyramid levels, the XCD with the light ones idles; plain
+     * order 3.95 ms but 2.13x the bytes (neighbours land on different L2s); by image: see DESIGN.md section 4a. */
+    int bid, b;
+    if (by_image) {
+        const unsigned L = blockIdx.x, xcd = L & 7u, j = L >> 3;
+        const unsigned grp = j / (unsigned)nBlocks;
+        bid = (int)(j - grp * (unsigned)nBlocks);
+        b = (int)(grp * 8u + xcd);
+        if (b >= nImages) return;
+    } else {
+        bid = (int)blockIdx.x;
+        b = (int)blockIdx.y;
+    }
     if (bid >= nBlocks) return;
-    const int b = blockIdx.y;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const FastBlock blk = blocks[bid];
@@ -744,14 +758,16 @@ int tbk_fast_cells(tb_extractor* ex, int n, int init_th, int min_th) {
     tb_ctx* ctx = ex->ctx;
     TB_HIP(ctx, hipMemsetAsync(ex->d_candCount, 0, sizeof(int32_t) * TB_MAX_LEVELS * n, ctx->stream));
     if (ex->nBlocksTotal == 0) return TB_OK;
-    dim3 grid(ex->nBlocksTotal, n);
+    /* batches: an image per XCD at a time (see the kernel); a few images: plain (block, image) order so that all XCDs work */
+    const int by_image = n >= 64 ? 1 : 0;
+    const dim3 grid = by_image ? dim3((unsigned)ex->nBlocksTotal * 8u * (unsigned)((n + 7) / 8)) : dim3(ex->nBlocksTotal, n);
     static_assert(FB_LDS_BYTES - FB_PAD_LDS <= 32 * 1024, "five blocks per CU");
     /* test hook: TB_FAST_DENSE=1 sends every block down the any-density path (same results, no lists) */
     const char* fd_env = getenv("TB_FAST_DENSE");
     const int force_dense = (fd_env && fd_env[0] == '1') ? 1 : 0;
     tb_prof_begin(ctx, "k_fast_cells");
     hipLaunchKernelGGL(k_fast_blocks, grid, dim3(256), FB_LDS_BYTES, ctx->stream, ex->g, ex->d_slab, ex->d_blocks, ex->nBlocksTotal,
-                       ex->d_cand, ex->d_candCount, init_th, min_th, force_dense);
+                       n, by_image, ex->d_cand, ex->d_candCount, init_th, min_th, force_dense);
     tb_prof_end(ctx);
     TB_HIP(ctx, hipGetLastError());
     return TB_OK;

@@ -109,9 +109,13 @@ struct FastBlock {
     uint16_t invNss;        /*   ceil(32768 / nss): lane / nss == (lane * invNss) >> 15 for lane < 64 */
 };
 #define FB_S 160            /* LDS row stride of a block tile (bytes, 10 x 16) */
+#ifndef FB_TH
 #define FB_TH 68            /* tile rows */
+#endif
 #define FB_MAX_CX 4
+#ifndef FB_MAX_CY
 #define FB_MAX_CY 2
+#endif
 
 /* resize tables, built on the host with the oracle-identical double/float arithmetic */
 struct ResizeX { int16_t sx, sx1, a0, a1; };
