@@ -235,41 +235,43 @@ __device__ __forceinline__ void ft_process(const uint8_t* __restrict__ img, int 
 #define FB_LDS_BYTES (FB_OFF_MISC + 64 + FB_PAD_LDS)
 #define FB_RETRY_CAP 512                           /* pixels per retry strip (wave-private lists over LIST) */
 
-typedef short ft_s16x2 __attribute__((ext_vector_type(2)));
-__device__ __forceinline__ ft_s16x2 ft_pack(int a, int b) { return (ft_s16x2){(short)a, (short)b}; }
-__device__ __forceinline__ ft_s16x2 ft_min(ft_s16x2 a, ft_s16x2 b) { return __builtin_elementwise_min(a, b); }
-__device__ __forceinline__ ft_s16x2 ft_max(ft_s16x2 a, ft_s16x2 b) { return __builtin_elementwise_max(a, b); }
+typedef _Float16 ft_h2 __attribute__((ext_vector_type(2)));
+typedef unsigned ft_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ ft_h2 ft_h2_bits(uint32_t u) { return __builtin_bit_cast(ft_h2, u); }
+__device__ __forceinline__ ft_h2 ft_min3(ft_h2 a, ft_h2 b, ft_h2 c) { return __builtin_elementwise_minimum(__builtin_elementwise_minimum(a, b), c); }
+__device__ __forceinline__ ft_h2 ft_max3(ft_h2 a, ft_h2 b, ft_h2 c) { return __builtin_elementwise_maximum(__builtin_elementwise_maximum(a, b), c); }
 
 __device__ __forceinline__ void ft_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
 
-/* exact FAST-9 scores of two pixels (tile pointers pA, pB; row stride FB_S), packed: max over the 16 arcs of min(d) and
- * of min(-d), d = centre - ring; the min over a 9-arc is a doubling network (2, 4, 8, 8 + 1), every step one
- * v_pk_min_i16 / v_pk_max_i16 for both pixels. score = result - 1; a pixel is a corner at t iff score >= t. */
-__device__ __forceinline__ ft_s16x2 fb_score2(const uint8_t* pA, const uint8_t* pB) {
-    constexpr int S = FB_S;
-    const ft_s16x2 vv = ft_pack(pA[0], pB[0]);
-    ft_s16x2 d[16];
-    d[0] = vv - ft_pack(pA[3 * S], pB[3 * S]);           d[1] = vv - ft_pack(pA[3 * S + 1], pB[3 * S + 1]);
-    d[2] = vv - ft_pack(pA[2 * S + 2], pB[2 * S + 2]);   d[3] = vv - ft_pack(pA[S + 3], pB[S + 3]);
-    d[4] = vv - ft_pack(pA[3], pB[3]);                   d[5] = vv - ft_pack(pA[-S + 3], pB[-S + 3]);
-    d[6] = vv - ft_pack(pA[-2 * S + 2], pB[-2 * S + 2]); d[7] = vv - ft_pack(pA[-3 * S + 1], pB[-3 * S + 1]);
-    d[8] = vv - ft_pack(pA[-3 * S], pB[-3 * S]);         d[9] = vv - ft_pack(pA[-3 * S - 1], pB[-3 * S - 1]);
-    d[10] = vv - ft_pack(pA[-2 * S - 2], pB[-2 * S - 2]); d[11] = vv - ft_pack(pA[-S - 3], pB[-S - 3]);
-    d[12] = vv - ft_pack(pA[-3], pB[-3]);                d[13] = vv - ft_pack(pA[S - 3], pB[S - 3]);
-    d[14] = vv - ft_pack(pA[2 * S - 2], pB[2 * S - 2]);  d[15] = vv - ft_pack(pA[3 * S - 1], pB[3 * S - 1]);
-    ft_s16x2 lo2[16], hi2[16], lo4[16], hi4[16];
+/* exact FAST-9 score + 1 of the pixel at tile pointer p (row stride FB_S): max over the 16 arcs of min(d) and of min(-d),
+ * d = centre - ring; a pixel is a corner at t iff the result - 1 >= t.
+ * BOTH SIGNS RIDE IN ONE REGISTER as two half-precision numbers of the binade [1024, 2048), where one ulp is 1 and the
+ * bit pattern 0x6600 + x IS the number 1536 + x: with K = (0x6600 - v) << 16 | (0x6600 + v), one 24-bit multiply-add per
+ * ring pixel, r * 0xffff + K, leaves 1536 + d in the low half and 1536 - d in the high half (no borrow: 0x6600 + v >= r).
+ * The minimum over a 9-arc is two rounds of gfx950's three-input packed minimum (v_pk_minimum3_f16: 3 x 3), the maximum
+ * over the arcs a tree of v_pk_maximum3_f16 -- 16 + 32 + 8 vector instructions per pixel where the 16-bit integer
+ * min / max network of two-input instructions took ~105. All operands are positive normal numbers of one binade, so the
+ * floating-point order is the integer order of the differences and no rounding ever happens. */
+__device__ __forceinline__ int fb_score1(const uint8_t* p) {
+    constexpr int S = FB_S, C = 3 * FB_S + 3;
+    const uint8_t* q = p - C;                      /* every ring offset non-negative: immediate DS offsets */
+    const uint32_t v = q[C];
+    const uint32_t K = ((0x6600u - v) << 16) | (0x6600u + v);
+    constexpr int off[16] = {C + 3 * S, C + 3 * S + 1, C + 2 * S + 2, C + S + 3, C + 3, C - S + 3, C - 2 * S + 2, C - 3 * S + 1,
+                             C - 3 * S, C - 3 * S - 1, C - 2 * S - 2, C - S - 3, C - 3, C + S - 3, C + 2 * S - 2, C + 3 * S - 1};
+    ft_h2 e[16], m3[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) { lo2[k] = ft_min(d[k], d[(k + 1) & 15]); hi2[k] = ft_max(d[k], d[(k + 1) & 15]); }
+    for (int k = 0; k < 16; k++) e[k] = ft_h2_bits(__umul24((uint32_t)q[off[k]], 0xffffu) + K);
 #pragma unroll
-    for (int k = 0; k < 16; k++) { lo4[k] = ft_min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = ft_max(hi2[k], hi2[(k + 2) & 15]); }
-    ft_s16x2 best = (ft_s16x2){0, 0};
+    for (int k = 0; k < 16; k++) m3[k] = ft_min3(e[k], e[(k + 1) & 15], e[(k + 2) & 15]);
+    ft_h2 m9[16];
 #pragma unroll
-    for (int k = 0; k < 16; k++) {
-        const ft_s16x2 lo9 = ft_min(ft_min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]);   /* min over the 9-arc starting at k */
-        const ft_s16x2 hi9 = ft_max(ft_max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
-        best = ft_max(best, ft_max(lo9, -hi9));
-    }
-    return best;
+    for (int k = 0; k < 16; k++) m9[k] = ft_min3(m3[k], m3[(k + 3) & 15], m3[(k + 6) & 15]);   /* min over the 9-arc starting at k */
+    const ft_h2 a0 = ft_max3(m9[0], m9[1], m9[2]), a1 = ft_max3(m9[3], m9[4], m9[5]), a2 = ft_max3(m9[6], m9[7], m9[8]);
+    const ft_h2 a3 = ft_max3(m9[9], m9[10], m9[11]), a4 = ft_max3(m9[12], m9[13], m9[14]);
+    const ft_h2 b = ft_max3(ft_max3(a0, a1, a2), ft_max3(a3, a4, m9[15]), m9[15]);
+    const uint32_t bits = __builtin_bit_cast(uint32_t, b);
+    return (int)max(bits & 0xffffu, bits >> 16) - 0x6600;
 }
 
 /* exact cardinal pre-test at threshold th (one pixel per lane; retry and dense paths) */
@@ -345,8 +347,7 @@ __device__ __forceinline__ void fb_dense(uint8_t* P, uint8_t* SC, const uint8_t*
             if (x < sw) {
                 const int idx = y * FB_S + G.scanX0 + x;
                 if (fb_cardinal(P + idx, tlow)) {
-                    const ft_s16x2 best = fb_score2(P + idx, P + idx);
-                    const int s = (int)best.x - 1;
+                    const int s = fb_score1(P + idx) - 1;
                     if (s >= tlow && s > 0) SC[idx] = (uint8_t)min(s, 255);
                 }
             }
@@ -372,6 +373,20 @@ __device__ __forceinline__ void fb_dense(uint8_t* P, uint8_t* SC, const uint8_t*
         }
     }
 }
+
+/* verdict-word masks: pixel j = 4 d + k of a lane's 16 sits in bit 8 k + 7 - d; ge[n] = pixels j >= n, lt[n] = pixels j < n */
+struct FbMask { uint32_t ge[17], lt[17]; };
+constexpr FbMask fb_make_mask() {
+    FbMask m{};
+    for (int n = 0; n <= 16; n++)
+        for (int j = 0; j < 16; j++) {
+            const uint32_t bit = 1u << (8 * (j & 3) + 7 - (j >> 2));
+            if (j >= n) m.ge[n] |= bit;
+            if (j < n) m.lt[n] |= bit;
+        }
+    return m;
+}
+__constant__ FbMask c_fbmask = fb_make_mask();
 
 #ifdef FB_TIMING   /* debug build (make EXTRA=-DFB_TIMING): per-stage shader clocks of wavefront 0 of every 64th block */
 __device__ unsigned long long fb_times[16];
@@ -446,6 +461,13 @@ k_fast_blocks(PlanGeom g, const uint8_t* __restrict__ slab, const FastBlock* __r
     unsigned long long dt_[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #endif
 
+    /* stage 1's lane map (from the host, FastBlock) and the lane's valid-pixel mask -- tile columns [scanX0, scanX1) in the
+     * layout of the verdict word: two table reads, issued here so that they arrive behind stage 0's loads */
+    const int nss = blk.nss, rowsPer = blk.rowsPer;
+    const int rr = (lane * (int)blk.invNss) >> 15, ss = lane - rr * nss;
+    const int col16 = 16 * (blk.sA + ss);
+    const uint32_t valid = c_fbmask.ge[min(max(scanX0 - col16, 0), 16)] & c_fbmask.lt[min(max(scanX1 - col16, 0), 16)];
+
     /* ---- stage 0 */
     if (tid < 8) misc[tid] = 0;
     if (wave == 3) {   /* cell tables: one wavefront, three columns and a row per lane (the other three go straight to the loads) */
@@ -474,54 +496,50 @@ k_fast_blocks(PlanGeom g, const uint8_t* __restrict__ slab, const FastBlock* __r
     }
     {
         const bool wide = ((stride & 15) == 0) && ((reinterpret_cast<uintptr_t>(img) & 15) == 0);
-        uint4 v[3];
-        int o[3];
-        int row = (tid * 6554) >> 16, seg = tid - row * FB_SEGS;      /* segment tid: row tid / 10 */
+        const uint32_t M6 = 0x3f3f3f3fu;
+        if (wide) {
+            /* Tile row r, 16-byte segment s is LDS segment 10 r + s (FB_S = 160): thread tid takes segments tid, tid + 256,
+             * tid + 512. One buffer resource per block, base = (row y0, column ax0), bounded by the end of the ROI's last row
+             * (padding included: rows are stride bytes apart inside one allocation): rows below the ROI read as zero without
+             * touching memory, and so do the segments right of the ROI (offset out of range). All three loads are in flight
+             * before the first LDS store; no 64-bit addresses. */
+            const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+                const_cast<uint8_t*>(img) + (size_t)blk.y0 * stride + G.ax0, 0, rh * stride - G.ax0, 0x00020000);
+            ft_u4 v[3];
 #pragma unroll
-        for (int k = 0; k < 3; k++) {       /* all row-segment loads in flight before the first LDS store */
-            v[k] = make_uint4(0, 0, 0, 0);
-            o[k] = row * FB_S + 16 * seg;
-            if (row < rh && seg < nseg) {
-                const uint8_t* src = img + (size_t)(blk.y0 + row) * stride + (G.ax0 + 16 * seg);
-                if (wide) {
-                    v[k] = *reinterpret_cast<const uint4*>(src);
-                } else {                    /* caller-owned level 0 with an odd stride: bytes, bounded by the row */
-                    uint32_t w4[4] = {0, 0, 0, 0};
+            for (int k = 0; k < 3; k++) {
+                const int sidx = tid + 256 * k;
+                const int row = (sidx * 6554) >> 16, seg = sidx - row * FB_SEGS;      /* sidx / 10 */
+                v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, seg < nseg ? row * stride + 16 * seg : 0x7ffffff0, 0, 0);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; k++)
+                if (k < 2 || tid < FB_NSEG_ALL - 512) {
+                    const int o = 16 * (tid + 256 * k);
+                    *reinterpret_cast<ft_u4*>(P + o) = v[k];
+                    *reinterpret_cast<ft_u4*>(Q + o) = (v[k] >> 2) & M6;
+                }
+        } else {                        /* caller-owned level 0 with an odd stride: bytes, bounded by the row */
 #pragma unroll 1
+            for (int sidx = tid; sidx < FB_NSEG_ALL; sidx += 256) {
+                const int row = (sidx * 6554) >> 16, seg = sidx - row * FB_SEGS;
+                uint32_t w4[4] = {0, 0, 0, 0};
+                if (row < rh && seg < nseg) {
+                    const uint8_t* src = img + (size_t)(blk.y0 + row) * stride + (G.ax0 + 16 * seg);
+#pragma unroll
                     for (int j = 0; j < 16; j++)
                         if (G.ax0 + 16 * seg + j < L.w) w4[j >> 2] |= (uint32_t)src[j] << (8 * (j & 3));
-                    v[k] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
                 }
+                *reinterpret_cast<uint4*>(P + 16 * sidx) = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                *reinterpret_cast<uint4*>(Q + 16 * sidx) = make_uint4((w4[0] >> 2) & M6, (w4[1] >> 2) & M6, (w4[2] >> 2) & M6, (w4[3] >> 2) & M6);
             }
-            row += 25; seg += 6;            /* + 256 segments */
-            if (seg >= FB_SEGS) { seg -= FB_SEGS; row++; }
         }
-#pragma unroll
-        for (int k = 0; k < 3; k++)
-            if (o[k] < FB_PX) {
-                *reinterpret_cast<uint4*>(P + o[k]) = v[k];
-                const uint32_t M6 = 0x3f3f3f3fu;
-                *reinterpret_cast<uint4*>(Q + o[k]) = make_uint4((v[k].x >> 2) & M6, (v[k].y >> 2) & M6, (v[k].z >> 2) & M6, (v[k].w >> 2) & M6);
-            }
     }
     __syncthreads();
     FB_T(0);
 
     /* ---- stage 1: quantised cardinal test, 16 pixels per lane */
     {
-        const int nss = blk.nss, rowsPer = blk.rowsPer;      /* lane map from the host (FastBlock) */
-        const int rr = (lane * (int)blk.invNss) >> 15, ss = lane - rr * nss;
-        const int col16 = 16 * (blk.sA + ss);
-        uint32_t ms[4];                              /* valid-pixel masks of the lane's four dwords, bit 7 of each byte, pre-shifted */
-#pragma unroll
-        for (int d = 0; d < 4; d++) {
-            /* bytes k of dword d cover tile columns col16 + 4 d + k: valid inside [scanX0, scanX1) */
-            const int c0 = col16 + 4 * d;
-            const int lo = min(max(scanX0 - c0, 0), 4), hi = min(max(scanX1 - c0, 0), 4);   /* valid bytes [lo, hi) */
-            const uint32_t below_hi = hi >= 4 ? 0xffffffffu : ((1u << (8 * hi)) - 1u);
-            const uint32_t below_lo = lo >= 4 ? 0xffffffffu : ((1u << (8 * lo)) - 1u);
-            ms[d] = ((below_hi & ~below_lo) & 0x80808080u) >> d;
-        }
         const int tq = (init_th + 1) >> 2;
         const uint32_t K = (uint32_t)(128 - tq) * 0x01010101u;
         const int nPass = blk.nPass;
@@ -549,7 +567,7 @@ k_fast_blocks(PlanGeom g, const uint8_t* __restrict__ slab, const FastBlock* __r
                     F[d] = (b08 & b412) | (d08 & d412);
                 }
                 /* 16 verdicts -> one word: dword d's land in bit 7 - d of every byte */
-                Gm = (F[0] & ms[0]) | ((F[1] >> 1) & ms[1]) | ((F[2] >> 2) & ms[2]) | ((F[3] >> 3) & ms[3]);
+                Gm = ((F[0] & 0x80808080u) | ((F[1] >> 1) & 0x40404040u) | ((F[2] >> 2) & 0x20202020u) | ((F[3] >> 3) & 0x10101010u)) & valid;
             }
             const bool hit = Gm != 0;
             const unsigned long long bm = __ballot(hit);
@@ -600,27 +618,24 @@ k_fast_blocks(PlanGeom g, const uint8_t* __restrict__ slab, const FastBlock* __r
     __syncthreads();
     FB_T(2);
 
-    /* ---- stage 2b: exact scores, two pixels per lane, batches of 128 dealt to the wavefronts */
+    /* ---- stage 2b: exact scores, one pixel per lane, batches of 64 dealt to the wavefronts */
     const int npx = misc[1];
     dense = dense || npx > FB_LIST_CAP;
     if (!dense) {
-        for (int base = 128 * wave; base < npx; base += 512) {
-            const int iA = base + lane, iB = iA + 64;
-            const bool vA = iA < npx, vB = iB < npx;
-            const int idxA = vA ? LIST[iA] : (3 * FB_S + 4), idxB = vB ? LIST[iB] : (3 * FB_S + 4);
-            const ft_s16x2 best = fb_score2(P + idxA, P + idxB);
-            const int sa = (int)best.x - 1, sb = (int)best.y - 1;
-            const bool cA = vA && sa >= init_th && sa > 0, cB = vB && sb >= init_th && sb > 0;
-            const unsigned long long mA = __ballot(cA), mB = __ballot(cB);
-            const int nA = __popcll(mA), nB = __popcll(mB);
-            if (nA + nB) {
+        for (int base = 64 * wave; base < npx; base += 256) {
+            const int i = base + lane;
+            const bool v = i < npx;
+            const int idx = v ? LIST[i] : (3 * FB_S + 4);
+            const int s = fb_score1(P + idx) - 1;
+            const bool c = v && s >= init_th && s > 0;
+            const unsigned long long m = __ballot(c);
+            if (m) {
                 int wbase = 0;
-                if (lane == 0) wbase = atomicAdd(&misc[2], nA + nB);
+                if (lane == 0) wbase = atomicAdd(&misc[2], __popcll(m));
                 wbase = __builtin_amdgcn_readfirstlane(wbase);
-                if (wbase + nA + nB <= FB_CL_CAP) {
-                    const unsigned long long below = (1ull << lane) - 1;
-                    if (cA) { CL[wbase + __popcll(mA & below)] = (uint16_t)idxA; SC[idxA] = (uint8_t)min(sa, 255); }
-                    if (cB) { CL[wbase + nA + __popcll(mB & below)] = (uint16_t)idxB; SC[idxB] = (uint8_t)min(sb, 255); }
+                if (wbase + __popcll(m) <= FB_CL_CAP && c) {
+                    CL[wbase + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)idx;
+                    SC[idx] = (uint8_t)min(s, 255);
                 }
             }
         }
@@ -674,24 +689,21 @@ k_fast_blocks(PlanGeom g, const uint8_t* __restrict__ slab, const FastBlock* __r
                             n += __popcll(bm);
                         }
                     ft_lds_fence();
-                    for (int base = 0; base < n; base += 128) {
-                        const int iA = base + lane, iB = iA + 64;
-                        const bool vA = iA < n, vB = iB < n;
-                        const int idxA = vA ? rl[iA] : (3 * FB_S + 4), idxB = vB ? rl[iB] : (3 * FB_S + 4);
-                        const ft_s16x2 best = fb_score2(P + idxA, P + idxB);
-                        const int sa = (int)best.x - 1, sb = (int)best.y - 1;
+                    for (int base = 0; base < n; base += 64) {
+                        const int i = base + lane;
+                        const bool v = i < n;
+                        const int idx = v ? rl[i] : (3 * FB_S + 4);
+                        const int s = fb_score1(P + idx) - 1;
                         /* corners at minTh that pass 1 has not listed already */
-                        const bool cA = vA && sa >= min_th && sa > 0 && sa < init_th, cB = vB && sb >= min_th && sb > 0 && sb < init_th;
-                        const unsigned long long mA = __ballot(cA), mB = __ballot(cB);
-                        const int nA = __popcll(mA), nB = __popcll(mB);
-                        if (nA + nB) {
+                        const bool c = v && s >= min_th && s > 0 && s < init_th;
+                        const unsigned long long m = __ballot(c);
+                        if (m) {
                             int wbase = 0;
-                            if (lane == 0) wbase = atomicAdd(&misc[2], nA + nB);
+                            if (lane == 0) wbase = atomicAdd(&misc[2], __popcll(m));
                             wbase = __builtin_amdgcn_readfirstlane(wbase);
-                            if (wbase + nA + nB <= FB_CL_CAP) {
-                                const unsigned long long below = (1ull << lane) - 1;
-                                if (cA) { CL[wbase + __popcll(mA & below)] = (uint16_t)idxA; SC[idxA] = (uint8_t)sa; }
-                                if (cB) { CL[wbase + nA + __popcll(mB & below)] = (uint16_t)idxB; SC[idxB] = (uint8_t)sb; }
+                            if (wbase + __popcll(m) <= FB_CL_CAP && c) {
+                                CL[wbase + __popcll(m & ((1ull << lane) - 1))] = (uint16_t)idx;
+                                SC[idx] = (uint8_t)s;
                             }
                         }
                     }
