@@ -114,26 +114,42 @@ __device__ __forceinline__ void ds_vcol(const uint32_t* h, uint8_t* out) {
  *   v-pass    the 39 x 39 outputs over ALL lanes: columns 0-31 as two half columns of 20 rows per lane, then columns
  *             32-38 as eight 5-row pieces; u16 inputs, three v_dot2_u32_u16 + one multiply-add per output;
  *   tests     4 x 64 rotated comparisons -> 4 ballots. */
-__global__ void __launch_bounds__(64)
+#define DS_KPB 4     /* keypoints (wavefronts) per workgroup */
+
+__device__ __forceinline__ void ds_wave_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); }
+
+__global__ void __launch_bounds__(64 * DS_KPB)
 k_describe(PlanGeom g, const uint8_t* __restrict__ slab, const uint32_t* __restrict__ sel,
            const int32_t* __restrict__ selCount, tb_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
-           int32_t* __restrict__ counts, int nImages, int by_image) {
-    __shared__ __attribute__((aligned(16))) uint8_t src[DS_P * DS_PS + 16];
-    __shared__ __attribute__((aligned(16))) unsigned short hp[DS_P * DS_HS];
-    __shared__ __attribute__((aligned(16))) uint8_t bl[(DS_B + 1) * DS_BS];   /* + one spare row: the v-pass stores unconditionally */
-    /* workgroup -> (image, slot). by_image (batches): a 1-D grid in which XCD k (workgroup id mod 8) takes images k, k + 8,
-     * ... slot by slot, so that all patch gathers of an image go through ONE L2 (its pyramid, 2.5 MB at 1280x720, fits the
-     * 4 MB); otherwise (slot, image) order, every XCD works on every image. */
-    int b, slot;
+           int32_t* __restrict__ counts, int nImages, int by_image, int slotGroups) {
+    __shared__ __attribute__((aligned(16))) uint8_t src_[DS_KPB][DS_P * DS_PS + 16];
+    __shared__ __attribute__((aligned(16))) unsigned short hp_[DS_KPB][DS_P * DS_HS];
+    __shared__ __attribute__((aligned(16))) uint8_t bl_[DS_KPB][(DS_B + 1) * DS_BS];   /* + one spare row: the v-pass stores unconditionally */
+    __shared__ int mom[DS_KPB][2];
+    __shared__ float rot[DS_KPB][4];
+    /* A workgroup = DS_KPB wavefronts = DS_KPB consecutive slots of one image, one keypoint per wavefront with its own patch
+     * buffers. The wavefronts meet twice: the orientation of a keypoint (fastAtan2, then sinf / cosf in the double-precision form
+     * that matches glibc bit for bit: ~100 wave-uniform vector instructions, an eighth of the kernel when every wavefront ran
+     * them on 64 identical lanes) is computed for all DS_KPB keypoints at once on DS_KPB lanes of wavefront 0, while the others are in
+     * their blur passes.
+     * workgroup -> (image, slot group). by_image (batches): a 1-D grid in which XCD k (workgroup id mod 8) takes images k, k + 8,
+     * ... group by group, so that all patch gathers of an image go through ONE L2 (its pyramid, 2.5 MB at 1280x720, fits the
+     * 4 MB); otherwise (group, image) order, every XCD works on every image. */
+    int b, sg;
     if (by_image) {
-        const unsigned L = blockIdx.x, j = L >> 3, grp = j / (unsigned)g.selCap;
-        slot = (int)(j - grp * (unsigned)g.selCap);
+        const unsigned L = blockIdx.x, j = L >> 3, grp = j / (unsigned)slotGroups;
+        sg = (int)(j - grp * (unsigned)slotGroups);
         b = (int)(grp * 8u + (L & 7u));
         if (b >= nImages) return;
     } else {
-        b = blockIdx.y; slot = blockIdx.x;
+        b = blockIdx.y; sg = blockIdx.x;
     }
-    const int lane = threadIdx.x;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int slot = sg * DS_KPB + wave;
+    uint8_t* const src = src_[wave];
+    unsigned short* const hp = hp_[wave];
+    uint8_t* const bl = bl_[wave];
     const int32_t* sc = selCount + b * TB_MAX_LEVELS;
     /* slot -> (level, index), level-major output base */
     int level = 0, base = 0;
@@ -148,105 +164,120 @@ k_describe(PlanGeom g, const uint8_t* __restrict__ slab, const uint32_t* __restr
     }
     const LevelGeom& G = g.lv[level];
     const int idx = slot - G.selBase;
-    if (idx >= sc[level]) return;
-    const uint32_t rec = sel[(size_t)b * g.selCap + slot];
-    const int kx = (int)(rec & 0xfff) + TB_BORDER, ky = (int)((rec >> 12) & 0xfff) + TB_BORDER;
-    int stride;
-    const uint8_t* img = tb_level_ptr(g, slab, b, level, &stride);
+    const bool active = slot < g.selCap && idx < sc[level];      /* wave-uniform; idle wavefronts still meet the barriers */
+    uint32_t rec = 0;
+    int kx = 0, ky = 0, sh = 0;
+    if (active) {
+        rec = sel[(size_t)b * g.selCap + slot];
+        kx = (int)(rec & 0xfff) + TB_BORDER; ky = (int)((rec >> 12) & 0xfff) + TB_BORDER;
+        int stride;
+        const uint8_t* img = tb_level_ptr(g, slab, b, level, &stride);
 
-    /* 1. stage the source patch: patch column c lives at LDS column c + sh */
-    const int x0 = kx - 22, y0 = ky - 22;
-    const bool interior = x0 >= 0 && y0 >= 0 && kx + 22 < G.w && ky + 22 < G.h && ((stride & 3) == 0) &&
-                          ((reinterpret_cast<uintptr_t>(img) & 3) == 0) && ((x0 & ~3) + 52 <= stride);
-    const int sh = interior ? (x0 & 3) : 0;
-    if (interior) {
-        const int rr = (lane * 5042) >> 16, dd = lane - rr * 13; /* lane / 13: 4 rows x 13 dwords per pass, lanes 52..63 idle */
-        const uint8_t* srcp = img + (size_t)y0 * stride + (x0 & ~3) + 4 * dd;
-        uint32_t v[12];
+        /* 1. stage the source patch: patch column c lives at LDS column c + sh */
+        const int x0 = kx - 22, y0 = ky - 22;
+        const bool interior = x0 >= 0 && y0 >= 0 && kx + 22 < G.w && ky + 22 < G.h && ((stride & 3) == 0) &&
+                              ((reinterpret_cast<uintptr_t>(img) & 3) == 0) && ((x0 & ~3) + 52 <= stride);
+        sh = interior ? (x0 & 3) : 0;
+        if (interior) {
+            const int rr = (lane * 5042) >> 16, dd = lane - rr * 13; /* lane / 13: 4 rows x 13 dwords per pass, lanes 52..63 idle */
+            const uint8_t* srcp = img + (size_t)y0 * stride + (x0 & ~3) + 4 * dd;
+            uint32_t v[12];
 #pragma unroll
-        for (int j = 0; j < 12; j++) {
-            const int r = 4 * j + rr;
-            v[j] = 0;
-            if (rr < 4 && r < DS_P) v[j] = *reinterpret_cast<const uint32_t*>(srcp + (size_t)r * stride);
-        }
+            for (int j = 0; j < 12; j++) {
+                const int r = 4 * j + rr;
+                v[j] = 0;
+                if (rr < 4 && r < DS_P) v[j] = *reinterpret_cast<const uint32_t*>(srcp + (size_t)r * stride);
+            }
 #pragma unroll
-        for (int j = 0; j < 12; j++) {
-            const int r = 4 * j + rr;
-            if (rr < 4 && r < DS_P) *reinterpret_cast<uint32_t*>(src + r * DS_PS + 4 * dd) = v[j];
+            for (int j = 0; j < 12; j++) {
+                const int r = 4 * j + rr;
+                if (rr < 4 && r < DS_P) *reinterpret_cast<uint32_t*>(src + r * DS_PS + 4 * dd) = v[j];
+            }
+        } else {
+            for (int e = lane; e < DS_P * DS_P; e += 64) {
+                const int r = e / DS_P, c = e - r * DS_P;
+                const int yy = ds_reflect(y0 + r, G.h), xx = ds_reflect(x0 + c, G.w);
+                src[r * DS_PS + c] = img[(size_t)yy * stride + xx];
+            }
         }
-    } else {
-        for (int e = lane; e < DS_P * DS_P; e += 64) {
-            const int r = e / DS_P, c = e - r * DS_P;
-            const int yy = ds_reflect(y0 + r, G.h), xx = ds_reflect(x0 + c, G.w);
-            src[r * DS_PS + c] = img[(size_t)yy * stride + xx];
+        ds_wave_fence();
+
+        /* 2. IC_Angle: integer moments over the radius-15 disc, lane = disc row v = lane - 15 */
+        int m10 = 0, m01 = 0;
+        if (lane < 31) {
+            const int v = lane - 15, av = v < 0 ? -v : v;
+            const int o = 7 + sh;                                  /* byte of u = -15 in the row (patch column 22 - 15) */
+            const uint32_t* rw = reinterpret_cast<const uint32_t*>(src + (22 + v) * DS_PS) + (o >> 2);
+            const uint4* t1 = reinterpret_cast<const uint4*>(c_disc.w1[av]);
+            const uint4* tu = reinterpret_cast<const uint4*>(c_disc.wu[av]);
+            const uint4 a0 = t1[0], a1 = t1[1], u0 = tu[0], u1 = tu[1];
+            const uint32_t w1[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
+            const uint32_t wu[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
+            uint32_t w[9];
+#pragma unroll
+            for (int k = 0; k < 9; k++) w[k] = rw[k];
+            uint32_t sI = 0, sW = 0;
+#pragma unroll
+            for (int k = 0; k < 8; k++) {
+                const uint32_t X = __builtin_amdgcn_alignbyte(w[k + 1], w[k], (uint32_t)(o & 3));
+                sI = __builtin_amdgcn_udot4(X, w1[k], sI, false);
+                sW = __builtin_amdgcn_udot4(X, wu[k], sW, false);
+            }
+            m10 = (int)sW - 16 * (int)sI;    /* sum u I = sum (u + 16) I - 16 sum I */
+            m01 = v * (int)sI;
         }
+        m10 = tb_wave_incl_scan_dpp(m10);
+        m01 = tb_wave_incl_scan_dpp(m01);
+        if (lane == 63) { mom[wave][0] = m10; mom[wave][1] = m01; }
     }
     __syncthreads();
 
-    /* 2. IC_Angle: integer moments over the radius-15 disc, lane = disc row v = lane - 15 */
-    int m10 = 0, m01 = 0;
-    if (lane < 31) {
-        const int v = lane - 15, av = v < 0 ? -v : v;
-        const int o = 7 + sh;                                  /* byte of u = -15 in the row (patch column 22 - 15) */
-        const uint32_t* rw = reinterpret_cast<const uint32_t*>(src + (22 + v) * DS_PS) + (o >> 2);
-        const uint4* t1 = reinterpret_cast<const uint4*>(c_disc.w1[av]);
-        const uint4* tu = reinterpret_cast<const uint4*>(c_disc.wu[av]);
-        const uint4 a0 = t1[0], a1 = t1[1], u0 = tu[0], u1 = tu[1];
-        const uint32_t w1[8] = {a0.x, a0.y, a0.z, a0.w, a1.x, a1.y, a1.z, a1.w};
-        const uint32_t wu[8] = {u0.x, u0.y, u0.z, u0.w, u1.x, u1.y, u1.z, u1.w};
-        uint32_t w[9];
-#pragma unroll
-        for (int k = 0; k < 9; k++) w[k] = rw[k];
-        uint32_t sI = 0, sW = 0;
-#pragma unroll
-        for (int k = 0; k < 8; k++) {
-            const uint32_t X = __builtin_amdgcn_alignbyte(w[k + 1], w[k], (uint32_t)(o & 3));
-            sI = __builtin_amdgcn_udot4(X, w1[k], sI, false);
-            sW = __builtin_amdgcn_udot4(X, wu[k], sW, false);
-        }
-        m10 = (int)sW - 16 * (int)sI;    /* sum u I = sum (u + 16) I - 16 sum I */
-        m01 = v * (int)sI;
+    /* 2b. orientations of the workgroup's keypoints, one lane each (ORBextractor.cpp:43, :52-55) */
+    if (wave == 0 && lane < DS_KPB) {
+        const float angle = tbm::fast_atan2((float)mom[lane][1], (float)mom[lane][0]);
+        const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+        float a, bsin;
+        tbm::sincosf_rn(TB_FMUL(angle, factorPI), &bsin, &a);
+        rot[lane][0] = angle; rot[lane][1] = a; rot[lane][2] = bsin;
     }
-    m10 = __builtin_amdgcn_readlane(tb_wave_incl_scan_dpp(m10), 63);
-    m01 = __builtin_amdgcn_readlane(tb_wave_incl_scan_dpp(m01), 63);
-    const float angle = tbm::fast_atan2((float)m01, (float)m10);
 
-    /* 3a. horizontal 7-tap pass, one lane per patch row (exact integers, u16 result) */
-    if (lane < DS_P) {
-        const uint32_t* rw = reinterpret_cast<const uint32_t*>(src + lane * DS_PS);
-        uint32_t w[14];
+    if (active) {
+        /* 3a. horizontal 7-tap pass, one lane per patch row (exact integers, u16 result) */
+        if (lane < DS_P) {
+            const uint32_t* rw = reinterpret_cast<const uint32_t*>(src + lane * DS_PS);
+            uint32_t w[14];
 #pragma unroll
-        for (int j = 0; j < 13; j++) w[j] = rw[j];
-        w[13] = 0;
-        unsigned short* out = hp + lane * DS_HS;
-        /* the sub-dword phase of the patch: four code paths with compile-time byte offsets */
-        if (sh == 0) ds_hrow<0>(w, out); else if (sh == 1) ds_hrow<1>(w, out); else if (sh == 2) ds_hrow<2>(w, out); else ds_hrow<3>(w, out);
+            for (int j = 0; j < 13; j++) w[j] = rw[j];
+            w[13] = 0;
+            unsigned short* out = hp + lane * DS_HS;
+            /* the sub-dword phase of the patch: four code paths with compile-time byte offsets */
+            if (sh == 0) ds_hrow<0>(w, out); else if (sh == 1) ds_hrow<1>(w, out); else if (sh == 2) ds_hrow<2>(w, out); else ds_hrow<3>(w, out);
+        }
+        ds_wave_fence();
+        /* 3b. vertical pass over all 64 lanes */
+        {
+            /* columns 0..31: lane = (column, upper / lower half): rows [0, 20) and [20, 39) */
+            const int c = lane & 31, r0 = 20 * (lane >> 5);
+            uint32_t h[26];
+#pragma unroll
+            for (int i = 0; i < 26; i++) h[i] = hp[min(r0 + i, DS_P - 1) * DS_HS + c];
+            ds_vcol<20>(h, bl + r0 * DS_BS + c);          /* the lower half's 20th output is row 39: the spare row */
+        }
+        {
+            /* columns 32..38: lane = (column, one of eight 5-row pieces) */
+            const int cc = lane & 7, r0 = 5 * (lane >> 3);
+            const int c = 32 + min(cc, 6);
+            uint32_t h[11];
+#pragma unroll
+            for (int i = 0; i < 11; i++) h[i] = hp[min(r0 + i, DS_P - 1) * DS_HS + c];
+            ds_vcol<5>(h, bl + r0 * DS_BS + c);           /* lanes with cc == 7 repeat column 38 (same values); rows reach 39 at most */
+        }
     }
     __syncthreads();
-    /* 3b. vertical pass over all 64 lanes */
-    {
-        /* columns 0..31: lane = (column, upper / lower half): rows [0, 20) and [20, 39) */
-        const int c = lane & 31, r0 = 20 * (lane >> 5);
-        uint32_t h[26];
-#pragma unroll
-        for (int i = 0; i < 26; i++) h[i] = hp[min(r0 + i, DS_P - 1) * DS_HS + c];
-        ds_vcol<20>(h, bl + r0 * DS_BS + c);          /* the lower half's 20th output is row 39: the spare row */
-    }
-    {
-        /* columns 32..38: lane = (column, one of eight 5-row pieces) */
-        const int cc = lane & 7, r0 = 5 * (lane >> 3);
-        const int c = 32 + min(cc, 6);
-        uint32_t h[11];
-#pragma unroll
-        for (int i = 0; i < 11; i++) h[i] = hp[min(r0 + i, DS_P - 1) * DS_HS + c];
-        ds_vcol<5>(h, bl + r0 * DS_BS + c);           /* lanes with cc == 7 repeat column 38 (same values); rows reach 39 at most */
-    }
-    __syncthreads();
+    if (!active) return;
 
     /* 4. steered BRIEF, ORBextractor.cpp:52-84 */
-    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
-    float a, bsin;
-    tbm::sincosf_rn(TB_FMUL(angle, factorPI), &bsin, &a);
+    const float angle = rot[wave][0], a = rot[wave][1], bsin = rot[wave][2];
     const uint8_t* center = bl + 19 * DS_BS + 19;
     const size_t out = (size_t)b * g.selCap + base + idx;
     unsigned long long* d64 = reinterpret_cast<unsigned long long*>(desc + out * 32);
@@ -285,10 +316,11 @@ k_describe(PlanGeom g, const uint8_t* __restrict__ slab, const uint32_t* __restr
 int tbk_describe(tb_extractor* ex, int n) {
     tb_ctx* ctx = ex->ctx;
     const int by_image = n >= 64 ? 1 : 0;
-    const dim3 grid = by_image ? dim3((unsigned)ex->g.selCap * 8u * (unsigned)((n + 7) / 8)) : dim3(ex->g.selCap, n);
+    const int slotGroups = (ex->g.selCap + DS_KPB - 1) / DS_KPB;
+    const dim3 grid = by_image ? dim3((unsigned)slotGroups * 8u * (unsigned)((n + 7) / 8)) : dim3(slotGroups, n);
     tb_prof_begin(ctx, "k_describe");
-    hipLaunchKernelGGL(k_describe, grid, dim3(64), 0, ctx->stream, ex->g, ex->d_slab, ex->d_sel, ex->d_selCount,
-                       ex->d_kps, ex->d_desc, ex->d_counts, n, by_image);
+    hipLaunchKernelGGL(k_describe, grid, dim3(64 * DS_KPB), 0, ctx->stream, ex->g, ex->d_slab, ex->d_sel, ex->d_selCount,
+                       ex->d_kps, ex->d_desc, ex->d_counts, n, by_image, slotGroups);
     tb_prof_end(ctx);
     TB_HIP(ctx, hipGetLastError());
     return TB_OK;
