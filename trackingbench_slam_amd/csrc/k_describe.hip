@@ -49,7 +49,7 @@ constexpr DsDisc ds_make_disc() {
 __constant__ __attribute__((aligned(16))) DsDisc c_disc = ds_make_disc();
 
 #define DS_P 45      /* source patch edge */
-#define DS_PS 52     /* source patch row stride: 13 dwords (odd) -> one-row-per-lane accesses hit distinct banks */
+#define DS_PS 84     /* source patch row stride: 21 dwords (odd) -> one-row-per-lane accesses hit distinct banks; = the h-pass row (below) */
 #define DS_B 39      /* blurred patch edge */
 #define DS_HS 42     /* h-pass row stride in u16 (21 dwords, odd) */
 #define DS_BS 40     /* blurred patch row stride */
@@ -122,9 +122,12 @@ __global__ void __launch_bounds__(64 * DS_KPB)
 k_describe(PlanGeom g, const uint8_t* __restrict__ slab, const uint32_t* __restrict__ sel,
            const int32_t* __restrict__ selCount, tb_keypoint* __restrict__ kps, uint8_t* __restrict__ desc,
            int32_t* __restrict__ counts, int nImages, int by_image, int slotGroups) {
-    __shared__ __attribute__((aligned(16))) uint8_t src_[DS_KPB][DS_P * DS_PS + 16];
-    __shared__ __attribute__((aligned(16))) unsigned short hp_[DS_KPB][DS_P * DS_HS];
-    __shared__ __attribute__((aligned(16))) uint8_t bl_[DS_KPB][(DS_B + 1) * DS_BS];   /* + one spare row: the v-pass stores unconditionally */
+    /* ONE patch buffer per keypoint, three tenants in turn: the source patch (rows of 84 bytes, 52 used), the h-pass sums (u16, the
+     * same 84-byte rows: every lane has its whole source row in registers before it stores), the blurred patch (40-byte rows from
+     * offset 0: every lane has all its h-pass operands in registers before the first store). 3.8 KB per keypoint instead of 7.7:
+     * the kernel's occupancy is bound by LDS (20 -> 32 wavefronts per CU, now the register limit). */
+    static_assert(DS_PS == DS_HS * 2, "source rows and h-pass rows share their LDS");
+    __shared__ __attribute__((aligned(16))) uint8_t buf_[DS_KPB][DS_P * DS_PS + 16];
     __shared__ int mom[DS_KPB][2];
     __shared__ float rot[DS_KPB][4];
     /* A workgroup = DS_KPB wavefronts = DS_KPB consecutive slots of one image, one keypoint per wavefront with its own patch
@@ -147,9 +150,9 @@ k_describe(PlanGeom g, const uint8_t* __restrict__ slab, const uint32_t* __restr
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int slot = sg * DS_KPB + wave;
-    uint8_t* const src = src_[wave];
-    unsigned short* const hp = hp_[wave];
-    uint8_t* const bl = bl_[wave];
+    uint8_t* const src = buf_[wave];
+    unsigned short* const hp = reinterpret_cast<unsigned short*>(buf_[wave]);
+    uint8_t* const bl = buf_[wave];
     const int32_t* sc = selCount + b * TB_MAX_LEVELS;
     /* slot -> (level, index), level-major output base */
     int level = 0, base = 0;
@@ -254,23 +257,21 @@ k_describe(PlanGeom g, const uint8_t* __restrict__ slab, const uint32_t* __restr
             if (sh == 0) ds_hrow<0>(w, out); else if (sh == 1) ds_hrow<1>(w, out); else if (sh == 2) ds_hrow<2>(w, out); else ds_hrow<3>(w, out);
         }
         ds_wave_fence();
-        /* 3b. vertical pass over all 64 lanes */
+        /* 3b. vertical pass over all 64 lanes: all operands first (the outputs overwrite them) */
         {
             /* columns 0..31: lane = (column, upper / lower half): rows [0, 20) and [20, 39) */
             const int c = lane & 31, r0 = 20 * (lane >> 5);
-            uint32_t h[26];
+            /* columns 32..38: lane = (column, one of eight 5-row pieces) */
+            const int cc = lane & 7, q0 = 5 * (lane >> 3);
+            const int c2 = 32 + min(cc, 6);
+            uint32_t h[26], h2[11];
 #pragma unroll
             for (int i = 0; i < 26; i++) h[i] = hp[min(r0 + i, DS_P - 1) * DS_HS + c];
-            ds_vcol<20>(h, bl + r0 * DS_BS + c);          /* the lower half's 20th output is row 39: the spare row */
-        }
-        {
-            /* columns 32..38: lane = (column, one of eight 5-row pieces) */
-            const int cc = lane & 7, r0 = 5 * (lane >> 3);
-            const int c = 32 + min(cc, 6);
-            uint32_t h[11];
 #pragma unroll
-            for (int i = 0; i < 11; i++) h[i] = hp[min(r0 + i, DS_P - 1) * DS_HS + c];
-            ds_vcol<5>(h, bl + r0 * DS_BS + c);           /* lanes with cc == 7 repeat column 38 (same values); rows reach 39 at most */
+            for (int i = 0; i < 11; i++) h2[i] = hp[min(q0 + i, DS_P - 1) * DS_HS + c2];
+            ds_wave_fence();
+            ds_vcol<20>(h, bl + r0 * DS_BS + c);          /* the lower half's 20th output is row 39: the spare row */
+            ds_vcol<5>(h2, bl + q0 * DS_BS + c2);         /* lanes with cc == 7 repeat column 38 (same values); rows reach 39 at most */
         }
     }
     __syncthreads();
