@@ -214,6 +214,10 @@ __device__ __forceinline__ void ft_process(const uint8_t* __restrict__ img, int 
  * average of textured frames); a block that overflows them -- dense noise, thresholds near zero -- is redone by
  * fb_dense(): scores of all scanned pixels straight into the map, then per cell threshold choice, NMS and emission by
  * scanning the map. No list, any density, same results (tests force it with TB_FAST_DENSE=1). */
+#ifndef FB_NW
+#define FB_NW 4                                    /* wavefronts per block */
+#endif
+#define FB_NT (64 * FB_NW)
 #define FB_SEGS (FB_S / 16)
 #define FB_NSEG_ALL (FB_SEGS * FB_TH)              /* 680 16-byte segments */
 #define FB_PX (FB_S * FB_TH)                       /* 10880 */
@@ -337,11 +341,11 @@ __device__ __forceinline__ void fb_emit_wave(bool e, uint32_t rec, int lane, int
 __device__ __forceinline__ void fb_dense(uint8_t* P, uint8_t* SC, const uint8_t* colinfo, const uint8_t* rowinfo, const FbGeom G,
                                       int init_th, int min_th, int* __restrict__ count, uint32_t* __restrict__ out, int cap) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    for (int i = tid; i < FB_PX / 16; i += 256) reinterpret_cast<uint4*>(SC)[i] = make_uint4(0, 0, 0, 0);
+    for (int i = tid; i < FB_PX / 16; i += FB_NT) reinterpret_cast<uint4*>(SC)[i] = make_uint4(0, 0, 0, 0);
     __syncthreads();
     const int tlow = min(init_th, min_th);
     const int sw = G.scanX1 - G.scanX0;
-    for (int y = 3 + wave; y < G.scanY1; y += 4)
+    for (int y = 3 + wave; y < G.scanY1; y += FB_NW)
         for (int x0 = 0; x0 < sw; x0 += 64) {
             const int x = x0 + lane;
             if (x < sw) {
@@ -353,7 +357,7 @@ __device__ __forceinline__ void fb_dense(uint8_t* P, uint8_t* SC, const uint8_t*
             }
         }
     __syncthreads();
-    for (int cellId = wave; cellId < FB_MAX_CX * FB_MAX_CY; cellId += 4) {
+    for (int cellId = wave; cellId < FB_MAX_CX * FB_MAX_CY; cellId += FB_NW) {
         const int cx = cellId & (FB_MAX_CX - 1), cy = cellId / FB_MAX_CX;
         if (cx >= G.ncx || cy >= G.ncy) continue;
         const int X0 = G.scanX0 + cx * G.wCell, X1 = min(X0 + G.wCell, G.scanX1);
@@ -403,7 +407,11 @@ extern "C" int tb_debug_fast_times(unsigned long long* out, int reset) {
 #ifndef FB_MINW
 #define FB_MINW 5
 #endif
-__global__ void __launch_bounds__(256, FB_MINW)   /* five blocks = 20 wavefronts per CU: at most 96 VGPRs */
+/* FB_NW = 4 wavefronts per block, five blocks (30 KB of LDS each) per CU. Measured with FB_NW = 8 (4 blocks = 32 wavefronts per CU, the
+ * hardware limit, instead of 20): 4.32 ms against 3.40 per 1024 images -- every wavefront pays ~300 instructions of fixed cost (block
+ * decode, lane maps, stage transitions, emission) whatever its share of the tile, and the kernel is bound by instruction issue, not by
+ * latency. */
+__global__ void __launch_bounds__(FB_NT, FB_MINW)
 k_fast_blocks(PlanGeom g, const uint8_t* __restrict__ slab, const FastBlock* __restrict__ blocks, int nBlocks, int nImages, int by_image,
               uint32_t* __restrict__ cand, int32_t* __restrict__ candCount, int init_th, int min_th, int force_dense) {
     extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -470,7 +478,7 @@ k_fast_blocks(PlanGeom g, const uint8_t* __restrict__ slab, const FastBlock* __r
 
     /* ---- stage 0 */
     if (tid < 8) misc[tid] = 0;
-    if (wave == 3) {   /* cell tables: one wavefront, three columns and a row per lane (the other three go straight to the loads) */
+    if (wave == FB_NW - 1) {   /* cell tables: one wavefront, three columns and a row per lane (the others go straight to the loads) */
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             const int tx = lane + 64 * j;
@@ -498,30 +506,30 @@ k_fast_blocks(PlanGeom g, const uint8_t* __restrict__ slab, const FastBlock* __r
         const bool wide = ((stride & 15) == 0) && ((reinterpret_cast<uintptr_t>(img) & 15) == 0);
         const uint32_t M6 = 0x3f3f3f3fu;
         if (wide) {
-            /* Tile row r, 16-byte segment s is LDS segment 10 r + s (FB_S = 160): thread tid takes segments tid, tid + 256,
-             * tid + 512. One buffer resource per block, base = (row y0, column ax0), bounded by the end of the ROI's last row
+            /* Tile row r, 16-byte segment s is LDS segment 10 r + s (FB_S = 160): thread tid takes segments tid, tid + FB_NT, ... One buffer resource per block, base = (row y0, column ax0), bounded by the end of the ROI's last row
              * (padding included: rows are stride bytes apart inside one allocation): rows below the ROI read as zero without
              * touching memory, and so do the segments right of the ROI (offset out of range). All three loads are in flight
              * before the first LDS store; no 64-bit addresses. */
             const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
                 const_cast<uint8_t*>(img) + (size_t)blk.y0 * stride + G.ax0, 0, rh * stride - G.ax0, 0x00020000);
-            ft_u4 v[3];
+            constexpr int NLD = (FB_NSEG_ALL + FB_NT - 1) / FB_NT;
+            ft_u4 v[NLD];
 #pragma unroll
-            for (int k = 0; k < 3; k++) {
-                const int sidx = tid + 256 * k;
+            for (int k = 0; k < NLD; k++) {
+                const int sidx = tid + FB_NT * k;
                 const int row = (sidx * 6554) >> 16, seg = sidx - row * FB_SEGS;      /* sidx / 10 */
                 v[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, seg < nseg ? row * stride + 16 * seg : 0x7ffffff0, 0, 0);
             }
 #pragma unroll
-            for (int k = 0; k < 3; k++)
-                if (k < 2 || tid < FB_NSEG_ALL - 512) {
-                    const int o = 16 * (tid + 256 * k);
+            for (int k = 0; k < NLD; k++)
+                if (k < NLD - 1 || tid < FB_NSEG_ALL - FB_NT * (NLD - 1)) {
+                    const int o = 16 * (tid + FB_NT * k);
                     *reinterpret_cast<ft_u4*>(P + o) = v[k];
                     *reinterpret_cast<ft_u4*>(Q + o) = (v[k] >> 2) & M6;
                 }
         } else {                        /* caller-owned level 0 with an odd stride: bytes, bounded by the row */
 #pragma unroll 1
-            for (int sidx = tid; sidx < FB_NSEG_ALL; sidx += 256) {
+            for (int sidx = tid; sidx < FB_NSEG_ALL; sidx += FB_NT) {
                 const int row = (sidx * 6554) >> 16, seg = sidx - row * FB_SEGS;
                 uint32_t w4[4] = {0, 0, 0, 0};
                 if (row < rh && seg < nseg) {
@@ -543,7 +551,7 @@ k_fast_blocks(PlanGeom g, const uint8_t* __restrict__ slab, const FastBlock* __r
         const int tq = (init_th + 1) >> 2;
         const uint32_t K = (uint32_t)(128 - tq) * 0x01010101u;
         const int nPass = blk.nPass;
-        for (int p = wave; p < nPass; p += 4) {
+        for (int p = wave; p < nPass; p += FB_NW) {
             const int r = 3 + p * rowsPer + rr;
             uint32_t Gm = 0;
             const int base = r * FB_S + col16;
@@ -589,8 +597,8 @@ k_fast_blocks(PlanGeom g, const uint8_t* __restrict__ slab, const FastBlock* __r
     const int nrec = misc[0];
     bool dense = force_dense != 0;
     if (!dense) {
-        for (int i = tid; i < FB_PX / 16; i += 256) reinterpret_cast<uint4*>(SC)[i] = make_uint4(0, 0, 0, 0);
-        for (int i0 = 0; i0 < nrec; i0 += 256) {
+        for (int i = tid; i < FB_PX / 16; i += FB_NT) reinterpret_cast<uint4*>(SC)[i] = make_uint4(0, 0, 0, 0);
+        for (int i0 = 0; i0 < nrec; i0 += FB_NT) {
             const int i = i0 + tid;
             uint32_t Gm = 0;
             int px0 = 0;
@@ -622,7 +630,7 @@ k_fast_blocks(PlanGeom g, const uint8_t* __restrict__ slab, const FastBlock* __r
     const int npx = misc[1];
     dense = dense || npx > FB_LIST_CAP;
     if (!dense) {
-        for (int base = 64 * wave; base < npx; base += 256) {
+        for (int base = 64 * wave; base < npx; base += FB_NT) {
             const int i = base + lane;
             const bool v = i < npx;
             const int idx = v ? LIST[i] : (3 * FB_S + 4);
@@ -647,7 +655,7 @@ k_fast_blocks(PlanGeom g, const uint8_t* __restrict__ slab, const FastBlock* __r
     const int ncl = misc[2];
     dense = dense || ncl > FB_CL_CAP;
     if (!dense) {
-        for (int i0 = 0; i0 < ncl; i0 += 256) {
+        for (int i0 = 0; i0 < ncl; i0 += FB_NT) {
             const int i = i0 + tid;
             int cellbit = 0;
             if (i < ncl) {
@@ -672,7 +680,7 @@ k_fast_blocks(PlanGeom g, const uint8_t* __restrict__ slab, const FastBlock* __r
             int k = 0;
             for (int cellId = 0; cellId < FB_MAX_CX * FB_MAX_CY; cellId++) {
                 if (!((need >> cellId) & 1u)) continue;
-                if ((k++ & 3) != wave) continue;
+                if ((k++ & 3) != wave) continue;      /* wave-private lists for four wavefronts: the others have none to do */
                 const int cx = cellId & (FB_MAX_CX - 1), cy = cellId / FB_MAX_CX;
                 const int X0 = scanX0 + cx * wCell, X1 = min(X0 + wCell, scanX1);
                 const int Y0 = 3 + cy * hCell, Y1 = min(Y0 + hCell, scanY1);
@@ -714,7 +722,7 @@ k_fast_blocks(PlanGeom g, const uint8_t* __restrict__ slab, const FastBlock* __r
             nAll = misc[2];
             dense = nAll > FB_CL_CAP;
             if (!dense) {
-                for (int i = ncl + tid; i < nAll; i += 256) {
+                for (int i = ncl + tid; i < nAll; i += FB_NT) {
                     int cell;
                     if (!fb_nms_keep(SC, colinfo, rowinfo, CL[i], &cell)) CL[i] = 0xffff;
                 }
@@ -735,7 +743,7 @@ k_fast_blocks(PlanGeom g, const uint8_t* __restrict__ slab, const FastBlock* __r
     /* ---- emit: every wavefront its share of the list, one global atomic each */
     {
         int mine = 0;
-        for (int i0 = 64 * wave; i0 < nAll; i0 += 256) {
+        for (int i0 = 64 * wave; i0 < nAll; i0 += FB_NT) {
             const int i = i0 + lane;
             mine += __popcll(__ballot(i < nAll && CL[i] != 0xffff));
         }
@@ -743,7 +751,7 @@ k_fast_blocks(PlanGeom g, const uint8_t* __restrict__ slab, const FastBlock* __r
             int wbase = 0;
             if (lane == 0) wbase = atomicAdd(count, mine);
             wbase = __builtin_amdgcn_readfirstlane(wbase);
-            for (int i0 = 64 * wave; i0 < nAll; i0 += 256) {
+            for (int i0 = 64 * wave; i0 < nAll; i0 += FB_NT) {
                 const int i = i0 + lane;
                 const int idx = i < nAll ? CL[i] : 0xffff;
                 const bool e = idx != 0xffff;
@@ -778,7 +786,7 @@ int tbk_fast_cells(tb_extractor* ex, int n, int init_th, int min_th) {
     const char* fd_env = getenv("TB_FAST_DENSE");
     const int force_dense = (fd_env && fd_env[0] == '1') ? 1 : 0;
     tb_prof_begin(ctx, "k_fast_cells");
-    hipLaunchKernelGGL(k_fast_blocks, grid, dim3(256), FB_LDS_BYTES, ctx->stream, ex->g, ex->d_slab, ex->d_blocks, ex->nBlocksTotal,
+    hipLaunchKernelGGL(k_fast_blocks, grid, dim3(FB_NT), FB_LDS_BYTES, ctx->stream, ex->g, ex->d_slab, ex->d_blocks, ex->nBlocksTotal,
                        n, by_image, ex->d_cand, ex->d_candCount, init_th, min_th, force_dense);
     tb_prof_end(ctx);
     TB_HIP(ctx, hipGetLastError());
