@@ -320,7 +320,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--ba-split", type=int, default=0,
-                    help="partitions of the BA windows, one stream + host thread each (0 = by batch size: 1 up to 64 frames, else 2)")
+                    help="partitions of the BA windows, one stream + host thread each (0 = by batch size: 1 up to 64 frames, else 3)")
     ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic stereo pairs tiled over the batch")
     ap.add_argument("--ba-distinct", type=int, default=32, help="distinct synthetic BA windows tiled over the batch")
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)   # gloo: CPU test of the launcher / exchange
@@ -351,7 +351,7 @@ def main(argv=None):
         torch.cuda.set_device(dev)
         pipe = TrackingPipeline(args.width, args.height, args.levels, args.scale, args.target, args.init_th, args.min_th,
                                 frames=args.frames, device=dev, with_ba=not args.no_ba, ba_kf=args.ba_kf, ba_pts=args.ba_pts,
-                                ba_iters=args.ba_iters, seed=rank, ba_split=args.ba_split or (1 if args.frames <= 64 else 2),
+                                ba_iters=args.ba_iters, seed=rank, ba_split=args.ba_split or (1 if args.frames <= 64 else 3),
                                 ba_distinct=args.ba_distinct)
         pipe.set_synthetic(distinct=args.distinct, first=rank * args.frames)
     else:

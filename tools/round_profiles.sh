@@ -2,11 +2,11 @@
 # Round-end measurement on the GPU box (run from the repo root): GPU tests, the default bench line, rocprofv3
 # kernel-trace stats of the bench command and of the extractor chain alone, and the two PMC passes behind
 # profiles/*_hbm_traffic_pmc.json -- taken AT THE BENCH'S OWN LAUNCH SIZE (default: 512 stereo frames = 1024 images per
-# extractor launch, 2 BA partitions of 256 windows). Everything lands in gpurun_out/; copy what should be judged into profiles/.
+# extractor launch, 3 BA partitions of 171 windows). Everything lands in gpurun_out/; copy what should be judged into profiles/.
 set -u
 tag=${1:-r02}
 frames=${2:-512}
-split=${3:-2}
+split=${3:-3}
 timeout -k 10 900 python -m pytest tests -m gpu -q > gpurun_out/${tag}_gpu_tests.log 2>&1; echo "gpu tests rc=$?"; tail -2 gpurun_out/${tag}_gpu_tests.log
 timeout -k 10 400 python bench.py > gpurun_out/${tag}_bench.json.log 2>gpurun_out/${tag}_bench.err; echo "bench rc=$?"
 tools/rocprof_stats.sh ${tag}_bench bench.py --no-cpu-baseline > /dev/null; echo "stats bench rc=$?"

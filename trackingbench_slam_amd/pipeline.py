@@ -9,6 +9,7 @@ Everything stays in HBM between stages; torch supplies device memory, the stream
 RCCL gather.  All compute goes through the C ABI of libtb_hip.so -- there is no torch or CPU fallback.
 """
 import ctypes as C
+import os
 
 import numpy as np
 import torch
@@ -32,7 +33,7 @@ class TrackingPipeline:
         # torch's default stream has handle 0, which tb_set_stream() reads as "the context's own stream" -- torch-side
         # work (zero_(), the RCCL gather) would then be unordered against the kernels. Everything torch does for this
         # chain is issued under `with torch.cuda.stream(self.main)`.
-        self.main = torch.cuda.Stream(device=self.dev)
+        self.main = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("TB_MAIN_PRIO", "0")))   # A/B hook
         self.ctx = capi.Context(device, stream=self.main.cuda_stream)
         self.ex = capi.Extractor(self.ctx, width, height, nlevels, scale, 2 * self.F, target)
         self.kps_ptr, self.desc_ptr, self.counts_ptr, self.kp_cap = self.ex.results_dev()
@@ -75,7 +76,10 @@ class TrackingPipeline:
             nsplit = max(1, min(int(ba_split), F))
             bounds = [F * i // nsplit for i in range(nsplit + 1)]
             for i in range(nsplit):
-                st = torch.cuda.Stream(device=self.dev)
+                # HIGH priority for the BA streams: a partition's chain of small latency-bound launches is the step's critical
+                # path (it is still running when the extractor chain has finished); with equal priorities its workgroups queue
+                # behind the extractor's half-million (measured, 512 frames: 21.66 -> 21.14 ms per step; TB_BA_PRIO=0 restores)
+                st = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("TB_BA_PRIO", "-1")))
                 cx = capi.Context(device, stream=st.cuda_stream)
                 self.bas.append((BatchedLocalBA(cx, bounds[i + 1] - bounds[i], ba_kf, ba_pts, ba_iters, seed * 16 + i, self.dev,
                                                 distinct=max(1, -(-int(ba_distinct) // nsplit)), stream=st), st, cx))
