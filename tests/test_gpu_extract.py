@@ -225,6 +225,45 @@ def test_cell_candidates_dense_images(ctx):
     assert _cand_vs_oracle(ctx, mixed, 3, 0.8, 20, 7) > 3000
 
 
+def test_cell_candidates_extreme_values(ctx):
+    """Pixels of 0 and 255 only: every ring difference is 0 or +-255, the ends of the range the packed half-precision score
+    routine maps onto [1281, 1791] (fb_score1); scores of 254 and single-pixel structures next to saturated neighbours."""
+    rng = np.random.default_rng(11)
+    blobs = (rng.random((240, 400)) < 0.5).astype(np.uint8) * 255
+    blobs = np.kron(blobs[::4, ::4], np.ones((4, 4), np.uint8))          # 4 x 4 blocks of 0 / 255
+    assert _cand_vs_oracle(ctx, blobs, 3, 0.8, 80, 30) > 100
+    assert _cand_vs_oracle(ctx, blobs, 2, 0.8, 254, 200) >= 0            # only full-range corners survive the first pass
+    specks = np.zeros((200, 330), np.uint8)
+    specks[rng.integers(3, 197, 600), rng.integers(3, 327, 600)] = 255   # isolated bright pixels on black, and the inverse
+    assert _cand_vs_oracle(ctx, specks, 2, 0.8, 100, 20) > 100
+    assert _cand_vs_oracle(ctx, 255 - specks, 2, 0.8, 100, 20) > 100
+
+
+def test_orb_extract_aligned_device_frames_with_padding(ctx):
+    """Caller-owned level-0 frames with a 16-byte aligned stride wider than the image take the bounded buffer-load path of
+    the FAST kernel on memory the extractor does not own: the padding (255) right of the image is loaded into tile columns no
+    stage looks at, and the last row's loads stop at the end of the allocation."""
+    import torch
+    w, h, stride = 333, 241, 336
+    img = synth.frame(70, w, h)
+    buf = np.full((h, stride), 255, np.uint8)
+    buf[:, :w] = img
+    dev = torch.from_numpy(buf).cuda()
+    ex = capi.Extractor(ctx, w, h, 4, 0.8, 1, 500)
+    torch.cuda.synchronize()
+    ex.set_images_dev(dev.data_ptr(), 1, stride, stride * h)
+    ex.build_pyramid(1)
+    ex.orb(1, 500, 40, 10)
+    k, d = ex.results(0, 1000)
+    lv, sf = oracle.pyramid(img, 4, 0.8)
+    ko, do, _ = oracle.orb_extract(lv, sf, 500, 40, 10)
+    _eq_struct(k, ko)
+    assert np.array_equal(d, do)
+    for l in range(4):
+        _eq_struct(ex.candidates(0, l), oracle.orb_candidates(lv[l], 40, 10))
+    ex.close()
+
+
 def test_cell_candidates_forced_dense_path(ctx, kitti_pair, monkeypatch):
     """TB_FAST_DENSE=1 sends every block down the list-free path: it must reproduce the ordinary path's output."""
     monkeypatch.setenv("TB_FAST_DENSE", "1")

@@ -70,15 +70,18 @@ def _check_pipeline(p, L, R, seed, oracle_cache):
         w0 += ba.W
 
 
-def test_timed_configuration_unsynchronised_steps():
-    """bench.py's default shape at a size the oracle finishes in seconds: 1280x720, 12 stereo frames, 10-KF / 5000-point
+@pytest.mark.parametrize("ba_lag", [False, True])
+def test_timed_configuration_unsynchronised_steps(ba_lag):
+    """ba_lag=True is what bench.py times by default: the BA windows of a batch run beside the next batch's extraction and
+    step() returns without joining them (frame_results() drains before anything is read).
+    bench.py's default shape at a size the oracle finishes in seconds: 1280x720, 12 stereo frames, 10-KF / 5000-point
     windows, ba_split=3. One step, check; then four more steps back to back with no host synchronisation between them
     (what the timed loop does), check again: a torch-side operation that is not ordered against the kernel chain
     (round-1 advice: outlier.zero_() on the null stream) shows up as stale or cleared pose-opt flags."""
     from trackingbench_slam_amd.pipeline import TrackingPipeline
     F, seed = 12, 7
     p = TrackingPipeline(1280, 720, 8, 0.8, 2000, 80.0, 30.0, frames=F, with_ba=True, ba_kf=10, ba_pts=5000, ba_iters=10,
-                         seed=seed, ba_split=3, ba_distinct=6)
+                         seed=seed, ba_split=3, ba_distinct=6, ba_lag=ba_lag)
     assert len(p.bas) == 3 and p.main.cuda_stream != 0 and all(st.cuda_stream != 0 for _, st, _ in p.bas)
     L, R = p.set_synthetic(distinct=F, first=300)
     cache = {}

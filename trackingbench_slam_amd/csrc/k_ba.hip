@@ -60,6 +60,7 @@ struct BaDims {
     unsigned long long wstride, oT, oP, oHll, oBl, oHq, oHpp, oBp, oXp, oPartKF, oPartP, oPartS;
     /* per-window offsets, in ints, into the int workspace */
     unsigned long long istride, oPtStart, oPtFree, oKfStart, oKfEdges, oFreeKP;
+    unsigned long long oKfRec;   /* ints: 16-byte records {pt, u, v, inv_sigma2} of every edge in keyframe order (the keyframe pass) */
     unsigned long long oGrp;     /* ints: point groups of the Schur kernel (grp[0..ng], ng at [npt + 1]); grouped != 0 if built */
     int grouped, pad1;
 };
@@ -240,7 +241,15 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
         int base = 0;
         const int mine = ba_ordered_rank(nobs, tmp, [&](int e) { return obs[e].kf == k; },
                                          [&](int e) { const int kf = obs[e].kf; return kf >= 0 && kf < k; }, &base,
-                                         [&](int e, int rank, bool hit) { if (hit) I[d.oKfEdges + base + rank] = e; });
+                                         [&](int e, int rank, bool hit) {
+                                             if (hit) {   /* the edge's index, and its observation as the keyframe pass reads it */
+                                                 I[d.oKfEdges + base + rank] = e;
+                                                 const tb_ba_obs o = obs[e];
+                                                 int4 r;
+                                                 r.x = o.pt; r.y = __float_as_int(o.u); r.z = __float_as_int(o.v); r.w = __float_as_int(o.inv_sigma2);
+                                                 *reinterpret_cast<int4*>(I + d.oKfRec + 4 * (size_t)(base + rank)) = r;
+                                             }
+                                         });
         if (tid == 0) {
             I[d.oKfStart + k] = base;
             if (k == d.nkf - 1) I[d.oKfStart + d.nkf] = base + mine;
@@ -450,7 +459,6 @@ k_ba_kf(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw,
     const int w = blockIdx.z, kf = d.nfixed + blockIdx.y, tid = threadIdx.x;
     const BaState st = states[w];
     if (st.status || !st.need_lin) return;
-    const tb_ba_obs* obs = obsAll + (size_t)w * d.obs_pitch;
     double* D = dw + (size_t)w * d.wstride;
     const int* I = iw + (size_t)w * d.istride;
     const int beg = I[d.oKfStart + kf], end = I[d.oKfStart + kf + 1];
@@ -463,32 +471,33 @@ k_ba_kf(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw,
         double acc[27];
 #pragma unroll
         for (int i = 0; i < 27; i++) acc[i] = 0;
-        /* three rounds of independent loads (edge ids, observations, points), each round in flight together: a
-         * load-use-load chain per edge would be three memory latencies per edge */
-        int ee[BA_KFCH / BA_T];
-        tb_ba_obs oo[BA_KFCH / BA_T];
+        /* two rounds of independent loads, each in flight together: the keyframe-ordered 16-byte records of the chunk's edges
+         * (written by the setup kernel: coalesced, no edge-id -> observation gather), then their points. A load-use-load
+         * chain per edge would be one memory latency per edge and round; the pass is bound by exactly these latencies, most
+         * of all inside the pipeline where the extractor's kernels load the memory system. */
+        int4 rr[BA_KFCH / BA_T];
         double XX[BA_KFCH / BA_T][3];
+        const int4* KR = reinterpret_cast<const int4*>(I + d.oKfRec);
 #pragma unroll
         for (int j = 0; j < BA_KFCH / BA_T; j++) {
             const int idx = beg + chunk * BA_KFCH + j * BA_T + tid;
-            ee[j] = (idx < end) ? I[d.oKfEdges + idx] : -1;
+            rr[j] = KR[min(idx, end - 1)];
+            if (idx >= end) rr[j].x = -1;
         }
 #pragma unroll
-        for (int j = 0; j < BA_KFCH / BA_T; j++) oo[j] = obs[max(ee[j], 0)];
-#pragma unroll
         for (int j = 0; j < BA_KFCH / BA_T; j++) {
-            const int p = min(max(oo[j].pt, 0), d.npt - 1);
+            const int p = min(max(rr[j].x, 0), d.npt - 1);
             XX[j][0] = P[3 * p]; XX[j][1] = P[3 * p + 1]; XX[j][2] = P[3 * p + 2];
         }
 #pragma unroll
         for (int j = 0; j < BA_KFCH / BA_T; j++) {
-            if (ee[j] < 0) continue;
-            const tb_ba_obs o = oo[j];
+            if (rr[j].x < 0) continue;
+            const float ou = __int_as_float(rr[j].y), ov = __int_as_float(rr[j].z), ow = __int_as_float(rr[j].w);
             const double* X = XX[j];
             double Jp[12];
             BaLin L; /* residual and Huber weight exactly as the point pass computes them (same helper): cheaper than a
                         24-byte-per-edge round trip through HBM */
-            ba_residual(Tk, X, o.u, o.v, o.inv_sigma2, d.fx, d.fy, d.cx, d.cy, delta, L);
+            ba_residual(Tk, X, ou, ov, ow, d.fx, d.fy, d.cx, d.cy, delta, L);
             ba_jac_pose_iz(L.pc, L.invz, d.fx, d.fy, Jp);
             const double ww = L.ww, e0 = L.e0, e1 = L.e1;
 #pragma unroll
@@ -1611,6 +1620,7 @@ static void ba_dims(BaDims& d, int W, const double K[4], int nkf, int nfixed, in
     d.oKfStart = itake(nkf + 1);
     d.oKfEdges = itake(obs_pitch);
     d.oFreeKP = itake(4ull * obs_pitch);
+    d.oKfRec = itake(4ull * obs_pitch);
     d.grouped = (!d.big && npt <= BA_GRP_MAXPT) ? 1 : 0;
     d.oGrp = itake(d.grouped ? (unsigned long long)npt + 2 : 0);
     d.oPairStart = itake(d.big ? d.npairs + 1 : 0);

@@ -448,7 +448,18 @@ k_fast_blocks(PlanGeom g, const uint8_t* __restrict__ slab, const FastBlock* __r
     if (bid >= nBlocks) return;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    const FastBlock blk = blocks[bid];
+    /* the block descriptor through the SCALAR cache (constant address space: s_load instead of a vector load + six
+     * v_readfirstlane): it heads the chain descriptor -> level geometry -> tile loads that every block waits out */
+    FastBlock blk;
+    {
+        static_assert(sizeof(FastBlock) == 24, "six dwords");
+        const __attribute__((address_space(4))) uint32_t* cb =
+            reinterpret_cast<const __attribute__((address_space(4))) uint32_t*>(reinterpret_cast<uintptr_t>(blocks + bid));
+        uint32_t wds[6];
+#pragma unroll
+        for (int i = 0; i < 6; i++) wds[i] = cb[i];
+        __builtin_memcpy(&blk, wds, sizeof blk);
+    }
     const LevelGeom& L = g.lv[blk.level];
     int stride;
     const uint8_t* img = tb_level_ptr(g, slab, b, blk.level, &stride);

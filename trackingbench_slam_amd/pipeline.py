@@ -22,7 +22,7 @@ KITTI_K = (718.856, 718.856, 607.1928, 185.2157)  # hard-coded in the reference,
 class TrackingPipeline:
     def __init__(self, width=1280, height=720, nlevels=8, scale=0.8, target=2000, init_th=80.0, min_th=30.0,
                  frames=16, bf_ratio=10.0, bf_min_th=30.0, device=0, with_ba=True, ba_kf=10, ba_pts=5000, ba_iters=10,
-                 seed=0, ba_split=3, ba_distinct=4):
+                 seed=0, ba_split=3, ba_distinct=4, ba_lag=False):
         self.dev = torch.device("cuda", device)
         torch.cuda.set_device(self.dev)
         self.F = int(frames)
@@ -67,6 +67,8 @@ class TrackingPipeline:
         # kernels (64-block solves, one-block decisions) that leave most CUs idle, while the extractor kernels
         # are throughput bound -- the two overlap on the chip instead of queueing behind each other.
         self.with_ba = with_ba
+        self.ba_lag = bool(ba_lag) and with_ba
+        self._futures = []
         self.bas = []          # (BatchedLocalBA, torch stream, context) per partition of the windows
         self._step_done = None
         self._pool = None
@@ -102,6 +104,7 @@ class TrackingPipeline:
         return torch.cuda.stream(self.main)
 
     def close(self):
+        self.drain()
         torch.cuda.synchronize(self.dev)
         if self._pool is not None:
             self._pool.shutdown(wait=True)
@@ -148,6 +151,18 @@ class TrackingPipeline:
         F, ex, ctx, L = self.F, self.ex, self.ctx, capi.lib()
         main = self.main
         self._cur ^= 1                           # this batch's records go to the other set
+        if self.ba_lag:
+            # Software-pipelined form (a local-mapping thread that runs one batch behind tracking): this batch's extractor
+            # chain is queued at once; the BA partitions are handed their next batch as soon as their host drivers have
+            # returned from the previous one (a driver blocks on its stream once per call: LM termination is data
+            # dependent). step() does not wait for them -- the windows of batch s run beside the extraction of batch s + 1,
+            # so the latency-bound tail of a partition's LM chain no longer leaves the chip to itself at the end of every
+            # step. drain() joins everything; nothing reads a BA buffer between a step and the next without it.
+            self.extract_chain()
+            for fu in self._futures:
+                fu.result()
+            self._futures = [self._pool.submit(self._run_ba, ba, st) for ba, st, _ in self.bas]
+            return
         futures = []
         for ba, st, _ in self.bas:
             # the BA windows run beside the extractor chain on their own streams (and host threads)
@@ -162,6 +177,16 @@ class TrackingPipeline:
         if self.bas:
             self._step_done = torch.cuda.Event()
             self._step_done.record(main)
+
+    def drain(self):
+        """Join the BA partitions' host drivers and order the main stream behind their streams (ba_lag: the windows of the
+        last batch may still be running, or not even be queued completely, when step() returns)."""
+        for fu in self._futures:
+            fu.result()
+        self._futures = []
+        if self.ba_lag:
+            for _, st, _ in self.bas:
+                self.main.wait_stream(st)
 
     def extract_chain(self):
         """pyramid -> ORB -> searchByBF -> pose-opt -> track records of the resident batch, on the context's stream."""
@@ -185,6 +210,7 @@ class TrackingPipeline:
     # ---- outputs (host copies, for tests)
     def frame_results(self, f):
         """(kps_left, desc_left, kps_right, desc_right, matches, Tcw, n_inliers, outlier) of frame f."""
+        self.drain()
         torch.cuda.synchronize(self.dev)
         kl, dl = self.ex.results(f, self.kp_cap)
         kr, dr = self.ex.results(self.F + f, self.kp_cap)
