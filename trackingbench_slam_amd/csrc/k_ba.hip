@@ -361,7 +361,10 @@ __global__ void __launch_bounds__(BA_T)
 k_ba_points(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw, const int* __restrict__ iw,
             BaState* __restrict__ states, const int* __restrict__ errflag) {
     __shared__ double red[4];
-    __shared__ double sRt[TB_MAX_LEVELS * 8 * 12];
+    /* keyframe poses as R | t, 12 doubles each: DYNAMIC shared memory sized by the window (960 bytes at 10 keyframes, where a static
+     * array for the largest window took 6 KB): the pass is bound by HBM latency and bandwidth, its wavefronts are meant to sit on
+     * CUs beside the extractor's workgroups, which leave ~10 KB of LDS free */
+    extern __shared__ __attribute__((aligned(16))) double sRt[];
     const int w = blockIdx.y, tid = threadIdx.x;
     if (errflag[w]) { /* k_ba_setup rejected the window's observations: nothing may index with them */
         if (blockIdx.x == 0 && tid == 0) { states[w].status = 1; states[w].err = 1; }
@@ -416,25 +419,26 @@ k_ba_points(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
 /* ---- B: keyframe pass: Hpp (21 unique) + bp (6) per free keyframe, chunked tree reductions */
 /* Sum of 27 per-thread doubles over the 256 threads of a workgroup, result in threads 0..26 (value = thread index).
  * A butterfly of wave shuffles costs 12 LDS permutes and 6 adds PER VALUE (64-bit values travel as two dwords): 324
- * permutes per wavefront, more than the keyframe pass spends on its edges. Here every lane stores its values once, 14 at a
+ * permutes per wavefront, more than the keyframe pass spends on its edges. Here every lane stores its values once, BA_KFG at a
  * time ([value][lane], row stride 65 doubles: conflict-free both ways), four lanes per value add 16 partials each in lane
  * order, one lane adds the four quarter sums, and threads 0..26 add the four wavefronts' sums: ~110 LDS / add slots per
- * wavefront, every sum of fixed shape. sh: 4 * (14 * 65 + 64) + 4 * 27 doubles. */
-#define BA_KFR_LDS (4 * (14 * 65 + 64) + 4 * 27)
+ * wavefront, every sum of fixed shape. sh: BA_KFR_LDS doubles. */
+#define BA_KFG 14  /* values per transpose round: 32 KB of LDS per workgroup. 7 (17 KB, four rounds) measured 0.85 against 0.78 ms per 256 windows alone and the same step time inside the pipeline */
+#define BA_KFR_LDS (4 * (BA_KFG * 65 + 64) + 4 * 27)
 __device__ __forceinline__ double ba_block_sum27(const double (&v)[27], double* sh) {
     const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-    double* T = sh + wave * (14 * 65 + 64);       /* this wavefront's transpose tile */
-    double* Qs = T + 14 * 65;                     /* its 56 quarter sums */
-    double* red = sh + 4 * (14 * 65 + 64);        /* [4][27] wavefront sums */
+    double* T = sh + wave * (BA_KFG * 65 + 64);   /* this wavefront's transpose tile */
+    double* Qs = T + BA_KFG * 65;                 /* its 4 BA_KFG quarter sums */
+    double* red = sh + 4 * (BA_KFG * 65 + 64);    /* [4][27] wavefront sums */
 #pragma unroll
-    for (int g = 0; g < 2; g++) {
-        const int nv = g == 0 ? 14 : 13;
+    for (int g = 0; g < (27 + BA_KFG - 1) / BA_KFG; g++) {
+        const int nv = min(BA_KFG, 27 - BA_KFG * g);
 #pragma unroll
-        for (int i = 0; i < 14; i++)
-            if (i < nv) T[i * 65 + lane] = v[14 * g + i];
+        for (int i = 0; i < BA_KFG; i++)
+            if (i < nv) T[i * 65 + lane] = v[BA_KFG * g + i];
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        const int q = lane / 14, i = lane - 14 * q;    /* lanes 0..55: quarter q of value i */
-        if (lane < 56 && i < nv) {
+        const int q = lane / BA_KFG, i = lane - BA_KFG * q;    /* lanes 0..4 BA_KFG - 1: quarter q of value i */
+        if (lane < 4 * BA_KFG && i < nv) {
             const double* src = T + i * 65 + 16 * q;
             double s = src[0];
 #pragma unroll
@@ -442,7 +446,7 @@ __device__ __forceinline__ double ba_block_sum27(const double (&v)[27], double* 
             Qs[lane] = s;
         }
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
-        if (lane < nv) red[wave * 27 + 14 * g + lane] = (Qs[lane] + Qs[14 + lane]) + (Qs[28 + lane] + Qs[42 + lane]);
+        if (lane < nv) red[wave * 27 + BA_KFG * g + lane] = (Qs[lane] + Qs[BA_KFG + lane]) + (Qs[2 * BA_KFG + lane] + Qs[3 * BA_KFG + lane]);
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront");
     }
     __syncthreads();
@@ -1446,9 +1450,11 @@ __global__ void __launch_bounds__(BA_T)
 k_ba_update(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw, const int* __restrict__ iw,
             const BaState* __restrict__ states) {
     __shared__ double red[4];
-    __shared__ double sRt[TB_MAX_LEVELS * 8 * 12];  /* trial poses */
-    __shared__ double sx[6 * BA_BIG_MAXF];
-    __shared__ double sRtc[TB_MAX_LEVELS * 8 * 12]; /* linearisation state */
+    /* dynamic shared memory sized by the window (see k_ba_points): trial poses, linearisation state, pose increments */
+    extern __shared__ __attribute__((aligned(16))) double sdyn[];
+    double* const sRt = sdyn;                      /* [nkf][12] trial poses */
+    double* const sRtc = sdyn + (size_t)d.nkf * 12;/* [nkf][12] linearisation state */
+    double* const sx = sdyn + (size_t)d.nkf * 24;  /* [np] */
     const int w = blockIdx.y, tid = threadIdx.x;
     const BaState st = states[w];
     if (st.status) return;
@@ -1685,7 +1691,7 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
     while (host_running > 0 && rounds < max_rounds) {
         for (int r = 0; r < batch && rounds < max_rounds; r++, rounds++) {
             tb_prof_begin(ctx, "k_ba_points");
-            hipLaunchKernelGGL(k_ba_points, dim3(d.nblkP, W), dim3(BA_T), 0, s, d, d_obs, dw, iw, states, errflag);
+            hipLaunchKernelGGL(k_ba_points, dim3(d.nblkP, W), dim3(BA_T), (size_t)d.nkf * 12 * sizeof(double), s, d, d_obs, dw, iw, states, errflag);
             tb_prof_end(ctx);
             tb_prof_begin(ctx, "k_ba_kf");
             hipLaunchKernelGGL(k_ba_kf, dim3(std::min(BA_KFBLK, d.kfChunks), d.nfree, W), dim3(BA_T), 0, s, d, d_obs, dw, iw, states);
@@ -1727,7 +1733,7 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
             tb_prof_end(ctx);
             }
             tb_prof_begin(ctx, "k_ba_update");
-            hipLaunchKernelGGL(k_ba_update, dim3(d.nblkP, W), dim3(BA_T), 0, s, d, d_obs, dw, iw, states);
+            hipLaunchKernelGGL(k_ba_update, dim3(d.nblkP, W), dim3(BA_T), ((size_t)d.nkf * 24 + d.np) * sizeof(double), s, d, d_obs, dw, iw, states);
             tb_prof_end(ctx);
             tb_prof_begin(ctx, "k_ba_decide");
             hipLaunchKernelGGL(k_ba_decide, dim3((W + 63) / 64), dim3(64), 0, s, d, dw, states, running + rounds % ring);
