@@ -302,6 +302,29 @@ int tb_local_ba_batch_dev(tb_ctx* ctx, int nwindows, const double K[4], int nkf,
                           float* pts, const tb_ba_obs* obs, const int32_t* obs_counts, int obs_pitch, int iters,
                           double* stats);
 
+/* ---- multi-GPU batch entry (SURVEY.md section 8(b) `tb_batch_run`, 8(e): frames are independent units through
+ * extract -> left/right match, sharded as contiguous blocks of frames, one exchange step at the end).
+ * The in-process counterpart of trackingbench_slam_amd/dist.py for a C++ host that holds one context per GPU:
+ * frame f of the batch goes to context f * ngpu / nframes; every context's chain -- Frame::ComputePyramid (Frame.cpp:414-427),
+ * ORBExtractor::operator() (ORBextractor.cpp:906-978) on the left and the right image, Matcher::searchByBF left <-> right
+ * (matcher.cpp:168-228) -- is queued on its own stream before any context is waited for, so the GPUs work concurrently; then
+ * the per-frame track records are gathered into the caller's HOST arrays (no collective: the records of a shard come straight
+ * from its GPU).  ctxs may name the same device more than once (the shards then share it).
+ *   left, right   host frames [nframes][height][stride] (pitch bytes apart)
+ *   kps / desc    [2][nframes][cap] records / [2][nframes][cap][32] bytes: side 0 = left, 1 = right
+ *   counts        [2][nframes]; matches [nframes][cap] (queryIdx = left key, trainIdx = right key), match_counts [nframes]
+ * cap must hold every frame's keypoints and matches (TB_ECAPACITY otherwise). */
+typedef struct tb_batch_params {
+    int width, height, nlevels;
+    float scale;                /* Frame::Frame scale step (0.8) */
+    int target;                 /* keypoints per image */
+    float init_th, min_th;      /* FAST thresholds */
+    float bf_ratio, bf_min_th;  /* searchByBF */
+} tb_batch_params;
+int tb_batch_run(tb_ctx** ctxs, int ngpu, const tb_batch_params* p, int nframes, const uint8_t* left, const uint8_t* right,
+                 int stride, size_t pitch, int cap, tb_keypoint* kps, uint8_t* desc, int32_t* counts, tb_match* matches,
+                 int32_t* match_counts);
+
 #ifdef __cplusplus
 }
 #endif

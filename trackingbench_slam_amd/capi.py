@@ -41,6 +41,7 @@ EXPORTS = [
     "tb_search_by_violence_batch_dev", "tb_pose_opt", "tb_pose_opt_batch_dev", "tb_local_ba", "tb_local_ba_batch_dev",
     "tb_clahe", "tb_clahe_dev", "tb_optical_flow_pyr_lk", "tb_optical_flow_pyr_lk_dev", "tb_optical_flow_pyr_lk_batch_dev", "tb_search_by_opflow", "tb_search_by_opflow_batch_dev",
     "tb_find_fundamental_ransac", "tb_reject_with_f", "tb_add_map_points_by_stereo", "tb_add_map_points_by_stereo_batch_dev",
+    "tb_batch_run",
 ]
 
 
@@ -130,6 +131,34 @@ def three_maxima(sizes):
     i1, i2, i3 = C.c_int(-1), C.c_int(-1), C.c_int(-1)
     lib().tb_three_maxima(_p(sizes), len(sizes), C.byref(i1), C.byref(i2), C.byref(i3))
     return i1.value, i2.value, i3.value
+
+
+class BatchParams(C.Structure):
+    """tb_batch_params of include/tb_capi.h"""
+    _fields_ = [("width", C.c_int), ("height", C.c_int), ("nlevels", C.c_int), ("scale", C.c_float), ("target", C.c_int),
+                ("init_th", C.c_float), ("min_th", C.c_float), ("bf_ratio", C.c_float), ("bf_min_th", C.c_float)]
+
+
+def batch_run(contexts, left, right, nlevels=8, scale=0.8, target=2000, init_th=80.0, min_th=30.0, bf_ratio=10.0,
+              bf_min_th=30.0, cap=None):
+    """tb_batch_run: a batch of stereo frames (uint8 [F, H, W] each side) sharded over `contexts` (one per GPU, or several on
+    one), pyramid -> ORB (both sides) -> searchByBF left <-> right per shard, records gathered on the host.
+    Returns per frame (kps_left, desc_left, kps_right, desc_right, matches)."""
+    left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
+    F, H, W = left.shape
+    assert right.shape == left.shape and len(contexts) >= 1
+    cap = int(cap or (target + 512))
+    prm = BatchParams(W, H, int(nlevels), float(scale), int(target), float(init_th), float(min_th), float(bf_ratio), float(bf_min_th))
+    kps = np.zeros((2, F, cap), KEYPOINT); desc = np.zeros((2, F, cap, 32), np.uint8); cnt = np.zeros((2, F), np.int32)
+    mt = np.zeros((F, cap), MATCH); mc = np.zeros(F, np.int32)
+    hs = (C.c_void_p * len(contexts))(*[c._h for c in contexts])
+    rc = lib().tb_batch_run(hs, len(contexts), C.byref(prm), F, _p(left), _p(right), W, C.c_size_t(W * H), cap, _p(kps), _p(desc),
+                            _p(cnt), _p(mt), _p(mc))
+    if rc != 0:
+        msgs = [lib().tb_last_error(c._h).decode() for c in contexts]
+        raise TBError(rc, "; ".join(m for m in msgs if m) or lib().tb_strerror(rc).decode())
+    return [(kps[0, f, :cnt[0, f]].copy(), desc[0, f, :cnt[0, f]].copy(), kps[1, f, :cnt[1, f]].copy(), desc[1, f, :cnt[1, f]].copy(),
+             mt[f, :mc[f]].copy()) for f in range(F)]
 
 
 class Context:

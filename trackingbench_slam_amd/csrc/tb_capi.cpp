@@ -1643,4 +1643,102 @@ int tb_add_map_points_by_stereo(tb_ctx* ctx, const uint8_t* img_stereo, const ui
     return TB_OK;
 }
 
+/* ---- multi-GPU batch entry: see include/tb_capi.h */
+int tb_batch_run(tb_ctx** ctxs, int ngpu, const tb_batch_params* p, int nframes, const uint8_t* left, const uint8_t* right,
+                 int stride, size_t pitch, int cap, tb_keypoint* kps, uint8_t* desc, int32_t* counts, tb_match* matches,
+                 int32_t* match_counts) {
+    if (!ctxs || ngpu < 1 || !p || nframes < 0 || !kps || !desc || !counts || !matches || !match_counts || cap < 1) return TB_EINVAL;
+    for (int i = 0; i < ngpu; i++)
+        if (!ctxs[i]) return TB_EINVAL;
+    if (nframes == 0) return TB_OK;
+    tb_ctx* c0 = ctxs[0];
+    if (!left || !right || stride < p->width || pitch < (size_t)stride * p->height || p->nlevels < 2 || p->nlevels > TB_MAX_LEVELS)
+        return tb_fail(c0, TB_EINVAL, "tb_batch_run: frame geometry / level count");
+    std::vector<float> sf(p->nlevels), tmp(p->nlevels);
+    tb_scale_factors(p->nlevels, p->scale, sf.data(), tmp.data(), tmp.data(), tmp.data());
+    struct Shard {
+        tb_ctx* ctx = nullptr;
+        tb_extractor* ex = nullptr;
+        int f0 = 0, m = 0;
+        tb_keypoint* d_kps = nullptr; uint8_t* d_desc = nullptr; int32_t* d_counts = nullptr;   /* [2 m][cap] compact records */
+        tb_match* d_matches = nullptr; int32_t* d_mcounts = nullptr;
+    };
+    std::vector<Shard> sh(ngpu);
+    auto release = [&]() {
+        for (Shard& s : sh) {
+            if (!s.ctx) continue;
+            hipSetDevice(s.ctx->device);
+            hipStreamSynchronize(s.ctx->stream);
+            if (s.ex) tb_extractor_destroy(s.ex);
+            hipFree(s.d_kps); hipFree(s.d_desc); hipFree(s.d_counts); hipFree(s.d_matches); hipFree(s.d_mcounts);
+        }
+    };
+    int rc = TB_OK;
+    /* 1. queue every shard's chain: contiguous blocks of frames, left images [0, m), right images [m, 2 m) of the plan */
+    for (int i = 0; i < ngpu && rc == TB_OK; i++) {
+        Shard& s = sh[i];
+        const int f0 = (int)((long long)nframes * i / ngpu), f1 = (int)((long long)nframes * (i + 1) / ngpu);
+        if (f1 == f0) continue;
+        s.ctx = ctxs[i]; s.f0 = f0; s.m = f1 - f0;
+        tb_ctx* ctx = s.ctx;
+        const int m = s.m;
+        if ((rc = tb_extractor_create(ctx, p->width, p->height, p->nlevels, sf.data(), nullptr, nullptr, 2 * m, p->target, &s.ex))) break;
+        tb_extractor* ex = s.ex;   /* tb_extractor_create has bound this thread to the context's device */
+        const LevelGeom& L0 = ex->g.lv[0];
+        hipError_t e = hipSuccess;
+        for (int side = 0; side < 2 && e == hipSuccess; side++)
+            for (int f = 0; f < m && e == hipSuccess; f++)
+                e = hipMemcpy2DAsync(ex->d_slab + (size_t)(side * m + f) * ex->g.slabBytes + L0.off, L0.stride,
+                                     (side ? right : left) + (size_t)(f0 + f) * pitch, stride, L0.w, L0.h, hipMemcpyHostToDevice,
+                                     ctx->stream);
+        if (e != hipSuccess) { rc = tb_fail(ctx, TB_EDEVICE, "tb_batch_run: frame upload: %s", hipGetErrorString(e)); break; }
+        ex->g.img0 = nullptr;
+        if ((rc = tb_extractor_build_pyramid(ex, 2 * m))) break;
+        if ((rc = tb_extractor_orb(ex, 2 * m, p->target, p->init_th, p->min_th, 0, nullptr, 0))) break;
+        if (hipMalloc(&s.d_kps, (size_t)2 * m * cap * sizeof(tb_keypoint)) != hipSuccess ||
+            hipMalloc(&s.d_desc, (size_t)2 * m * cap * 32) != hipSuccess || hipMalloc(&s.d_counts, (size_t)2 * m * sizeof(int32_t)) != hipSuccess ||
+            hipMalloc(&s.d_matches, (size_t)m * cap * sizeof(tb_match)) != hipSuccess ||
+            hipMalloc(&s.d_mcounts, (size_t)m * sizeof(int32_t)) != hipSuccess) {
+            rc = tb_fail(ctx, TB_ENOMEM, "tb_batch_run: record buffers of shard %d", i);
+            break;
+        }
+        if ((rc = tb_extractor_copy_results_dev(ex, 2 * m, s.d_kps, s.d_desc, s.d_counts, cap))) break;
+        /* searchByBF on the plan's own descriptor sets: left set f against right set m + f */
+        const uint8_t* dsc = nullptr; const int32_t* cnt = nullptr; int selCap = 0;
+        tb_extractor_results_dev(ex, nullptr, &dsc, &cnt, &selCap);
+        if ((rc = tb_search_by_bf_batch_dev(ctx, m, dsc, cnt, dsc + (size_t)m * selCap * 32, cnt + m, (size_t)selCap * 32, p->bf_ratio,
+                                            p->bf_min_th, s.d_matches, cap, s.d_mcounts)))
+            break;
+    }
+    /* 2. the exchange step: every shard's records into the caller's arrays (waits for that shard only; the others keep working) */
+    for (int i = 0; i < ngpu && rc == TB_OK; i++) {
+        Shard& s = sh[i];
+        if (!s.ctx) continue;
+        tb_ctx* ctx = s.ctx;
+        const int m = s.m, f0 = s.f0;
+        hipError_t e = hipSetDevice(ctx->device);
+        for (int side = 0; side < 2 && e == hipSuccess; side++) {
+            e = hipMemcpyAsync(kps + ((size_t)side * nframes + f0) * cap, s.d_kps + (size_t)side * m * cap, (size_t)m * cap * sizeof(tb_keypoint),
+                               hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(desc + ((size_t)side * nframes + f0) * cap * 32, s.d_desc + (size_t)side * m * cap * 32, (size_t)m * cap * 32,
+                                   hipMemcpyDeviceToHost, ctx->stream);
+            if (e == hipSuccess)
+                e = hipMemcpyAsync(counts + (size_t)side * nframes + f0, s.d_counts + (size_t)side * m, (size_t)m * sizeof(int32_t),
+                                   hipMemcpyDeviceToHost, ctx->stream);
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(matches + (size_t)f0 * cap, s.d_matches, (size_t)m * cap * sizeof(tb_match), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(match_counts + f0, s.d_mcounts, (size_t)m * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) { rc = tb_fail(ctx, TB_EDEVICE, "tb_batch_run: gather of shard %d: %s", i, hipGetErrorString(e)); break; }
+        /* the compact records were cut at cap: say so instead of handing back a truncated frame */
+        std::vector<int32_t> full(2 * m);
+        if (tb_extractor_counts_host(s.ex, 2 * m, full.data()) == TB_OK)
+            for (int k = 0; k < 2 * m; k++)
+                if (full[k] > cap) { rc = tb_fail(ctx, TB_ECAPACITY, "tb_batch_run: %d keypoints in a frame of shard %d, capacity %d", full[k], i, cap); break; }
+    }
+    release();
+    return rc;
+}
+
 }  // extern "C"
