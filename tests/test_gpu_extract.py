@@ -112,6 +112,38 @@ def test_orb_extract_batched_plan(ctx):
     ex.close()
 
 
+def test_orb_extract_batches_take_the_image_per_xcd_order(ctx):
+    """From 64 images per launch on, the pyramid, FAST and descriptor kernels map workgroups to (image, tile) so that XCD k
+    works through images k, k + 8, ... (what bench.py's 1024-image launches run). 70 images -- not a multiple of 8: the last
+    group's missing images are workgroups that exit -- of 5 distinct frames, every slot against the oracle: pyramid levels,
+    FAST candidates per level, keypoints and descriptors."""
+    w, h, nl, N = 320, 200, 5, 400
+    distinct = [synth.frame(90 + i, w, h) for i in range(5)]
+    n = 70
+    imgs = np.stack([distinct[i % 5] for i in range(n)])
+    ex = capi.Extractor(ctx, w, h, nl, 0.8, n, N)
+    assert ex.set_images_host(imgs) == n
+    ex.build_pyramid(n)
+    ex.orb(n, N, 40, 12)
+    cnt = ex.counts(n)
+    ref = []
+    for img in distinct:
+        lv, sf = oracle.pyramid(img, nl, 0.8)
+        ko, do, _ = oracle.orb_extract(lv, sf, N, 40, 12)
+        ref.append((lv, ko, do, [oracle.orb_candidates(lv[l], 40, 12) for l in range(nl)]))
+    for b in range(n):
+        lv, ko, do, cands = ref[b % 5]
+        k, d = ex.results(b)
+        assert cnt[b] == len(ko)
+        _eq_struct(k, ko)
+        assert np.array_equal(d, do)
+        if b in (0, 7, 8, 63, 64, 69):             # levels and candidates: first / last of an XCD group, last image
+            for l in range(nl):
+                assert np.array_equal(ex.get_level(b, l), lv[l])
+                _eq_struct(ex.candidates(b, l), cands[l])
+    ex.close()
+
+
 def test_orb_extract_edge_cases(ctx):
     sf = oracle.scale_factors(3, 0.8)[0]
     flat = [np.full((120, 160), 90, np.uint8), np.full((96, 128), 90, np.uint8), np.full((76, 102), 90, np.uint8)]

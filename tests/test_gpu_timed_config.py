@@ -97,6 +97,50 @@ def test_timed_configuration_unsynchronised_steps(ba_lag):
     p.close()
 
 
+def test_pipeline_batches_of_64_images_and_more():
+    """The launch shapes bench.py times differ from the small-batch tests in one more way: from 64 images per launch on the
+    extractor kernels take the image-per-XCD workgroup order. 36 stereo frames (72 images) of 3 distinct pairs, BA on three
+    streams, two unsynchronised steps: every frame's keypoints / descriptors / matches against the oracle (cached per distinct
+    pair), its pose problem (seeded per frame), and every BA window."""
+    from trackingbench_slam_amd.pipeline import KITTI_K, TrackingPipeline
+    F, seed, nd = 36, 3, 3
+    p = TrackingPipeline(1280, 720, 8, 0.8, 2000, 80.0, 30.0, frames=F, with_ba=True, ba_kf=10, ba_pts=600, ba_iters=6,
+                         seed=seed, ba_split=3, ba_distinct=3)
+    L, R = p.set_synthetic(distinct=nd, first=500)
+    p.step()
+    p.step()
+    ref = []
+    for i in range(nd):
+        lvL, sf = oracle.pyramid(L[i], 8, 0.8)
+        lvR, _ = oracle.pyramid(R[i], 8, 0.8)
+        ko, do, _ = oracle.orb_extract(lvL, sf, 2000, 80, 30)
+        kro, dro, _ = oracle.orb_extract(lvR, sf, 2000, 80, 30)
+        ref.append((ko, do, kro, dro, oracle.search_by_bf(do, dro, 10.0, 30.0)))
+    for f in range(F):
+        kl, dl, kr, dr, m, T, ninl, outl = p.frame_results(f)
+        ko, do, kro, dro, mo = ref[f % nd]
+        _eq_struct(kl, ko); _eq_struct(kr, kro)
+        assert np.array_equal(dl, do) and np.array_equal(dr, dro)
+        _eq_struct(m, mo)
+        _, Ti, obs = synth.pose_problem(seed * 1000 + f, p.kp_cap, KITTI_K)
+        n, To, oo, _ = oracle.pose_opt(KITTI_K, Ti, obs[:len(mo)])
+        assert ninl == n and np.array_equal(outl[:len(mo)], oo)
+        _close(T, To)
+    cache = {}
+    for ba, _, _ in p.bas:
+        P = ba.poses.cpu().numpy(); X = ba.pts.cpu().numpy(); st = ba.stats.cpu().numpy()
+        for w in range(ba.W):
+            n = int(ba.host["counts"][w])
+            key = ba.host["obs"][w, :n].tobytes() + ba.host["poses"][w].tobytes()
+            if key not in cache:
+                cache[key] = oracle.local_ba(K, ba.host["poses"][w], 2, ba.host["pts"][w], ba.host["obs"][w, :n], ba.iters)
+            io, Po, Xo, so = cache[key]
+            _close(P[w].reshape(-1, 4, 4), Po)
+            _close(X[w], Xo)
+            assert np.isclose(st[w, 2], so[2], rtol=1e-6) and int(st[w, 0]) == io
+    p.close()
+
+
 def test_context_refuses_the_null_stream():
     with pytest.raises(ValueError):
         capi.Context(0, stream=0)
