@@ -123,6 +123,28 @@ def test_local_ba_batched_windows(ctx):
         assert np.isclose(float(ba.stats[w, 2]), so[2], rtol=1e-6)
 
 
+def test_local_ba_bench_launch_shape(ctx):
+    """One of bench.py's three BA partitions: 171 windows of 10 keyframes / 5000 points per call -- the number of Schur
+    workgroups per window (1024 / W) and with it the number of partial systems the solve adds up follow from W, so the
+    shape the bench times gets its own check. 3 distinct windows tiled over the 171, each against the oracle."""
+    import torch
+    from trackingbench_slam_amd.ba import BatchedLocalBA
+    ba = BatchedLocalBA(ctx, 171, nkf=10, npt=5000, iters=10, seed=9, device=torch.device("cuda", 0), distinct=3)
+    ba.run()
+    torch.cuda.synchronize()
+    P = ba.poses.cpu().numpy(); X = ba.pts.cpu().numpy(); st = ba.stats.cpu().numpy()
+    ref = []
+    for w in range(3):
+        n = int(ba.host["counts"][w])
+        ref.append(oracle.local_ba(K, ba.host["poses"][w], 2, ba.host["pts"][w], ba.host["obs"][w, :n], 10))
+    for w in range(171):
+        io, Po, Xo, so = ref[w % 3]
+        _close(P[w].reshape(-1, 4, 4), Po)
+        _close(X[w], Xo)
+        assert np.isclose(st[w, 2], so[2], rtol=1e-6) and int(st[w, 0]) == io
+    assert np.array_equal(P[0], P[3]) and np.array_equal(X[1], X[4])      # copies of one window agree bit for bit
+
+
 def test_local_ba_rejects_bad_input(ctx):
     Pt, Pi, Xt, Xi, obs = synth.ba_problem(1, 4, 30, K)
     bad = obs.copy(); bad["kf"][0] = 99
