@@ -1,6 +1,7 @@
-/* Header shim: the slice of TRACKING_BENCH::Frame / Feature / MapPoint that the hot-path operators read and
- * write (reference include/types/Frame.h:28-203, include/types/MapPoint.h:19-60): image pyramid + scale
- * vectors, keypoints + descriptors, pose, per-feature map-point position and outlier flag.
+/* Header shim: the slice of TRACKING_BENCH::Frame / Feature that the hot-path operators read and
+ * write (reference include/types/Frame.h:28-203): image pyramid + scale vectors, keypoints + descriptors, pose,
+ * per-feature map point and outlier flag. MapPoint and Map live in types/MapPoint.h and types/Map.h as in the
+ * reference (its drivers include both, test/test_matcher.cpp:7-8); this header includes them.
  * Frame::ComputePyramid runs on the GPU through tb_pyramid. Map bookkeeping, BoW, undistortion and the
  * lookup-grid containers stay out of scope; the window matcher rebuilds the 120x36
  * grid inside tb_search_by_violence from the keypoints. */
@@ -10,6 +11,8 @@
 #include <utility>
 #include <vector>
 #include "../tb_compat/deps.h"
+#include "MapPoint.h"
+#include "Map.h"
 
 namespace TRACKING_BENCH
 {
@@ -17,48 +20,6 @@ namespace TRACKING_BENCH
 #define FRAME_GRID_COLS 120
     class Frame;
     class CameraModel;
-
-    class MapPoint
-    {
-    public:
-        explicit MapPoint(const Eigen::Vector3f& Pos) : mWorldPos(Pos) {}
-        // shim-only constructor: position + descriptor (the reference's takes Map / Frame / Feature handles,
-        // MapPoint.h:22-24; map bookkeeping is out of scope)
-        MapPoint(const Eigen::Vector3f& Pos, cv::Mat des) : mWorldPos(Pos), mDescriptor(std::move(des)) {}
-        void SetWorldPos(const Eigen::Vector3f& pos) { mWorldPos = pos; }
-        Eigen::Vector3f GetWorldPos() { return mWorldPos; }
-        // what the projection matchers read (reference MapPoint.h:30,37,44-45,55,60-61)
-        Eigen::Vector3f GetNormal() { return mNormalVector; }
-        int Observations() { return nObs; }
-        void SetBadFlag() { mbBad = true; }
-        bool isBad() { return mbBad; }
-        cv::Mat GetDescriptor() { return mDescriptor; }
-        float GetMinDistanceInvariance() { return 1; }      // constants in the reference (MapPoint.cpp:207-217)
-        float GetMaxDistanceInvariance() { return 1000; }
-        // shim-only setters for the state the reference derives in AddObservation / UpdateNormalAndDepth
-        void SetObservations(int n) { nObs = n; }
-        void SetNormal(const Eigen::Vector3f& normal) { mNormalVector = normal; }
-    private:
-        Eigen::Vector3f mWorldPos;
-        Eigen::Vector3f mNormalVector = Eigen::Vector3f::Zero();
-        cv::Mat mDescriptor;
-        int nObs = 0;
-        bool mbBad = false;
-    };
-
-    // Map: only the container the projection matcher walks (reference Map.h:13-42). The reference keeps the points in
-    // a std::set ordered by pointer value, so its GetAllMapPoints() order -- and with it DMatch::trainIdx -- changes
-    // from run to run; here it is insertion order.
-    class Map
-    {
-    public:
-        void AddMapPoint(const std::shared_ptr<MapPoint>& pMP) { mvpMapPoints.push_back(pMP); }
-        std::vector<std::shared_ptr<MapPoint>> GetAllMapPoints() { return mvpMapPoints; }
-        long unsigned int MapPointsInMap() { return mvpMapPoints.size(); }
-        void clear() { mvpMapPoints.clear(); }
-    private:
-        std::vector<std::shared_ptr<MapPoint>> mvpMapPoints;
-    };
 
     class Feature
     {
@@ -81,11 +42,13 @@ namespace TRACKING_BENCH
         Eigen::Matrix4f GetPoseInverse() { return mTwc; }
         Eigen::Matrix3f GetRotation();
         Eigen::Vector3f GetTranslation();
+        Eigen::Vector3f GetCameraCenter() { return mOw; }   // reference Frame.cpp:75
         // features (reference Frame.cpp:94-116)
         void SetKeys(std::vector<cv::KeyPoint>& pts, const std::shared_ptr<Frame>& frame, cv::Mat mDescriptors = cv::Mat(), bool unDistort = false);
         std::vector<std::shared_ptr<Feature>>& GetKeys(){return mvKeys;}
         std::shared_ptr<Feature>& GetKey(size_t id){return mvKeys.at(id);}
         cv::Mat GetDescriptors() const{return mDescriptors;}
+        cv::Mat GetDescriptor(int id) const{return mDescriptors.row(id);}   // reference Frame.h:81
         // reference Frame.h:98 (filled by ComputeBoW, Frame.cpp:266-271; here the caller fills it, the vocabulary is not part of the path)
         DBoW2::FeatureVector& GetFeatureVector(){return mFeatVec;}
         bool GetOutlier(size_t id){return mvbOutlier.at(id) != 0;}
@@ -96,6 +59,7 @@ namespace TRACKING_BENCH
         // map points
         std::shared_ptr<MapPoint> GetMapPoint(const size_t &idx) { return mvpMapPoints.at(idx); }
         void AddMapPoint(std::shared_ptr<MapPoint>& pMP, const size_t& idx) { mvpMapPoints.at(idx) = pMP; }
+        std::vector<std::shared_ptr<MapPoint>> GetMapPointMatches() { return mvpMapPoints; }   // reference Frame.h:104
         // key frame / pyramid
         int GetMaxLevel() const{return nLevels;}
         void ComputePyramid(cv::Mat image);

@@ -19,6 +19,8 @@
 #include "mapping/LocalBA.h"
 #include "matchers/matcher.h"
 #include "types/Frame.h"
+#include "types/Map.h"
+#include "types/MapPoint.h"
 #include "tb_types.h"
 
 using namespace TRACKING_BENCH;
@@ -70,14 +72,17 @@ int main(int argc, char** argv)
     std::ifstream ob(argv[3], std::ios::binary);
     int32_t n = 0; ob.read((char*)&n, 4);
     std::vector<float> rec((size_t)n * 6); ob.read((char*)rec.data(), (std::streamsize)rec.size() * 4);
+    auto pose_map_ptr = std::make_shared<Map>();
     for (int i = 0; i < n && i < (int)keypoints1.size(); i++)
     {
         auto& f = frame1_ptr->GetKey(i);
         f->px[0] = rec[6 * i]; f->px[1] = rec[6 * i + 1];
         f->kp.octave = (int)rec[6 * i + 5];
         Eigen::Vector3f X; X[0] = rec[6 * i + 2]; X[1] = rec[6 * i + 3]; X[2] = rec[6 * i + 4];
-        auto mp = std::make_shared<MapPoint>(X);
+        // the reference's four-argument construction (test/test_vo.cpp:344; the descriptor argument defaults to empty)
+        auto mp = std::make_shared<MapPoint>(X, pose_map_ptr, frame1_ptr, f);
         frame1_ptr->AddMapPoint(mp, i);
+        pose_map_ptr->AddMapPoint(mp);
     }
     frame1_ptr->SetPose(Eigen::Matrix4f::Identity());
     LocalBA localBa;
@@ -101,13 +106,20 @@ int main(int argc, char** argv)
         Eigen::Vector3f Pc; Pc[0] = (x - 607.1928f) / 718.856f * depth; Pc[1] = (y - 185.2157f) / 718.856f * depth; Pc[2] = depth;
         Eigen::Vector3f Pw;
         for (int a = 0; a < 3; a++) Pw[a] = Twc(a, 0) * Pc[0] + Twc(a, 1) * Pc[1] + Twc(a, 2) * Pc[2] + Twc(a, 3);
-        cv::Mat des(1, 32, CV_8UC1);
-        std::memcpy(des.ptr(0), descriptors1.ptr(j), 32);
-        des.ptr(0)[i2 % 32] ^= (uint8_t)(i2 & 0x7); // a few flipped bits
-        auto mp = std::make_shared<MapPoint>(Pw, des);
-        Eigen::Vector3f nrm; for (int a = 0; a < 3; a++) nrm[a] = Pw[a] - Twc(a, 3);
-        const float nn = std::sqrt(nrm[0] * nrm[0] + nrm[1] * nrm[1] + nrm[2] * nrm[2]);
-        for (int a = 0; a < 3; a++) nrm[a] /= nn;
+        // constructed exactly as test/test_projection.cpp:631 builds its map: position, map, the frame and the feature the
+        // point was seen from, that feature's descriptor. The constructor derives the unit viewing direction from the
+        // frame's camera centre and takes the feature's descriptor row (reference MapPoint.cpp:24-37)
+        auto mp = std::make_shared<MapPoint>(Pw, map_ptr, frame1_ptr, frame1_ptr->GetKey(j), frame1_ptr->GetDescriptor(j));
+        cv::Mat des = mp->GetDescriptor();
+        if (des.rows != 1 || std::memcmp(des.ptr(0), descriptors1.ptr(j), 32) != 0) { std::cerr << "MapPoint descriptor\n"; return 3; }
+        des.ptr(0)[i2 % 32] ^= (uint8_t)(i2 & 0x7); // a few flipped bits (the point's own copy of the row)
+        Eigen::Vector3f nrm = mp->GetNormal();
+        {
+            float chk[3], nn = 0;
+            for (int a = 0; a < 3; a++) { chk[a] = Pw[a] - Twc(a, 3); nn += chk[a] * chk[a]; }
+            nn = std::sqrt(nn);
+            for (int a = 0; a < 3; a++) if (std::fabs(chk[a] / nn - nrm[a]) > 1e-6f) { std::cerr << "MapPoint normal\n"; return 3; }
+        }
         if (i2 % 4 == 1) nrm[0] = -nrm[0]; // some points face away
         mp->SetNormal(nrm);
         if (i2 % 11 == 3) mp->SetBadFlag();

@@ -32,15 +32,16 @@
 #include "tb_se3.h"
 
 #define BA_T 256
-#define BA_CP 4               /* points per Schur chunk (one wavefront each) */
-#define BA_LD (BA_CP * 3 + 1) /* LDS row stride (doubles) of the densified tiles */
 #define BA_KFCH 1024          /* edges per keyframe-pass chunk */
 #define BA_KFBLK 4            /* workgroups per keyframe in the keyframe pass */
 #define BA_BIG_MAXF 64        /* free keyframes of a large window (6 bits of the free-edge key) */
-#ifndef BA_GP
-#define BA_GP 8               /* points per Schur group at most (k_ba_schur_g); see the kernel for how 8 was chosen */
+#define BA_SMALL_MAXF 10      /* free keyframes of a window on the MFMA path (visibility patterns are 10-bit masks) */
+#ifndef BA_EMAX
+#define BA_EMAX 64            /* free-keyframe edges of a Schur group at most: one lane each */
 #endif
-#define BA_GRP_MAXPT 32768    /* windows up to this many points get a group table (one byte of LDS per point in the setup) */
+#ifndef BA_PCAP
+#define BA_PCAP 21            /* points of a Schur group at most (their 12-double records fill 252 of 256 staged doubles) */
+#endif
 
 struct BaState {
     double lambda, ni, currentChi, chi0, scale_p, rho;
@@ -61,8 +62,11 @@ struct BaDims {
     /* per-window offsets, in ints, into the int workspace */
     unsigned long long istride, oPtStart, oPtFree, oKfStart, oKfEdges, oFreeKP;
     unsigned long long oKfRec;   /* ints: 16-byte records {pt, u, v, inv_sigma2} of every edge in keyframe order (the keyframe pass) */
-    unsigned long long oGrp;     /* ints: point groups of the Schur kernel (grp[0..ng], ng at [npt + 1]); grouped != 0 if built */
-    int grouped, pad1;
+    /* ints, windows on the MFMA path (k_ba_groups): visibility mask per point, the two permutation buffers of the pattern
+     * sort, rank of every point in pattern order (its record's slot in Hq; identity for large windows), the free-keyframe
+     * edge records in pattern order (4 ints each), the group descriptors (int4 each, count at [4 npt]) */
+    unsigned long long oPtMask, oPermA, oPermB, oPtRank, oKPs, oGDesc;
+    int schurWaveLds, pad1;      /* doubles of LDS per Schur wavefront (host: ba_c_wave_lds(nfree)) */
 };
 
 typedef double ba_d4 __attribute__((ext_vector_type(4)));
@@ -275,31 +279,6 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
                 }
             });
         for (int p = max((nobs > 0 ? obs[nobs - 1].pt : -1) + 1, 0) + tid; p <= d.npt; p += BA_T) I[d.oPtFree + p] = nfreeE;
-        __syncthreads();
-        if (d.grouped) {
-            /* point groups of k_ba_schur_g: maximal runs of whole points with at most BA_GP points and 64 free-keyframe
-             * edges (one lane per edge), greedy from point 0. Every thread finds where a group that starts at its point
-             * would end (15 independent loads), one thread then walks the chain through LDS (~npt / 12 steps). */
-            __shared__ unsigned char span[BA_GRP_MAXPT];
-            __threadfence_block();
-            for (int p = tid; p < d.npt; p += BA_T) {
-                int pf[BA_GP + 1];
-#pragma unroll
-                for (int i = 0; i <= BA_GP; i++) pf[i] = I[d.oPtFree + min(p + i, d.npt)];
-                int n = 1;
-#pragma unroll
-                for (int i = 2; i <= BA_GP; i++)
-                    if (n == i - 1 && p + i <= d.npt && pf[i] - pf[0] <= 64) n = i;
-                span[p] = (unsigned char)n;
-            }
-            __syncthreads();
-            if (tid == 0) {
-                int g = 0;
-                for (int p = 0; p < d.npt; p += span[p]) I[d.oGrp + g++] = p;
-                I[d.oGrp + g] = d.npt;
-                I[d.oGrp + d.npt + 1] = g;
-            }
-        }
         return;
     }
     if (tid == 0) {
@@ -313,6 +292,7 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
         for (int p = max(prev + 1, 0); p <= min(cur, d.npt); p++) I[d.oPtStart + p] = e;
     }
     for (int p = max((nobs > 0 ? obs[nobs - 1].pt : -1) + 1, 0) + tid; p <= d.npt; p += BA_T) I[d.oPtStart + p] = nobs;
+    if (d.big) for (int p = tid; p < d.npt; p += BA_T) I[d.oPtRank + p] = p; /* large windows keep the point records in point order */
     for (int kk = tid; kk < d.nkf; kk += BA_T) {
         const float* T = poses + ((size_t)w * d.nkf + kk) * 16;
         double R[9], t[3];
@@ -405,7 +385,7 @@ k_ba_points(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
         }
         for (int a = 0; a < 6; a++) D[d.oHll + (size_t)p * 6 + a] = Hll[a];
         for (int a = 0; a < 3; a++) D[d.oBl + (size_t)p * 3 + a] = bl[a];
-        if (st.iter > 0) ba_write_rec(D + d.oHq + (size_t)p * 12, Hll, bl, X, st.lambda, states + w); /* lambda of this trial is final */
+        if (st.iter > 0) ba_write_rec(D + d.oHq + (size_t)I[d.oPtRank + p] * 12, Hll, bl, X, st.lambda, states + w); /* lambda of this trial is final; records sit in pattern order */
         maxd = fmax(fabs(Hll[0]), fmax(fabs(Hll[3]), fabs(Hll[5])));
     }
     const double s = ba_block_sum1(chi, red);
@@ -558,17 +538,167 @@ k_ba_reduce(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, BaSta
  * (Hll + lambda I)^-1 (ba_inv3's result is symmetric bit for bit) followed by bl, or zeros for a singular block.
  * The Schur wavefronts fetch these 9-double records with their edge rows instead of inverting on 4 lanes. */
 __global__ void __launch_bounds__(BA_T)
-k_ba_hinv(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) {
+k_ba_hinv(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, BaState* __restrict__ states) {
     const int w = blockIdx.y, p = blockIdx.x * BA_T + threadIdx.x;
     const BaState st = states[w];
     if (st.status || st.hq_fresh || p >= d.npt) return; /* hq_fresh: k_ba_points wrote the records for this lambda */
     double* D = dw + (size_t)w * d.wstride;
+    const int* I = iw + (size_t)w * d.istride;
     double ph[6], pb[3], X[3];
 #pragma unroll
     for (int i = 0; i < 6; i++) ph[i] = D[d.oHll + (size_t)p * 6 + i];
 #pragma unroll
     for (int i = 0; i < 3; i++) { pb[i] = D[d.oBl + (size_t)p * 3 + i]; X[i] = D[d.oP + ((size_t)st.cur * d.npt + p) * 3 + i]; }
-    ba_write_rec(D + d.oHq + (size_t)p * 12, ph, pb, X, st.lambda, states + w);
+    ba_write_rec(D + d.oHq + (size_t)I[d.oPtRank + p] * 12, ph, pb, X, st.lambda, states + w);
+}
+
+/* ---- D: Schur complement S' (np x np, lower triangle) and reduced rhs, pattern-compact MFMA form (round 3).
+ * Nothing per edge is stored between the passes: S' = sum_l Z_l Z_l^T with Z_l = Hpl_l U_l (6 nfree x 3), where U_l
+ * comes from the point record (A_l^-1 = U_l U_l^T) and every Hpl block = ww Jp^T Jl is rebuilt from the 16-byte
+ * free-edge record and the linearisation state.
+ *
+ * Rounds 1-2 densified Z into a (6 nfree)-row tile and ran v_mfma_f64_16x16x4 over all of it: a point is seen by ~3.4 of
+ * the 8 free keyframes, so 2.97 x the algorithmic flops were products with zero rows. Here the points of a window are
+ * SORTED BY VISIBILITY PATTERN once per call (k_ba_groups: the mask of free keyframes that see the point), a group is a
+ * run of up to BA_PCAP points / BA_EMAX edges with ONE pattern of k keyframes, and its tile holds only the 6 k rows that
+ * exist (+ one row for the rhs): Zc[6 slot + a][3 pl + c], slot = rank of the keyframe inside the pattern. The block
+ * product Zc Zc^T runs on v_mfma_f64_4x4x4 (four independent 4x4x4 products per instruction, 16 clocks: the same
+ * 32 flop / clock / SIMD as the 16x16x4 form, measured in tools/ubench/mfma_f64_4x4.hip) at 4-row granularity:
+ *   operand V_m      = rows 16 m .. 16 m + 15 of the tile (lane 16 kq + r: row r, column 4 ks + kq -- the 16x16x4 A layout
+ *                      IS the 4x4x4 layout of four consecutive row blocks), one ds_read_b64;
+ *   rot_s(V_m)       = its four row blocks rotated by s (DPP row_ror, two 32-bit moves): mfma(rot_s(V_m), V_m') is the
+ *                      block diagonal s of tile (m, m'); s = 0, 1, 2 cover a diagonal tile's ten unique blocks, s = 0..3
+ *                      the sixteen of an off-diagonal one;
+ *   W_r              = one row block broadcast to all four positions (LDS read with a repeated address), for the
+ *                      nb mod 4 row blocks behind the last full tile: one instruction per full tile instead of four.
+ * Instructions per 4 columns: 3 (k = 2), 5 (k = 3), 9 (k = 4), 10 (k = 5), ... 25 (k = 8) against 6 x 4 = 24 block-equivalents
+ * of the dense 48-row form whatever k is. The rhs sum_l Z_l (U_l^T bl_l) is row 6 k of the same product (its own row of the
+ * tile holds U^T bl per column). A group's result is a compact (6 k + 1) x 6 k triangle: it goes through LDS once
+ * (4x4 blocks, aliasing the tile) and is added into the wavefront's DENSE accumulators, which live in registers for the
+ * whole kernel -- one register per 6 x 6 block pair (a >= b), lanes 0..35 its entries -- by a wave-uniform walk over the
+ * pairs the pattern has. Every sum has a fixed order (groups in index order per wavefront, wavefronts in order, workgroups
+ * in order in k_ba_solve), so the result is reproducible bit for bit.
+ * Records are prefetched two groups ahead into one of two register sets, as before. */
+#define BA_MAXT 4 /* 16-row tiles per side of the dense system (np <= 60) */
+#define BA_REC 12
+#define BA_RECS_LDS 256 /* staged point records of a group: BA_PCAP * BA_REC <= 256 doubles */
+/* The Schur tile is private to one wavefront and the LDS executes a wavefront's instructions in issue order, so
+ * cross-lane visibility needs no counter wait: a wavefront-scope fence only pins the compiler's ordering (a
+ * workgroup-scope one would also drain vmcnt, i.e. the prefetched records, on every phase change). */
+__device__ __forceinline__ void ba_wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
+
+/* geometry of a pattern with k keyframes: points per group, 4-row blocks (6 k rows + the rhs row), tile row stride.
+ * The stride is 2 mod 4: the operand reads (16 rows x 2 columns per half wavefront) then hit 32 different 8-byte banks. */
+__host__ __device__ constexpr int ba_c_cap(int k) { return (BA_EMAX / k) < BA_PCAP ? (BA_EMAX / k) : BA_PCAP; }
+__host__ __device__ constexpr int ba_c_nb(int k) { return (6 * k + 1 + 3) / 4; }
+__host__ __device__ constexpr int ba_c_ld(int k) { return ((3 * ba_c_cap(k) + 3) / 4) * 4 + 2; }
+__host__ __device__ constexpr int ba_c_tile(int k) { return 4 * ba_c_nb(k) * ba_c_ld(k); }
+__host__ __device__ constexpr int ba_c_tri(int k) { return 16 * (ba_c_nb(k) * (ba_c_nb(k) + 1) / 2); } /* compact result, 4x4 blocks */
+struct BaCTab { int cap[BA_SMALL_MAXF + 1], ld[BA_SMALL_MAXF + 1]; };
+__host__ __device__ constexpr BaCTab ba_c_tab() {
+    BaCTab t = {};
+    for (int k = 1; k <= BA_SMALL_MAXF; k++) { t.cap[k] = ba_c_cap(k); t.ld[k] = ba_c_ld(k); }
+    return t;
+}
+__device__ const BaCTab ba_ctab = ba_c_tab();
+static int ba_c_wave_lds(int nfree) {
+    int m = 0;
+    for (int k = 1; k <= nfree; k++) m = std::max(m, std::max(ba_c_tile(k), ba_c_tri(k)));
+    return ((m + 3) & ~3) + BA_RECS_LDS;
+}
+
+/* Stable partition of src[0..n) by a predicate into dst (zeros first, both classes in source order) by one 256-thread
+ * workgroup: every wavefront owns a contiguous quarter, counts, one barrier gives the bases, ballots rank. One pass of the
+ * LSD pattern sort. tmp: >= 4 ints of LDS. Ends with a barrier (dst visible to the workgroup). */
+template <class IsZero>
+__device__ __forceinline__ void ba_stable_split(int n, int* tmp, const int* src, int* dst, IsZero isZero) {
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int q = (((n + 3) >> 2) + 63) & ~63, lo = min(wave * q, n), hi = min(lo + q, n);
+    int cnt = 0;
+    for (int e = lo + lane; e < hi; e += 64) cnt += isZero(src[e]) ? 1 : 0;
+    cnt = tb_wave_sum(cnt);
+    if (lane == 0) tmp[wave] = cnt;
+    __syncthreads();
+    int z = 0;
+    for (int v = 0; v < wave; v++) z += tmp[v];
+    int o = (tmp[0] + tmp[1] + tmp[2] + tmp[3]) + (lo - z); /* ones start behind all zeros; lo - z of them come before this quarter */
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+    for (int e0 = lo; e0 < hi; e0 += 64) {
+        const int e = e0 + lane;
+        const bool valid = e < hi;
+        const int v = valid ? src[e] : 0;
+        const bool f = valid && isZero(v);
+        const unsigned long long m0 = __ballot(f), m1 = __ballot(valid && !f);
+        if (valid) dst[f ? z + __popcll(m0 & lt) : o + __popcll(m1 & lt)] = v;
+        z += __popcll(m0);
+        o += __popcll(m1);
+    }
+    __threadfence_block();
+    __syncthreads();
+}
+
+/* ---- once per call, windows on the MFMA path: visibility patterns, pattern sort, ranks, pattern-ordered edge records,
+ * group descriptors. grid (W) x 256 threads. */
+__global__ void __launch_bounds__(BA_T)
+k_ba_groups(BaDims d, int* __restrict__ iw, const int* __restrict__ errflag) {
+    __shared__ int cntb[1 << BA_SMALL_MAXF], bst[1 << BA_SMALL_MAXF], ebin[1 << BA_SMALL_MAXF], tmp[16];
+    const int w = blockIdx.x, tid = threadIdx.x;
+    if (errflag[w]) return; /* observations rejected by k_ba_setup: k_ba_points ends the window before anything reads the tables */
+    int* I = iw + (size_t)w * d.istride;
+    const int4* KP = reinterpret_cast<const int4*>(I + d.oFreeKP);
+    const int nbins = 1 << d.nfree;
+    for (int i = tid; i < nbins; i += BA_T) cntb[i] = 0;
+    __syncthreads();
+    for (int p = tid; p < d.npt; p += BA_T) {
+        const int e0 = I[d.oPtFree + p], e1 = I[d.oPtFree + p + 1];
+        int m = 0;
+        for (int e = e0; e < e1; e++) m |= 1 << (KP[e].x & 63);
+        I[d.oPtMask + p] = m;
+        I[d.oPermA + p] = p;
+        atomicAdd(&cntb[m], 1); /* counts only: the order of the adds does not matter */
+    }
+    __threadfence_block();
+    __syncthreads();
+    /* LSD sort of the points by mask, one stable split per free keyframe: equal masks end up adjacent, in point order */
+    int* src = I + d.oPermA;
+    int* dst = I + d.oPermB;
+    for (int b = 0; b < d.nfree; b++) {
+        ba_stable_split(d.npt, tmp, src, dst, [&](int p) { return ((I[d.oPtMask + p] >> b) & 1) == 0; });
+        int* t = src; src = dst; dst = t;
+    }
+    for (int r = tid; r < d.npt; r += BA_T) I[d.oPtRank + src[r]] = r;
+    /* first rank and first pattern-ordered edge of every pattern */
+    for (int i = tid; i < nbins; i += BA_T) { bst[i] = cntb[i]; ebin[i] = cntb[i] * __popc(i); }
+    __syncthreads();
+    tb_block_excl_scan(bst, nbins, tmp);
+    tb_block_excl_scan(ebin, nbins, tmp);
+    __threadfence_block();
+    __syncthreads();
+    /* the free-keyframe edge records in pattern order; a point's edges in ascending keyframe order (slot = row block) */
+    int4* KPs = reinterpret_cast<int4*>(I + d.oKPs);
+    for (int p = tid; p < d.npt; p += BA_T) {
+        const int m = I[d.oPtMask + p];
+        if (m == 0) continue;
+        const int k = __popc(m), base = ebin[m] + (I[d.oPtRank + p] - bst[m]) * k;
+        const int e0 = I[d.oPtFree + p], e1 = I[d.oPtFree + p + 1];
+        for (int e = e0; e < e1; e++) {
+            const int4 rec = KP[e];
+            KPs[base + __popc(m & ((1 << (rec.x & 63)) - 1))] = rec;
+        }
+    }
+    /* groups: every ba_c_cap(k)-th point of a pattern's run starts one */
+    int unused = 0;
+    int4* GD = reinterpret_cast<int4*>(I + d.oGDesc);
+    auto starts = [&](int r) {
+        const int m = I[d.oPtMask + src[r]];
+        return m != 0 && (r - bst[m]) % ba_ctab.cap[__popc(m)] == 0;
+    };
+    const int ng = ba_ordered_rank(d.npt, tmp, starts, [](int) { return false; }, &unused, [&](int r, int g, bool hit) {
+        if (!hit) return;
+        const int m = I[d.oPtMask + src[r]], k = __popc(m), at = r - bst[m];
+        GD[g] = make_int4(r, ebin[m] + at * k, m, min(ba_ctab.cap[k], cntb[m] - at));
+    });
+    if (tid == 0) I[d.oGDesc + 4 * (size_t)d.npt] = ng;
 }
 
 /* broadcast of one lane's double through the scalar unit (lane index wave-uniform) */
@@ -577,96 +707,171 @@ __device__ __forceinline__ double ba_readlane(double v, int lane) {
     const int hi = __builtin_amdgcn_readlane(__double2hiint(v), lane);
     return __hiloint2double(hi, lo);
 }
+/* rot_S: lane x of every row of 16 lanes reads lane x + 4 S of the same row (row_ror:16 - 4 S moves data 16 - 4 S lanes up) */
+template <int S>
+__device__ __forceinline__ double ba_rot(double v) {
+    static_assert(S >= 1 && S <= 3, "rotation by whole row blocks");
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + 16 - 4 * S, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + 16 - 4 * S, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+template <int S>
+__device__ __forceinline__ double ba_rot_any(double v) {
+    if constexpr (S == 0) return v;
+    else return ba_rot<S>(v);
+}
 
-/* ---- D: Schur complement S' (np x np, lower triangle) and reduced rhs as an FP64 MFMA block product.
- * Nothing per edge is stored between the passes: S' = sum_l Z_l Z_l^T with Z_l = Hpl_l U_l (6 nfree x 3), where U_l
- * comes from the point record (A_l^-1 = U_l U_l^T) and every Hpl block = ww Jp^T Jl is rebuilt from the 16-byte
- * free-edge record and the linearisation state -- ~250 FP64 vector operations per edge, hidden behind the matrix
- * pipe, against 144 bytes of HBM traffic per edge and pass when the blocks were stored.
- * Every WAVEFRONT works on its own 4-point chunks with a private LDS tile (no workgroup barrier in the loop):
- *   lane = one free-keyframe edge of the chunk (at most 4 nfree <= 40): linearise, Z rows into the dense tile
- *   Z[6 kfree + a][3 pl + c]; 3 k-steps of v_mfma_f64_16x16x4 over the lower-triangle 16x16 tiles with both operands
- *   read from that one tile; reduced rhs = sum_l Z_l (U_l^T bl_l) as 12 FMAs per lane (lane = row); the touched
- *   entries are cleared again. Records are prefetched two chunks ahead into one of two register sets; the fetch
- *   path is unconditional (clamped indices, chunks past the end fetch the last one and stage nothing), so the
- *   number of loads in flight is the same on every path and the compiler waits with vmcnt(N).
- * The four waves' accumulators are summed through LDS in wave order; one partial per workgroup goes to k_ba_solve. */
-#define BA_MAXT 4 /* 16-row tiles per side (np <= 60) */
-/* The Schur tile is private to one wavefront and the LDS executes a wavefront's instructions in issue order, so
- * cross-lane visibility needs no counter wait: a wavefront-scope fence only pins the compiler's ordering (a
- * workgroup-scope one would also drain vmcnt, i.e. the prefetched records, on every phase change). */
-__device__ __forceinline__ void ba_wave_lds_fence() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
-/* LDS of one wavefront, in doubles: the Z tile [16 R][BA_LD], the chunk's BA_CP point records, a 4-double sink */
-#define BA_REC 12
-#define BA_TRASH_R(R) (16 * (R) * BA_LD + BA_CP * BA_REC)
-#define BA_WAVE_LDS_R(R) (BA_TRASH_R(R) + 4)
-
-/* one prefetched Schur chunk */
-struct BaPre {
-    int key;        /* lane < edges of the chunk: pt << 6 | free keyframe index, else -1 */
-    float u, v, w;  /* pixel, information scale */
-    double rq;      /* lane < BA_CP * BA_REC: one double of the chunk's point records */
-    int ne0, ne1;   /* compact edge range of the chunk this set fetches next */
+/* one prefetched Schur group */
+struct BaPreC {
+    int key;           /* lane < edges of the group: pt << 6 | free keyframe index, else -1 */
+    float u, v, w;     /* pixel, information scale */
+    double r0, r1, r2, r3; /* doubles lane, 64 + lane, ... of the group's point records */
+    int4 cur;          /* the group this set holds: first rank, first edge, pattern, points */
+    int4 nxt;          /* the group it fetches next */
 };
 
-template <int R> /* R = 16-row tiles of the pose block: compile-time tile set (lower triangle), so the MFMA phase is
-                     straight-line code with the accumulators pinned in registers */
+/* Block product of a group's tile for a pattern of K keyframes, result into C as 4x4 blocks of the lower triangle:
+ * block (rb >= cb) at C[16 (rb (rb + 1) / 2 + cb)], row major. C may alias the tile (it is written after the last read). */
+template <int K>
+__device__ __forceinline__ void ba_c_product(const double* __restrict__ Zt, double* __restrict__ C, int nks, int lane) {
+    constexpr int NB = ba_c_nb(K), LD = ba_c_ld(K), NVF = NB / 4, REM = NB % 4;
+    constexpr int NACC = 3 * NVF + 2 * NVF * (NVF - 1) + REM * (NVF + 1);
+    constexpr int LASTROW = 4 * NB - 1;
+    double acc[NACC];
+#pragma unroll
+    for (int i = 0; i < NACC; i++) acc[i] = 0;
+    const int kq = lane >> 4, r16 = lane & 15;
+    int vofs[NVF + 1], wofs[REM + 1];
+#pragma unroll
+    for (int m = 0; m <= NVF; m++) vofs[m] = min(16 * m + r16, LASTROW) * LD + kq; /* m = NVF: the partial tile, rows clamped (unused blocks) */
+#pragma unroll
+    for (int r = 0; r < REM; r++) wofs[r] = (4 * (4 * NVF + r) + (lane & 3)) * LD + kq;
+    for (int ks = 0; ks < nks; ks++) {
+        const double* z = Zt + 4 * ks;
+        double V[NVF + 1];
+#pragma unroll
+        for (int m = 0; m < NVF; m++) V[m] = z[vofs[m]];
+#pragma unroll
+        for (int m = 0; m < NVF; m++) {
+            const double r1 = ba_rot<1>(V[m]), r2 = ba_rot<2>(V[m]);
+            acc[3 * m] = __builtin_amdgcn_mfma_f64_4x4x4f64(V[m], V[m], acc[3 * m], 0, 0, 0);
+            acc[3 * m + 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(r1, V[m], acc[3 * m + 1], 0, 0, 0);
+            acc[3 * m + 2] = __builtin_amdgcn_mfma_f64_4x4x4f64(r2, V[m], acc[3 * m + 2], 0, 0, 0);
+            if (m > 0) {
+                const double r3 = ba_rot<3>(V[m]);
+#pragma unroll
+                for (int mp = 0; mp < m; mp++) {
+                    const int o = 3 * NVF + 4 * (m * (m - 1) / 2 + mp);
+                    acc[o] = __builtin_amdgcn_mfma_f64_4x4x4f64(V[m], V[mp], acc[o], 0, 0, 0);
+                    acc[o + 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(r1, V[mp], acc[o + 1], 0, 0, 0);
+                    acc[o + 2] = __builtin_amdgcn_mfma_f64_4x4x4f64(r2, V[mp], acc[o + 2], 0, 0, 0);
+                    acc[o + 3] = __builtin_amdgcn_mfma_f64_4x4x4f64(r3, V[mp], acc[o + 3], 0, 0, 0);
+                }
+            }
+        }
+        if (REM > 0) {
+            double W[REM + 1];
+#pragma unroll
+            for (int r = 0; r < REM; r++) W[r] = z[wofs[r]];
+            const double VP = (REM > 1) ? z[vofs[NVF]] : W[0]; /* one trailing block: every position of W[0] x W[0] is that block */
+#pragma unroll
+            for (int r = 0; r < REM; r++) {
+                const int o = 3 * NVF + 2 * NVF * (NVF - 1) + r * (NVF + 1);
+#pragma unroll
+                for (int mp = 0; mp < NVF; mp++) acc[o + mp] = __builtin_amdgcn_mfma_f64_4x4x4f64(W[r], V[mp], acc[o + mp], 0, 0, 0);
+                acc[o + NVF] = __builtin_amdgcn_mfma_f64_4x4x4f64(W[r], VP, acc[o + NVF], 0, 0, 0);
+            }
+        }
+    }
+    ba_wave_lds_fence();
+    /* result lane 16 i + 4 q + j = entry (i, j) of position q's block */
+    const int i = lane >> 4, q = (lane >> 2) & 3, j = lane & 3;
+    auto put = [&](int bA, int bB, double v, bool ok) {
+        const int rb = max(bA, bB), cb = min(bA, bB);
+        const int ri = (bA >= bB) ? i : j, ci = (bA >= bB) ? j : i; /* a wrapped position holds the transposed upper block */
+        if (ok) C[16 * (rb * (rb + 1) / 2 + cb) + 4 * ri + ci] = v;
+    };
+#pragma unroll
+    for (int m = 0; m < NVF; m++) {
+        put(4 * m + q, 4 * m + q, acc[3 * m], true);
+        put(4 * m + ((q + 1) & 3), 4 * m + q, acc[3 * m + 1], true);
+        put(4 * m + ((q + 2) & 3), 4 * m + q, acc[3 * m + 2], q < 2); /* positions 2, 3 repeat 0, 1 transposed */
+#pragma unroll
+        for (int mp = 0; mp < m; mp++) {
+            const int o = 3 * NVF + 4 * (m * (m - 1) / 2 + mp);
+#pragma unroll
+            for (int s = 0; s < 4; s++) put(4 * m + ((q + s) & 3), 4 * mp + q, acc[o + s], true);
+        }
+    }
+#pragma unroll
+    for (int r = 0; r < REM; r++) {
+        const int o = 3 * NVF + 2 * NVF * (NVF - 1) + r * (NVF + 1);
+#pragma unroll
+        for (int mp = 0; mp < NVF; mp++) put(4 * NVF + r, 4 * mp + q, acc[o + mp], true);
+        put(4 * NVF + r, 4 * NVF + ((REM > 1) ? q : r), acc[o + NVF], (REM > 1) ? (q <= r) : (q == 0));
+    }
+    ba_wave_lds_fence();
+}
+
+template <int R> /* 16-row tiles of the dense pose block; NF = free keyframes this instantiation holds */
 __global__ void __launch_bounds__(BA_T, 2)
-k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw, const int* __restrict__ iw,
-           BaState* __restrict__ states) {
+k_ba_schur_c(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, BaState* __restrict__ states) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    __shared__ double sRtf[10 * 12]; /* free keyframes at the linearisation state: R, t */
-    const int w = blockIdx.y, g = blockIdx.x, tid = threadIdx.x;
+    __shared__ double sRtf[BA_SMALL_MAXF * 12]; /* free keyframes at the linearisation state: R, t */
+    constexpr int NF = (R == 1) ? 2 : (R == 2) ? 5 : (R == 3) ? 8 : BA_SMALL_MAXF;
+    constexpr int NPAIR = NF * (NF + 1) / 2;
+    const int w = blockIdx.y, g0 = blockIdx.x, tid = threadIdx.x;
     const BaState st = states[w];
     if (st.status) return;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    constexpr int ROWS = 16 * R, BA_WAVE_LDS = BA_WAVE_LDS_R(R);
-    double* Zl = lds + (size_t)wave * BA_WAVE_LDS; /* [ROWS][BA_LD]: Hpl U */
-    double* Hi = Zl + ROWS * BA_LD;                /* [BA_CP][BA_REC] */
+    double* Zt = lds + (size_t)wave * d.schurWaveLds;          /* the group's tile, then its compact result */
+    double* Hi = Zt + (d.schurWaveLds - BA_RECS_LDS);           /* the group's point records */
     double* D = dw + (size_t)w * d.wstride;
     const int* I = iw + (size_t)w * d.istride;
     for (int k = tid; k < d.nfree; k += BA_T) ba_pose_to_Rt(D + d.oT + ((size_t)st.cur * d.nkf + d.nfixed + k) * 7, sRtf + k * 12);
-    ba_d4 acc[BA_MAXT][BA_MAXT];
+    double S[NPAIR]; /* dense accumulators: register p = block pair (a >= b), lane 6 i + j = entry (i, j) */
 #pragma unroll
-    for (int r = 0; r < BA_MAXT; r++)
-#pragma unroll
-        for (int c = 0; c < BA_MAXT; c++) acc[r][c] = (ba_d4){0, 0, 0, 0};
-    for (int i = lane; i < ROWS * BA_LD; i += 64) Zl[i] = 0;
+    for (int p = 0; p < NPAIR; p++) S[p] = 0;
+    double rhs = 0;  /* lane = dense row */
     __syncthreads();
     const double delta = (double)sqrtf(5.991f);
-    const int stride = d.G * 4, pf = 2 * stride; /* waves per window; chunk distance between a set's fills */
-    const int lastCh = d.nChunks - 1, lastE = d.obs_pitch - 1;
+    const int ng = I[d.oGDesc + 4 * (size_t)d.npt];
+    const int stride = d.G * 4, pf = 2 * stride;
+    const int lastG = ng - 1, lastE = d.obs_pitch - 1;
     const double* Hq = D + d.oHq;
-    const int4* KP = reinterpret_cast<const int4*>(I + d.oFreeKP);
-    auto range = [&](BaPre& X, int c) {
-        c = min(c, lastCh);
-        X.ne0 = I[d.oPtFree + c * BA_CP];
-        X.ne1 = I[d.oPtFree + min(c * BA_CP + BA_CP, d.npt)];
+    const int4* KPs = reinterpret_cast<const int4*>(I + d.oKPs);
+    const int4* GD = reinterpret_cast<const int4*>(I + d.oGDesc);
+    const unsigned lastQ = (unsigned)d.npt * BA_REC - 1u;
+    auto range = [&](BaPreC& X, int g) {
+        X.nxt = GD[min(g, lastG)];
+        if (g > lastG) X.nxt.w = 0; /* past the end: an empty group */
     };
-    auto preload = [&](BaPre& X, int c) { /* X.ne0/ne1 = compact edge range of chunk min(c, lastCh) */
-        const int p0 = min(c, lastCh) * BA_CP, ea = X.ne0, eb = (c <= lastCh) ? X.ne1 : ea; /* past the end: no items */
-        const int4 r = KP[(unsigned)min(ea + lane, lastE)]; /* unsigned 32-bit index: scalar base + vector offset */
-        X.key = (lane < eb - ea) ? r.x : -1;
+    auto preload = [&](BaPreC& X, int g) { /* X.nxt = descriptor of group g (fetched one fill earlier); then the one of g + pf */
+        const int4 gd = X.nxt;
+        const int4 r = KPs[(unsigned)min(gd.y + lane, lastE)];
+        X.key = (lane < gd.w * __popc(gd.z)) ? r.x : -1;
         X.u = __int_as_float(r.y); X.v = __int_as_float(r.z); X.w = __int_as_float(r.w);
-        X.rq = Hq[min((unsigned)p0 * BA_REC + (unsigned)min(lane, BA_CP * BA_REC - 1), (unsigned)d.npt * BA_REC - 1u)];
-        range(X, c + pf);
+        const unsigned qb = (unsigned)gd.x * BA_REC + (unsigned)lane;
+        X.r0 = Hq[min(qb, lastQ)];
+        X.r1 = Hq[min(qb + 64u, lastQ)];
+        X.r2 = Hq[min(qb + 128u, lastQ)];
+        X.r3 = Hq[min(qb + 192u, lastQ)];
+        X.cur = gd;
+        range(X, g + pf);
     };
-    const int kofs = lane >> 4, l15 = lane & 15;
-    double rhs = 0; /* lane = row: this wave's part of sum_l Z (U^T bl) */
-    auto chunk = [&](BaPre& X, int c) {
-        const int p0 = c * BA_CP, np1 = min(p0 + BA_CP, d.npt) - p0;
-        Hi[min(lane, BA_CP * BA_REC)] = X.rq; /* lanes past the records write the sink behind them */
-        double blp[BA_CP * 3]; /* U^T bl of the chunk's points, wave-uniform (scalar registers) */
-#pragma unroll
-        for (int k = 0; k < BA_CP * 3; k++) {
-            const double b = ba_readlane(X.rq, (k / 3) * BA_REC + 6 + (k % 3));
-            blp[k] = (k / 3 < np1) ? b : 0.0;
-        }
+    const int li = min(lane, 35), ei = li / 6, ej = li - 6 * ei; /* entry of a 6 x 6 block this lane accumulates */
+    auto group = [&](BaPreC& X, int g) {
+        const int mask = __builtin_amdgcn_readfirstlane(X.cur.z), npts = __builtin_amdgcn_readfirstlane(X.cur.w);
+        const int k = __popc(mask), ld = ba_ctab.ld[k];
+        Hi[lane] = X.r0;
+        Hi[64 + lane] = X.r1;
+        Hi[128 + lane] = X.r2;
+        Hi[192 + lane] = X.r3;
         ba_wave_lds_fence();
-        /* this lane's edge: linearise at the stored state, one Z block (6 x 3) into the tile */
+        /* this lane's edge: linearise at the stored state, one Z block (6 x 3) into the compact tile */
         const bool live = X.key >= 0;
-        const int pl = live ? (X.key >> 6) - p0 : 0, kf = live ? (X.key & 63) : 0;
-        const int zoff = (6 * kf) * BA_LD + 3 * pl;
+        const int pl = live ? (lane * ((65536 + k - 1) / k)) >> 16 : 0; /* lane / k, exact for lane < 64 */
+        const int slot = live ? lane - pl * k : 0, kf = live ? (X.key & 63) : 0;
         if (live) {
             const double* q = Hi + pl * BA_REC;
             const double u00 = q[0], u01 = q[1], u02 = q[2], u11 = q[3], u12 = q[4], u22 = q[5];
@@ -683,258 +888,67 @@ k_ba_schur(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ 
                 JU[3 * r + 1] = L.Jl[3 * r] * u01 + L.Jl[3 * r + 1] * u11;
                 JU[3 * r + 2] = L.Jl[3 * r] * u02 + L.Jl[3 * r + 1] * u12 + L.Jl[3 * r + 2] * u22;
             }
+            double* z = Zt + (6 * slot) * ld + 3 * pl;
 #pragma unroll
             for (int a = 0; a < 6; a++) {
                 const double p0w = L.ww * Jp[a], p1w = L.ww * Jp[6 + a];
-                double* z = Zl + zoff + a * BA_LD;
-                z[0] = p0w * JU[0] + p1w * JU[3];
-                z[1] = p0w * JU[1] + p1w * JU[4];
-                z[2] = p0w * JU[2] + p1w * JU[5];
+                z[a * ld] = p0w * JU[0] + p1w * JU[3];
+                z[a * ld + 1] = p0w * JU[1] + p1w * JU[4];
+                z[a * ld + 2] = p0w * JU[2] + p1w * JU[5];
+            }
+            if (slot == 0) { /* the rhs row: U^T bl of the point under its three columns */
+                double* zr = Zt + (6 * k) * ld + 3 * pl;
+                zr[0] = q[6]; zr[1] = q[7]; zr[2] = q[8];
             }
         }
-        ba_wave_lds_fence();
-        /* this set is free again: issue the loads of the chunk it holds next, before the MFMA phase */
-        preload(X, c + pf);
-        /* reduced right-hand side on the vector ALU: lane = row of Z, 3 * BA_CP products per chunk (as a 17th column
-         * of the block product it would cost R more MFMA tiles per k-step for one useful column) */
+        const int ncol = 3 * npts, nks = (ncol + 3) >> 2;
+        if (lane <= 6 * k) { /* columns that pad the last k-step: zero in every row that is read back */
 #pragma unroll
-        for (int k = 0; k < BA_CP * 3; k++) rhs = fma(Zl[min(lane, ROWS - 1) * BA_LD + k], blp[k], rhs); /* lanes >= ROWS: never read back */
-#pragma unroll
-        for (int kk = 0; kk < BA_CP * 3; kk += 4) {
-            double av[BA_MAXT];
-#pragma unroll
-            for (int t = 0; t < BA_MAXT; t++) av[t] = (t < R) ? Zl[(16 * t + l15) * BA_LD + kk + kofs] : 0.0;
-#pragma unroll
-            for (int r = 0; r < BA_MAXT; r++)
-#pragma unroll
-                for (int cc = 0; cc < BA_MAXT; cc++)
-                    if (r < R && cc <= r)
-                        acc[r][cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[r], av[cc], acc[r][cc], 0, 0, 0);
+            for (int c = 0; c < 3; c++)
+                if (ncol + c < 4 * nks) Zt[lane * ld + ncol + c] = 0;
         }
         ba_wave_lds_fence();
-        if (live) { /* clear what this lane wrote */
-#pragma unroll
-            for (int a = 0; a < 6; a++) {
-                double* z = Zl + zoff + a * BA_LD;
-                z[0] = z[1] = z[2] = 0;
-            }
-        }
-        ba_wave_lds_fence();
-    };
-    if (d.nChunks > 0) {
-        BaPre A, B;
-        int ch = g * 4 + wave;
-        range(A, ch);
-        range(B, ch + stride);
-        preload(A, ch);
-        preload(B, ch + stride);
-        for (; ch + stride < d.nChunks; ch += 2 * stride) {
-            chunk(A, ch);
-            chunk(B, ch + stride);
-        }
-        if (ch < d.nChunks) chunk(A, ch);
-    }
-    __syncthreads();
-    /* sum the four waves' accumulators through LDS in wave order (fixed shape), then one partial per block.
-     * C/D map of v_mfma_f64_16x16x4: col = lane & 15, row = (lane >> 4) + 4 * reg */
-    double* sum = lds; /* 16 R x 64, reuses the tile storage: every wave is past its last tile read */
-    for (int wv = 0; wv < 4; wv++) {
-        if (wave == wv) {
-#pragma unroll
-            for (int r = 0; r < BA_MAXT; r++)
-#pragma unroll
-                for (int c = 0; c < BA_MAXT; c++)
-                    if (r < R && c <= r)
-                        for (int q = 0; q < 4; q++) {
-                            const int idx = (16 * r + (lane >> 4) + 4 * q) * 64 + 16 * c + (lane & 15);
-                            sum[idx] = (wv == 0) ? acc[r][c][q] : sum[idx] + acc[r][c][q];
-                        }
-            ba_wave_lds_fence();
-            /* column np = reduced rhs (k_ba_solve reads it there); it may lie inside a diagonal tile, whose entries
-             * in that column are products with an all-zero row of Z: overwritten / added on top */
-            if (lane < d.np) sum[lane * 64 + d.np] = (wv == 0) ? rhs : sum[lane * 64 + d.np] + rhs;
-        }
-        __syncthreads();
-    }
-    double* out = D + d.oPartS + (size_t)g * 64 * 64;
-    for (int i = tid; i < 64 * 64; i += BA_T) {
-        const int r = i >> 6, c = i & 63, rt = r >> 4, ct = c >> 4;
-        if (rt < R && (ct <= rt || (c == d.np && r < d.np))) out[i] = sum[i];
-    }
-}
-
-/* ---- D, grouped form (round 2). The chunk kernel above spends as long in its FP64 VECTOR phase as in its MFMA phase:
- * the two run on the same units and add up (18 MFMAs x 64 clocks + ~1500 clocks of linearisation per 4-point chunk and
- * SIMD: 212 k chunks x 2650 clocks / 1024 SIMDs = the measured 229 us per 170-window launch), and the vector phase runs on
- * the ~16 live lanes (one per free-keyframe edge) of 64. Here a wavefront takes a GROUP of whole points with up to 64
- * free-keyframe edges (k_ba_setup's greedy table: at most BA_GP points): ONE linearisation pass fills a 48-row tile of
- * 3 BA_GP columns, then the k-steps of the MFMA phase walk its columns. BA_GP = 14 (~46 live lanes, 75 KB of LDS per
- * workgroup) is the fastest alone -- 6.3 ms per 512 windows against 7.3 for the chunk kernel -- but the SLOWEST inside the
- * pipeline (24.0 ms per step against 23.7): two such workgroups fill a CU's LDS and the extractor's kernels on the other
- * streams cannot co-reside. BA_GP = 8 (~26 live lanes, 45 KB) is 6.7 ms alone and the fastest in the step (23.2 ms);
- * 6 / 10 / 12 measured 24.0 / 23.3 / 23.4. Records are prefetched one group ahead per
- * register set (an edge record and three point-record doubles per lane); the point records go through LDS, where the
- * edges of a point and the rhs pass (lane = row, U^T bl as LDS broadcasts) read them. */
-#define BA_GLD ((((3 * BA_GP + 3) / 4) * 4) | 1)   /* tile row stride in doubles: 3 BA_GP columns, padded to whole k-steps, + 1 (odd) */
-#define BA_GHI (BA_GP * BA_REC)         /* 168 doubles of point records */
-#define BA_GWAVE_LDS_R(R) (16 * (R) * BA_GLD + 192 + 4)
-struct BaPreG {
-    int key;          /* lane < edges of the group: pt << 6 | free keyframe index, else -1 */
-    float u, v, w;
-    double r0, r1, r2;/* doubles lane, 64 + lane, 128 + lane of the group's point records */
-    int cp0, cnp;     /* the group whose records the set holds: first point, number of points */
-    int p0, p1, e0, e1; /* the group this set fetches NEXT: points [p0, p1), compact edges [e0, e1) */
-};
-
-#ifdef BA_TIMING   /* debug build: shader clocks of the grouped Schur kernel's phases (wavefront 0 of every block) */
-__device__ unsigned long long ba_times[16];
-extern "C" int tb_debug_ba_times(unsigned long long* out, int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ba_times), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(ba_times), z, sizeof z); }
-    return 0;
-}
-#define BA_TK(i) do { const unsigned long long t1_ = __builtin_readcyclecounter(); tk_[i] += t1_ - t0_; t0_ = t1_; } while (0)
-#else
-#define BA_TK(i) do { } while (0)
-#endif
-
-template <int R>
-__global__ void __launch_bounds__(BA_T, 2)
-k_ba_schur_g(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw, const int* __restrict__ iw,
-             BaState* __restrict__ states) {
-    extern __shared__ __attribute__((aligned(16))) double lds[];
-    __shared__ double sRtf[10 * 12];
-    const int w = blockIdx.y, g0 = blockIdx.x, tid = threadIdx.x;
-    const BaState st = states[w];
-    if (st.status) return;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    constexpr int ROWS = 16 * R, WAVE_LDS = BA_GWAVE_LDS_R(R);
-    double* Zl = lds + (size_t)wave * WAVE_LDS;    /* [ROWS][BA_GLD] */
-    double* Hi = Zl + ROWS * BA_GLD;               /* [BA_GP][BA_REC], then a sink */
-    double* D = dw + (size_t)w * d.wstride;
-    const int* I = iw + (size_t)w * d.istride;
-    for (int k = tid; k < d.nfree; k += BA_T) ba_pose_to_Rt(D + d.oT + ((size_t)st.cur * d.nkf + d.nfixed + k) * 7, sRtf + k * 12);
-    ba_d4 acc[BA_MAXT][BA_MAXT];
-#pragma unroll
-    for (int r = 0; r < BA_MAXT; r++)
-#pragma unroll
-        for (int c = 0; c < BA_MAXT; c++) acc[r][c] = (ba_d4){0, 0, 0, 0};
-    for (int i = lane; i < ROWS * BA_GLD; i += 64) Zl[i] = 0;
-    __syncthreads();
-    const double delta = (double)sqrtf(5.991f);
-    const int ng = I[d.oGrp + d.npt + 1];
-    const int stride = d.G * 4, pf = 2 * stride;
-    const int lastG = ng - 1, lastE = d.obs_pitch - 1;
-    const double* Hq = D + d.oHq;
-    const int4* KP = reinterpret_cast<const int4*>(I + d.oFreeKP);
-    const unsigned lastQ = (unsigned)d.npt * BA_REC - 1u;
-    auto range = [&](BaPreG& X, int g) {
-        const int gc = min(g, lastG);
-        X.p0 = I[d.oGrp + gc];
-        X.p1 = (g <= lastG) ? I[d.oGrp + gc + 1] : X.p0;      /* past the end: an empty group */
-        X.e0 = I[d.oPtFree + X.p0];
-        X.e1 = I[d.oPtFree + X.p1];
-    };
-    auto preload = [&](BaPreG& X, int g) {   /* X.p0.. = range of group g (fetched one fill earlier); then the range of g + pf */
-        const int4 r = KP[(unsigned)min(X.e0 + lane, lastE)];
-        X.key = (lane < X.e1 - X.e0) ? r.x : -1;
-        X.u = __int_as_float(r.y); X.v = __int_as_float(r.z); X.w = __int_as_float(r.w);
-        const unsigned qb = (unsigned)X.p0 * BA_REC + (unsigned)lane;
-        X.r0 = Hq[min(qb, lastQ)];
-        X.r1 = Hq[min(qb + 64u, lastQ)];
-        X.r2 = (BA_GP * BA_REC > 128) ? Hq[min(qb + 128u, lastQ)] : 0.0;
-        X.cp0 = X.p0;
-        X.cnp = X.p1 - X.p0;
-        range(X, g + pf);
-    };
-    const int kofs = lane >> 4, l15 = lane & 15;
-    double rhs = 0;
-#ifdef BA_TIMING
-    unsigned long long tk_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, t0_ = __builtin_readcyclecounter();
-#endif
-    auto group = [&](BaPreG& X, int g) {
-        const int p0 = X.cp0, npts = X.cnp;
-        BA_TK(5);
-        Hi[lane] = X.r0;
-        Hi[64 + lane] = X.r1;
-        if (BA_GP * BA_REC > 128) Hi[128 + lane] = X.r2;   /* the records end at BA_GP * BA_REC; the rest is spare */
-        ba_wave_lds_fence();
-        const bool live = X.key >= 0;
-        const int pl = live ? (X.key >> 6) - p0 : 0, kf = live ? (X.key & 63) : 0;
-        const int zoff = (6 * kf) * BA_GLD + 3 * pl;
-        if (live) {
-            const double* q = Hi + pl * BA_REC;
-            const double u00 = q[0], u01 = q[1], u02 = q[2], u11 = q[3], u12 = q[4], u22 = q[5];
-            const double Xp[3] = {q[9], q[10], q[11]};
-            BaLin L;
-            double Jp[12];
-            ba_linearize(sRtf + kf * 12, Xp, X.u, X.v, X.w, d.fx, d.fy, d.cx, d.cy, delta, L);
-            ba_jac_pose_iz(L.pc, L.invz, d.fx, d.fy, Jp);
-            double JU[6];
-#pragma unroll
-            for (int r = 0; r < 2; r++) {
-                JU[3 * r] = L.Jl[3 * r] * u00;
-                JU[3 * r + 1] = L.Jl[3 * r] * u01 + L.Jl[3 * r + 1] * u11;
-                JU[3 * r + 2] = L.Jl[3 * r] * u02 + L.Jl[3 * r + 1] * u12 + L.Jl[3 * r + 2] * u22;
-            }
-#pragma unroll
-            for (int a = 0; a < 6; a++) {
-                const double p0w = L.ww * Jp[a], p1w = L.ww * Jp[6 + a];
-                double* z = Zl + zoff + a * BA_GLD;
-                z[0] = p0w * JU[0] + p1w * JU[3];
-                z[1] = p0w * JU[1] + p1w * JU[4];
-                z[2] = p0w * JU[2] + p1w * JU[5];
-            }
-        }
-        ba_wave_lds_fence();
-        BA_TK(0);
-        /* the set is free: the range of its next group came in one fill ago -- issue that group's loads now */
+        /* this set is free again: issue the loads of the group it holds next, before the MFMA phase */
         preload(X, g + pf);
-        BA_TK(1);
-        /* reduced right-hand side: lane = row of Z, U^T bl of the group's points as LDS broadcasts (measured: unrolling this
-         * loop -- four points per step, or all 14 -- costs registers and time; the FP64 pipe is shared with the MFMAs of the
-         * SIMD's other wavefront either way) */
-        {
-            const double* zr = Zl + min(lane, ROWS - 1) * BA_GLD;
-            for (int pnt = 0; pnt < npts; pnt++) {
-                const double* b = Hi + pnt * BA_REC + 6;
-                rhs = fma(zr[3 * pnt], b[0], rhs);
-                rhs = fma(zr[3 * pnt + 1], b[1], rhs);
-                rhs = fma(zr[3 * pnt + 2], b[2], rhs);
+        switch (k) {
+            case 1: ba_c_product<1>(Zt, Zt, nks, lane); break;
+            case 2: ba_c_product<2>(Zt, Zt, nks, lane); break;
+            case 3: if constexpr (NF >= 3) ba_c_product<3>(Zt, Zt, nks, lane); break;
+            case 4: if constexpr (NF >= 4) ba_c_product<4>(Zt, Zt, nks, lane); break;
+            case 5: if constexpr (NF >= 5) ba_c_product<5>(Zt, Zt, nks, lane); break;
+            case 6: if constexpr (NF >= 6) ba_c_product<6>(Zt, Zt, nks, lane); break;
+            case 7: if constexpr (NF >= 7) ba_c_product<7>(Zt, Zt, nks, lane); break;
+            case 8: if constexpr (NF >= 8) ba_c_product<8>(Zt, Zt, nks, lane); break;
+            case 9: if constexpr (NF >= 9) ba_c_product<9>(Zt, Zt, nks, lane); break;
+            case 10: if constexpr (NF >= 10) ba_c_product<10>(Zt, Zt, nks, lane); break;
+            default: break;
+        }
+        /* compact result -> dense accumulators: block pair (a >= b) of the pattern sits at rows 6 slot(a).., columns
+         * 6 slot(b).. of the compact triangle; a diagonal pair reads its upper half from the mirrored entry */
+#pragma unroll
+        for (int a = 0; a < NF; a++) {
+            if (!((mask >> a) & 1)) continue;
+            const int sa = __popc(mask & ((1 << a) - 1));
+#pragma unroll
+            for (int b = 0; b <= a; b++) {
+                if (!((mask >> b) & 1)) continue;
+                const int sb = __popc(mask & ((1 << b) - 1));
+                int row = 6 * sa + ei, col = 6 * sb + ej;
+                if (a == b && col > row) { const int t = row; row = col; col = t; }
+                const int rb = row >> 2, cb = col >> 2;
+                S[a * (a + 1) / 2 + b] += Zt[16 * (rb * (rb + 1) / 2 + cb) + 4 * (row & 3) + (col & 3)];
             }
         }
-        BA_TK(2);
-        /* k-steps over the tile's columns (a hand-pipelined form -- operand rows of step ks + 1 read during the MFMAs of
-         * step ks -- measured 4 % slower) */
-        const int nks = (3 * npts + 3) >> 2;
-        for (int ks = 0; ks < nks; ks++) {
-            double av[BA_MAXT];
-#pragma unroll
-            for (int t = 0; t < BA_MAXT; t++) av[t] = (t < R) ? Zl[(16 * t + l15) * BA_GLD + 4 * ks + kofs] : 0.0;
-#pragma unroll
-            for (int r = 0; r < BA_MAXT; r++)
-#pragma unroll
-                for (int cc = 0; cc < BA_MAXT; cc++)
-                    if (r < R && cc <= r)
-                        acc[r][cc] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[r], av[cc], acc[r][cc], 0, 0, 0);
-        }
-        BA_TK(3);
-        ba_wave_lds_fence();
-        if (live) {
-#pragma unroll
-            for (int a = 0; a < 6; a++) {
-                double* z = Zl + zoff + a * BA_GLD;
-                z[0] = z[1] = z[2] = 0;
-            }
+        {   /* rhs: row 6 k of the compact triangle, scattered to the dense rows of the pattern's keyframes */
+            const int a = min(lane / 6, NF - 1), i6 = lane - 6 * (lane / 6);
+            const int col = 6 * __popc(mask & ((1 << a) - 1)) + i6, row = 6 * k;
+            const int rb = row >> 2, cb = col >> 2;
+            if (lane < 6 * NF && ((mask >> a) & 1)) rhs += Zt[16 * (rb * (rb + 1) / 2 + cb) + 4 * (row & 3) + (col & 3)];
         }
         ba_wave_lds_fence();
-        BA_TK(4);
-#ifdef BA_TIMING
-        tk_[6] += 1; tk_[7] += (unsigned long long)npts;
-#endif
     };
     if (ng > 0) {
-        BaPreG A, B;
+        BaPreC A, B;
         int g = g0 * 4 + wave;
         range(A, g);
         range(B, g + stride);
@@ -946,22 +960,21 @@ k_ba_schur_g(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict_
         }
         if (g < ng) group(A, g);
     }
-#ifdef BA_TIMING
-    if (tid == 0 && (w & 15) == 0) for (int i = 0; i < 8; i++) atomicAdd(&ba_times[i], tk_[i]);
-#endif
     __syncthreads();
-    double* sum = lds;
+    /* sum the four waves' accumulators through LDS in wave order (fixed shape), then one partial per block in the
+     * 64 x 64 layout k_ba_solve reads: lower triangle at [row][col], reduced rhs in column np */
+    double* sum = lds; /* reuses the tile storage: every wave is past its last tile read */
     for (int wv = 0; wv < 4; wv++) {
         if (wave == wv) {
+            if (lane < 36) {
 #pragma unroll
-            for (int r = 0; r < BA_MAXT; r++)
+                for (int a = 0; a < NF; a++)
 #pragma unroll
-                for (int c = 0; c < BA_MAXT; c++)
-                    if (r < R && c <= r)
-                        for (int q = 0; q < 4; q++) {
-                            const int idx = (16 * r + (lane >> 4) + 4 * q) * 64 + 16 * c + (lane & 15);
-                            sum[idx] = (wv == 0) ? acc[r][c][q] : sum[idx] + acc[r][c][q];
-                        }
+                    for (int b = 0; b <= a; b++) {
+                        const int idx = (6 * a + ei) * 64 + 6 * b + ej;
+                        sum[idx] = (wv == 0) ? S[a * (a + 1) / 2 + b] : sum[idx] + S[a * (a + 1) / 2 + b];
+                    }
+            }
             ba_wave_lds_fence();
             if (lane < d.np) sum[lane * 64 + d.np] = (wv == 0) ? rhs : sum[lane * 64 + d.np] + rhs;
         }
@@ -969,8 +982,8 @@ k_ba_schur_g(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict_
     }
     double* out = D + d.oPartS + (size_t)g0 * 64 * 64;
     for (int i = tid; i < 64 * 64; i += BA_T) {
-        const int r = i >> 6, c = i & 63, rt = r >> 4, ct = c >> 4;
-        if (rt < R && (ct <= rt || (c == d.np && r < d.np))) out[i] = sum[i];
+        const int r = i >> 6, c = i & 63;
+        if (r < d.np && (c <= r || c == d.np)) out[i] = sum[i];
     }
 }
 
@@ -1478,7 +1491,7 @@ k_ba_update(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
         const int eBeg = I[d.oPtStart + p], eEnd = I[d.oPtStart + p + 1];
         if (st.ok2) {
             /* the point record of this trial: A^-1 = U U^T (all zero for a singular block: xl stays 0) */
-            const double* q = D + d.oHq + (size_t)p * 12;
+            const double* q = D + d.oHq + (size_t)I[d.oPtRank + p] * 12;
             const double u00 = q[0], u01 = q[1], u02 = q[2], u11 = q[3], u12 = q[4], u22 = q[5];
             /* r = bl - sum_k Hpl_k^T x_k with Hpl_k = ww Jp^T Jl rebuilt from the observation (a 144-byte block per edge
              * would cost more to fetch than its ~150 flops): Hpl^T x = ww Jl^T (Jp x) */
@@ -1598,9 +1611,12 @@ static void ba_dims(BaDims& d, int W, const double K[4], int nkf, int nfixed, in
     d.iters = iters;
     d.nblkP = (npt + BA_T - 1) / BA_T;
     d.kfChunks = (obs_pitch + BA_KFCH - 1) / BA_KFCH;
-    d.nChunks = (npt + BA_CP - 1) / BA_CP;
-    d.G = std::min(std::max(1024 / std::max(W, 1), 1), std::max((d.nChunks + 3) / 4, 1)); /* up to 4 resident Schur blocks per CU */
-    d.big = d.nfree > 10;
+    d.nChunks = 0;
+    /* Schur workgroups per window: up to 4 resident per CU over the batch, no more than one per ~64 points (a group holds
+     * ~13), and at most 32 -- k_ba_solve adds the workgroups' partial systems in order */
+    d.G = std::min(std::min(std::max(1024 / std::max(W, 1), 1), 32), std::max((npt / 16 + 3) / 4, 1));
+    d.big = d.nfree > BA_SMALL_MAXF;
+    d.schurWaveLds = d.big ? 0 : ba_c_wave_lds(d.nfree);
     d.npairs = d.nfree * (d.nfree + 1) / 2;
     d.maxItems = (unsigned long long)obs_pitch * (d.nfree + 1) / 2 + 1; /* sum_p E_p (E_p + 1) / 2 with E_p <= nfree */
     d.fx = K[0]; d.fy = K[1]; d.cx = K[2]; d.cy = K[3];
@@ -1627,8 +1643,12 @@ static void ba_dims(BaDims& d, int W, const double K[4], int nkf, int nfixed, in
     d.oKfEdges = itake(obs_pitch);
     d.oFreeKP = itake(4ull * obs_pitch);
     d.oKfRec = itake(4ull * obs_pitch);
-    d.grouped = (!d.big && npt <= BA_GRP_MAXPT) ? 1 : 0;
-    d.oGrp = itake(d.grouped ? (unsigned long long)npt + 2 : 0);
+    d.oPtRank = itake(npt);
+    d.oPtMask = itake(d.big ? 0 : npt);
+    d.oPermA = itake(d.big ? 0 : npt);
+    d.oPermB = itake(d.big ? 0 : npt);
+    d.oKPs = itake(d.big ? 0 : 4ull * obs_pitch);
+    d.oGDesc = itake(d.big ? 0 : 4ull * npt + 4);
     d.oPairStart = itake(d.big ? d.npairs + 1 : 0);
     d.oPairCnt = itake(d.big ? d.npairs : 0);
     d.oPairItems = itake(d.big ? 2 * d.maxItems : 0);
@@ -1651,7 +1671,7 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
         return tb_fail(ctx, TB_EUNSUPPORTED, "local BA: %d free keyframes (this build supports 1..64)", nfree);
     if (nkf > TB_MAX_LEVELS * 8) return tb_fail(ctx, TB_EUNSUPPORTED, "local BA: too many keyframes");
     if (npt > (1 << 25)) return tb_fail(ctx, TB_EUNSUPPORTED, "local BA: more than 2^25 points per window");
-    if (nfree > 10 && (unsigned long long)obs_pitch * (nfree + 1) >= (1ull << 31))
+    if (nfree > BA_SMALL_MAXF && (unsigned long long)obs_pitch * (nfree + 1) >= (1ull << 31))
         return tb_fail(ctx, TB_EUNSUPPORTED, "local BA: large window with more than 2^31 / (free keyframes + 1) observations");
     if (iters > 99) return tb_fail(ctx, TB_EUNSUPPORTED, "local BA: more than 99 LM iterations (one still-running counter per trial, 1000 of them)");
     BaDims d;
@@ -1663,8 +1683,8 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
     BaState* states = (BaState*)((char*)iw + (size_t)W * d.istride * sizeof(int));
     int* running = (int*)((char*)states + (size_t)W * sizeof(BaState));
     hipStream_t s = ctx->stream;
-    const int Rt = (d.np + 15) >> 4;
-    const size_t lds = std::max<size_t>(4 * (size_t)BA_WAVE_LDS_R(Rt), (size_t)16 * Rt * 64) * sizeof(double);
+    /* Schur kernel: four wavefronts' tiles, reused for the 64 x 64 sum of their accumulators */
+    const size_t schur_lds = std::max<size_t>(4 * (size_t)d.schurWaveLds, 64 * 64) * sizeof(double);
     /* behind the states: one still-running counter per round (no memset node between the rounds), then one
      * rejected-input flag per window; zeroed together before the setup kernel */
     const int ring = 1000;
@@ -1675,6 +1695,15 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
     tb_prof_end(ctx);
     TB_HIP(ctx, hipGetLastError());
     const size_t big_lds = (size_t)(d.np + 1) * BA_PLD * sizeof(double);
+    if (!d.big) {
+        const int R = (d.np + 15) >> 4;
+        const void* ks = R == 1 ? (const void*)k_ba_schur_c<1> : R == 2 ? (const void*)k_ba_schur_c<2> : R == 3 ? (const void*)k_ba_schur_c<3> : (const void*)k_ba_schur_c<4>;
+        TB_HIP(ctx, hipFuncSetAttribute(ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_lds));
+        tb_prof_begin(ctx, "k_ba_groups");
+        hipLaunchKernelGGL(k_ba_groups, dim3(W), dim3(BA_T), 0, s, d, iw, errflag);
+        tb_prof_end(ctx);
+        TB_HIP(ctx, hipGetLastError());
+    }
     if (d.big) {
         /* block-pair item lists of the large-window Schur kernel: count, scan, fill */
         TB_HIP(ctx, hipFuncSetAttribute((const void*)k_ba_solve_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
@@ -1700,7 +1729,7 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
             hipLaunchKernelGGL(k_ba_reduce, dim3(W), dim3(BA_T), 0, s, d, dw, iw, states);
             tb_prof_end(ctx);
             tb_prof_begin(ctx, "k_ba_hinv");
-            hipLaunchKernelGGL(k_ba_hinv, dim3(d.nblkP, W), dim3(BA_T), 0, s, d, dw, states);
+            hipLaunchKernelGGL(k_ba_hinv, dim3(d.nblkP, W), dim3(BA_T), 0, s, d, dw, iw, states);
             tb_prof_end(ctx);
             if (d.big) {
                 tb_prof_begin(ctx, "k_ba_schur_pairs");
@@ -1713,16 +1742,9 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
             tb_prof_begin(ctx, "k_ba_schur");
             {
                 const int R = (d.np + 15) >> 4;
-                typedef void (*schur_t)(BaDims, const tb_ba_obs*, double*, const int*, BaState*);
-                /* whole-point groups of up to 64 edges (k_ba_schur_g) wherever the setup built the group table;
-                 * TB_BA_SCHUR=chunk keeps the 4-point chunk kernel (A/B measurements) */
-                const char* sel = getenv("TB_BA_SCHUR");
-                const bool grouped = d.grouped && !(sel && sel[0] == 'c');
-                const schur_t ks = grouped ? (R == 1 ? (schur_t)k_ba_schur_g<1> : R == 2 ? (schur_t)k_ba_schur_g<2> : R == 3 ? (schur_t)k_ba_schur_g<3> : (schur_t)k_ba_schur_g<4>)
-                                           : (R == 1 ? (schur_t)k_ba_schur<1> : R == 2 ? (schur_t)k_ba_schur<2> : R == 3 ? (schur_t)k_ba_schur<3> : (schur_t)k_ba_schur<4>);
-                const size_t lds_k = grouped ? std::max<size_t>(4 * (size_t)BA_GWAVE_LDS_R(R), (size_t)16 * R * 64) * sizeof(double) : lds;
-                TB_HIP(ctx, hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_k));
-                hipLaunchKernelGGL(ks, dim3(d.G, W), dim3(BA_T), lds_k, s, d, d_obs, dw, iw, states);
+                typedef void (*schur_t)(BaDims, double*, const int*, BaState*);
+                const schur_t ks = R == 1 ? (schur_t)k_ba_schur_c<1> : R == 2 ? (schur_t)k_ba_schur_c<2> : R == 3 ? (schur_t)k_ba_schur_c<3> : (schur_t)k_ba_schur_c<4>;
+                hipLaunchKernelGGL(ks, dim3(d.G, W), dim3(BA_T), schur_lds, s, d, dw, iw, states);
             }
             tb_prof_end(ctx);
             tb_prof_begin(ctx, "k_ba_solve");

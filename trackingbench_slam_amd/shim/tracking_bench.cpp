@@ -15,6 +15,8 @@
 #include "mapping/LocalBA.h"
 #include "matchers/matcher.h"
 #include "types/Frame.h"
+#include "types/Map.h"
+#include "types/MapPoint.h"
 
 namespace TRACKING_BENCH
 {
@@ -96,6 +98,31 @@ namespace TRACKING_BENCH
         for (auto& pt : pts) mvKeys.emplace_back(std::make_shared<Feature>(pt, (int)mvKeys.size()));
         mvpMapPoints.assign(pts.size(), nullptr);
         mvbOutlier.assign(pts.size(), false);
+    }
+
+    /* ------------------------------------------------------------------ MapPoint */
+    /* reference MapPoint.cpp:13-44: position, unit viewing direction from the reference frame's camera centre, the
+     * scale-invariance distances, the reference feature's descriptor row when the frame holds descriptors (it replaces the
+     * `des` argument, MapPoint.cpp:36-37), the id under the map's creation mutex; the reference then drops its frame handle
+     * (mpRefKF = nullptr, :42). Element-wise arithmetic: the same source builds against Eigen and the stand-in types. */
+    MapPoint::MapPoint(const Eigen::Vector3f &Pos, std::shared_ptr<Map>& pMap, std::shared_ptr<Frame>& pFrame,
+                       std::shared_ptr<Feature>& features, cv::Mat des)
+        : mWorldPos(Pos), mpRefFeature(features), mDescriptor(std::move(des)), mpMap(pMap)
+    {
+        mFeatures.emplace_back(mpRefFeature);
+        const Eigen::Vector3f Ow = pFrame->GetCameraCenter();
+        float d[3], n2 = 0;
+        for (int i = 0; i < 3; i++) { d[i] = mWorldPos[i] - Ow[i]; n2 += d[i] * d[i]; }
+        const float dist = std::sqrt(n2);
+        for (int i = 0; i < 3; i++) mNormalVector[i] = d[i] / dist;
+        const int level = mpRefFeature->kp.octave;
+        const std::vector<float> sf = pFrame->GetScaleFactors();
+        mfMaxDistance = dist * sf.at(level);
+        mfMinDistance = mfMaxDistance / sf.at(pFrame->GetLevels() - 1);
+        if (!pFrame->GetDescriptors().empty()) mDescriptor = pFrame->GetDescriptors().row(mpRefFeature->idxF).clone();
+        static long unsigned int nNextId = 0;
+        if (pMap) { std::unique_lock<std::mutex> lock(pMap->mMutexPointCreation); mnId = nNextId++; }
+        else mnId = nNextId++;
     }
 
     /* ------------------------------------------------------------------ extractors */
