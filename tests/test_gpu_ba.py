@@ -58,11 +58,15 @@ def test_local_ba_vs_cpu_solver(ctx, seed, nkf, npt, nfixed, iters):
 
 @pytest.mark.parametrize("seed,nkf,npt,nfixed,per_pt", [(11, 10, 600, 2, 10),  # every keyframe sees every point
                                                          (12, 6, 300, 1, 6), (13, 4, 120, 1, 4), (14, 3, 90, 2, 3),
-                                                         (15, 12, 150, 2, 12), (16, 10, 203, 0, 2)])
+                                                         (15, 12, 150, 2, 12), (16, 10, 203, 0, 2),
+                                                         (17, 5, 3000, 1, 2),     # few patterns, hundreds of points each: full groups
+                                                         (18, 10, 2500, 2, 7),    # patterns of 1..7 keyframes: both product paths
+                                                         (19, 9, 900, 1, 9), (20, 8, 64, 1, 6), (21, 2, 500, 1, 2)])
 def test_local_ba_chunk_capacities(ctx, seed, nkf, npt, nfixed, per_pt):
-    """The Schur kernel maps one free-keyframe edge of a 4-point chunk to one lane (at most 4 nfree <= 40) and has one
-    tile set per R = ceil(6 nfree / 16): sparse to fully dense windows with 1..10 free keyframes walk through every
-    instance."""
+    """The Schur kernel sorts a window's points by visibility pattern and works on groups of one pattern (one lane per
+    free-keyframe edge, up to 64): patterns of up to five keyframes run the compact v_mfma_f64_4x4x4 product, larger ones the
+    direct vector form, and the kernel has one instance per R = ceil(6 nfree / 16). Sparse to fully dense windows with
+    1..10 free keyframes walk through every instance, every pattern size and both group limits (points, edges)."""
     Pt, Pi, Xt, Xi, obs = synth.ba_problem(seed, nkf, npt, K, obs_per_pt=per_pt)
     io, Po, Xo, so = oracle.local_ba(K, Pi, nfixed, Xi, obs, 6)
     ig, Pg, Xg, sg = ctx.local_ba(K, Pi, nfixed, Xi, obs, 6)

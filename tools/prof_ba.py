@@ -34,8 +34,11 @@ if hasattr(capi.lib(), "tb_debug_ba_times"):
     ba.run(); torch.cuda.synchronize()
     capi.lib().tb_debug_ba_times(buf, 1)
     ngr = max(buf[6], 1)
-    names = ["stage + linearise", "preload issue", "rhs", "mfma", "clear", "between groups"]
-    tot = sum(buf[i] for i in range(6))
-    for i, nm in enumerate(names):
+    names = {0: "stage + linearise", 1: "preload issue", 2: "block product", 3: "compact -> dense", 5: "between groups"}
+    tot = sum(buf[i] for i in names)
+    for i, nm in names.items():
         print("  %-18s %8.0f clk/group  %5.1f%%" % (nm, buf[i] / ngr, 100.0 * buf[i] / max(tot, 1)))
     print("  groups sampled %d, points per group %.2f" % (ngr, buf[7] / ngr))
+    nwg = max(buf[10], 1)
+    print("  per sampled wavefront: prologue %.0f clk, first loads + loop tail %.0f, epilogue %.0f, groups %.1f (%.0f clk)" % (
+        buf[4] / nwg, buf[8] / nwg, buf[9] / nwg, ngr / nwg, tot / nwg))

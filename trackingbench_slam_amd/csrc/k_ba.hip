@@ -52,7 +52,8 @@ struct BaState {
 
 struct BaDims {
     int W, nkf, nfixed, nfree, np, npt, obs_pitch, iters;
-    int nblkP, kfChunks, G, nChunks;
+    int nblkP, kfChunks, G, nChunks; /* G: most Schur workgroups a window has */
+    int Gbase, Gextra;               /* window w has Gbase + (w < Gextra) of them: Schur workgroups over the batch = one resident round */
     int big, npairs;             /* more than 10 free keyframes: the block-pair Schur / panel solve kernels */
     unsigned long long oBigA;    /* large windows: the reduced system [np + 1][np] (row np = rhs) */
     unsigned long long oPairStart, oPairCnt, oPairItems, maxItems; /* ints: block-pair item lists */
@@ -66,6 +67,8 @@ struct BaDims {
      * sort, rank of every point in pattern order (its record's slot in Hq; identity for large windows), the free-keyframe
      * edge records in pattern order (4 ints each), the group descriptors (int4 each, count at [4 npt]) */
     unsigned long long oPtMask, oPermA, oPermB, oPtRank, oKPs, oGDesc;
+    unsigned long long oGCost;   /* ints: cost estimate of the groups before group g (exclusive prefix, total at [ng]) */
+    unsigned long long oGCut;    /* ints: first group of Schur wavefront v of the window (4 G + 1 entries) */
     int schurWaveLds, pad1;      /* doubles of LDS per Schur wavefront (host: ba_c_wave_lds(nfree)) */
 };
 
@@ -81,17 +84,27 @@ __device__ __forceinline__ double ba_huber_rho0(double c, double delta) {
  * ww Jp^T Jl: the blocks are never stored, the point pass, the Schur kernel and the back-substitution each rebuild
  * what they need from the 20-byte observation, and must agree bit for bit. */
 struct BaLin { double ww, e0, e1, c2, invz; double pc[3]; double Jl[6]; };
-/* residual and Huber-weighted information of one observation; one reciprocal per edge (an FP64 division is ~12
- * instructions around a quarter-rate v_rcp_f64, and these run on the same FP64 units as the MFMAs) */
+/* The helpers below spell out their fused multiply-adds (the library builds with -ffp-contract=off for the
+ * reference-facing float paths; here every product-sum is an explicit fma, ~140 FP64 instructions per edge instead of
+ * ~215 separate multiplies and adds -- they run on the same FP64 units as the MFMAs) and use ONE reciprocal per edge:
+ * v_rcp_f64 refined by two Newton steps (relative error ~1e-16; the IEEE division sequence is a dozen instructions
+ * around the same quarter-rate v_rcp_f64). Every kernel calls the same helpers, so they agree bit for bit. */
+__device__ __forceinline__ double ba_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+/* residual and Huber-weighted information of one observation */
 __device__ __forceinline__ void ba_residual(const double* Rt, const double* X, float u, float v, float inv_sigma2, double fx,
                                             double fy, double cx, double cy, double delta, BaLin& L) {
 #pragma unroll
-    for (int i = 0; i < 3; i++) L.pc[i] = ((Rt[3 * i] * X[0] + Rt[3 * i + 1] * X[1]) + Rt[3 * i + 2] * X[2]) + Rt[9 + i];
-    L.invz = 1.0 / L.pc[2];
-    L.e0 = (double)u - (L.pc[0] * L.invz * fx + cx);
-    L.e1 = (double)v - (L.pc[1] * L.invz * fy + cy);
+    for (int i = 0; i < 3; i++) L.pc[i] = fma(Rt[3 * i + 2], X[2], fma(Rt[3 * i + 1], X[1], fma(Rt[3 * i], X[0], Rt[9 + i])));
+    L.invz = ba_rcp(L.pc[2]);
+    L.e0 = (double)u - fma(L.pc[0] * L.invz, fx, cx);
+    L.e1 = (double)v - fma(L.pc[1] * L.invz, fy, cy);
     const double wgt = (double)inv_sigma2;
-    L.c2 = L.e0 * (wgt * L.e0) + L.e1 * (wgt * L.e1);
+    L.c2 = fma(L.e0, wgt * L.e0, L.e1 * (wgt * L.e1));
     const double r1 = (L.c2 <= delta * delta) ? 1.0 : delta / sqrt(L.c2);
     L.ww = r1 * wgt;
 }
@@ -101,8 +114,8 @@ __device__ __forceinline__ void ba_linearize(const double* Rt, const double* X, 
     const double ax = -(L.pc[0] * L.invz) * fx, ay = -(L.pc[1] * L.invz) * fy, m = -L.invz;
 #pragma unroll
     for (int c = 0; c < 3; c++) { /* Jl = -1/z [fx 0 -x/z fx; 0 fy -y/z fy] R */
-        L.Jl[c] = m * (fx * Rt[c] + ax * Rt[6 + c]);
-        L.Jl[3 + c] = m * (fy * Rt[3 + c] + ay * Rt[6 + c]);
+        L.Jl[c] = m * fma(ax, Rt[6 + c], fx * Rt[c]);
+        L.Jl[3 + c] = m * fma(ay, Rt[6 + c], fy * Rt[3 + c]);
     }
 }
 /* keyframe pose as the passes use it: rotation matrix (row major) and translation, 12 doubles. Every kernel converts
@@ -115,11 +128,11 @@ __device__ __forceinline__ void ba_pose_to_Rt(const double* T7, double* Rt) {
 }
 /* d(projection)/d(pose increment), 2 x 6, rows at J[0..5] and J[6..11] (g2o EdgeSE3ProjectXYZ convention) */
 __device__ __forceinline__ void ba_jac_pose_iz(const double* pc, double invz, double fx, double fy, double* J) {
-    const double x = pc[0], y = pc[1], invz_2 = invz * invz;
-    J[0] = x * y * invz_2 * fx; J[1] = -(1 + (x * x * invz_2)) * fx; J[2] = y * invz * fx;
-    J[3] = -invz * fx; J[4] = 0; J[5] = x * invz_2 * fx;
-    J[6] = (1 + y * y * invz_2) * fy; J[7] = -x * y * invz_2 * fy; J[8] = -x * invz * fy;
-    J[9] = 0; J[10] = -invz * fy; J[11] = y * invz_2 * fy;
+    const double xz = pc[0] * invz, yz = pc[1] * invz, xf = xz * fx, yf = yz * fy; /* x/z, y/z, fx x/z, fy y/z */
+    J[0] = xf * yz; J[1] = -fma(xf, xz, fx); J[2] = yz * fx;
+    J[3] = -invz * fx; J[4] = 0; J[5] = xf * invz;
+    J[6] = fma(yf, yz, fy); J[7] = -(xz * yf); J[8] = -xz * fy;
+    J[9] = 0; J[10] = -invz * fy; J[11] = yf * invz;
 }
 
 __device__ __forceinline__ bool ba_inv3(const double* H6, double lambda, double* I) {
@@ -375,13 +388,13 @@ k_ba_points(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
             const double ww = L.ww, e0 = L.e0, e1 = L.e1;
             const double* Jl = L.Jl;
             chi += ba_huber_rho0(L.c2, delta);
-            for (int a = 0; a < 3; a++) bl[a] -= ww * (Jl[a] * e0 + Jl[3 + a] * e1);
-            Hll[0] += ww * (Jl[0] * Jl[0] + Jl[3] * Jl[3]);
-            Hll[1] += ww * (Jl[0] * Jl[1] + Jl[3] * Jl[4]);
-            Hll[2] += ww * (Jl[0] * Jl[2] + Jl[3] * Jl[5]);
-            Hll[3] += ww * (Jl[1] * Jl[1] + Jl[4] * Jl[4]);
-            Hll[4] += ww * (Jl[1] * Jl[2] + Jl[4] * Jl[5]);
-            Hll[5] += ww * (Jl[2] * Jl[2] + Jl[5] * Jl[5]);
+            for (int a = 0; a < 3; a++) bl[a] = fma(-ww, fma(Jl[a], e0, Jl[3 + a] * e1), bl[a]);
+            Hll[0] = fma(ww, fma(Jl[0], Jl[0], Jl[3] * Jl[3]), Hll[0]);
+            Hll[1] = fma(ww, fma(Jl[0], Jl[1], Jl[3] * Jl[4]), Hll[1]);
+            Hll[2] = fma(ww, fma(Jl[0], Jl[2], Jl[3] * Jl[5]), Hll[2]);
+            Hll[3] = fma(ww, fma(Jl[1], Jl[1], Jl[4] * Jl[4]), Hll[3]);
+            Hll[4] = fma(ww, fma(Jl[1], Jl[2], Jl[4] * Jl[5]), Hll[4]);
+            Hll[5] = fma(ww, fma(Jl[2], Jl[2], Jl[5] * Jl[5]), Hll[5]);
         }
         for (int a = 0; a < 6; a++) D[d.oHll + (size_t)p * 6 + a] = Hll[a];
         for (int a = 0; a < 3; a++) D[d.oBl + (size_t)p * 3 + a] = bl[a];
@@ -486,9 +499,13 @@ k_ba_kf(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw,
             const double ww = L.ww, e0 = L.e0, e1 = L.e1;
 #pragma unroll
             for (int a = 0; a < 6; a++) {
-                acc[21 + a] -= ww * (Jp[a] * e0 + Jp[6 + a] * e1);
+                const double wa = ww * Jp[a], wb = ww * Jp[6 + a];
+                acc[21 + a] -= fma(wa, e0, wb * e1);
 #pragma unroll
-                for (int c = a; c < 6; c++) acc[a * 6 - (a * (a - 1)) / 2 + (c - a)] += ww * (Jp[a] * Jp[c] + Jp[6 + a] * Jp[6 + c]);
+                for (int c = a; c < 6; c++) {
+                    const int at = a * 6 - (a * (a - 1)) / 2 + (c - a);
+                    acc[at] += fma(wa, Jp[c], wb * Jp[6 + c]);
+                }
             }
         }
         const double tot = ba_block_sum27(acc, red);
@@ -582,6 +599,8 @@ k_ba_hinv(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, BaState
 #define BA_MAXT 4 /* 16-row tiles per side of the dense system (np <= 60) */
 #define BA_REC 12
 #define BA_RECS_LDS 256 /* staged point records of a group: BA_PCAP * BA_REC <= 256 doubles */
+#define BA_KMFMA 5      /* patterns of up to this many keyframes run on the MFMA path */
+#define BA_ZERO_LDS 40  /* a block of zeros behind them: what the block pairs a pattern does not have read */
 /* The Schur tile is private to one wavefront and the LDS executes a wavefront's instructions in issue order, so
  * cross-lane visibility needs no counter wait: a wavefront-scope fence only pins the compiler's ordering (a
  * workgroup-scope one would also drain vmcnt, i.e. the prefetched records, on every phase change). */
@@ -593,18 +612,24 @@ __host__ __device__ constexpr int ba_c_cap(int k) { return (BA_EMAX / k) < BA_PC
 __host__ __device__ constexpr int ba_c_nb(int k) { return (6 * k + 1 + 3) / 4; }
 __host__ __device__ constexpr int ba_c_ld(int k) { return ((3 * ba_c_cap(k) + 3) / 4) * 4 + 2; }
 __host__ __device__ constexpr int ba_c_tile(int k) { return 4 * ba_c_nb(k) * ba_c_ld(k); }
-__host__ __device__ constexpr int ba_c_tri(int k) { return 16 * (ba_c_nb(k) * (ba_c_nb(k) + 1) / 2); } /* compact result, 4x4 blocks */
-struct BaCTab { int cap[BA_SMALL_MAXF + 1], ld[BA_SMALL_MAXF + 1]; };
+#define BA_CB 37 /* doubles per 6 x 6 block of a group's compact result: 36 + 1, so that lanes reading different blocks at one offset spread over the banks */
+__host__ __device__ constexpr int ba_c_rhs(int k) { return BA_CB * (k * (k + 1) / 2); }   /* the compact rhs starts behind the blocks */
+__host__ __device__ constexpr int ba_c_tri(int k) { return ba_c_rhs(k) + 6 * k; }         /* compact result of a group */
+__host__ __device__ constexpr int ba_c_nacc(int k) { /* block-product instructions per k-step (= accumulators) of pattern size k */
+    const int nb = ba_c_nb(k), nvf = nb / 4, rem = nb % 4;
+    return 3 * nvf + 2 * nvf * (nvf - 1) + rem * (nvf + 1);
+}
+struct BaCTab { int cap[BA_SMALL_MAXF + 1], ld[BA_SMALL_MAXF + 1], nacc[BA_SMALL_MAXF + 1]; };
 __host__ __device__ constexpr BaCTab ba_c_tab() {
     BaCTab t = {};
-    for (int k = 1; k <= BA_SMALL_MAXF; k++) { t.cap[k] = ba_c_cap(k); t.ld[k] = ba_c_ld(k); }
+    for (int k = 1; k <= BA_SMALL_MAXF; k++) { t.cap[k] = ba_c_cap(k); t.ld[k] = ba_c_ld(k); t.nacc[k] = ba_c_nacc(k); }
     return t;
 }
 __device__ const BaCTab ba_ctab = ba_c_tab();
 static int ba_c_wave_lds(int nfree) {
     int m = 0;
-    for (int k = 1; k <= nfree; k++) m = std::max(m, std::max(ba_c_tile(k), ba_c_tri(k)));
-    return ((m + 3) & ~3) + BA_RECS_LDS;
+    for (int k = 1; k <= nfree; k++) m = std::max(m, std::max(ba_c_tile(k), k <= BA_KMFMA ? ba_c_tri(k) : 0));
+    return ((m + 3) & ~3) + BA_RECS_LDS + BA_ZERO_LDS;
 }
 
 /* Stable partition of src[0..n) by a predicate into dst (zeros first, both classes in source order) by one 256-thread
@@ -699,6 +724,36 @@ k_ba_groups(BaDims d, int* __restrict__ iw, const int* __restrict__ errflag) {
         GD[g] = make_int4(r, ebin[m] + at * k, m, min(ba_ctab.cap[k], cntb[m] - at));
     });
     if (tid == 0) I[d.oGDesc + 4 * (size_t)d.npt] = ng;
+    /* cost estimate per group (shader clocks / 64 of the Schur kernel's phases, measured: a fixed part for the linearisation
+     * and the bookkeeping, the k-steps times the pattern's products, the direct form per tile column), as an exclusive
+     * prefix: the Schur wavefronts cut the group list into runs of equal cost */
+    __threadfence_block();
+    __syncthreads();
+    int* GC = I + d.oGCost;
+    for (int g = tid; g < ng; g += BA_T) {
+        const int4 gd = GD[g];
+        const int k = __popc(gd.z), nks = (3 * gd.w + 3) >> 2;
+        GC[g] = 55 + ((k <= BA_KMFMA) ? nks * ba_ctab.nacc[k] : 12 * gd.w);
+    }
+    if (tid == 0) GC[ng] = 0;
+    __threadfence_block();
+    __syncthreads();
+    const int total = tb_block_excl_scan(GC, ng, tmp);
+    if (tid == 0) GC[ng] = total;
+    __threadfence_block();
+    __syncthreads();
+    /* where the window's Schur wavefronts start: wavefront v takes the groups whose cost prefix lies in
+     * [v, v + 1) / nwv of the total (a binary search per wavefront at kernel start cost 18 dependent loads) */
+    const int nwv = 4 * (d.Gbase + (w < d.Gextra ? 1 : 0));
+    for (int v = tid; v <= nwv; v += BA_T) {
+        const long long target = ((long long)total * v + nwv - 1) / nwv;
+        int lo = 0, hi = ng;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (GC[mid] < target) lo = mid + 1; else hi = mid;
+        }
+        I[d.oGCut + v] = (v == 0) ? 0 : (v == nwv) ? ng : lo;
+    }
 }
 
 /* broadcast of one lane's double through the scalar unit (lane index wave-uniform) */
@@ -711,8 +766,10 @@ __device__ __forceinline__ double ba_readlane(double v, int lane) {
 template <int S>
 __device__ __forceinline__ double ba_rot(double v) {
     static_assert(S >= 1 && S <= 3, "rotation by whole row blocks");
-    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x120 + 16 - 4 * S, 0xf, 0xf, false);
-    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x120 + 16 - 4 * S, 0xf, 0xf, false);
+    /* every lane has a source inside its row: the `old` operand is never used, passing the source avoids a zero fill */
+    const int l0 = __double2loint(v), h0 = __double2hiint(v);
+    const int lo = __builtin_amdgcn_update_dpp(l0, l0, 0x120 + 16 - 4 * S, 0xf, 0xf, false);
+    const int hi = __builtin_amdgcn_update_dpp(h0, h0, 0x120 + 16 - 4 * S, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
 template <int S>
@@ -720,6 +777,18 @@ __device__ __forceinline__ double ba_rot_any(double v) {
     if constexpr (S == 0) return v;
     else return ba_rot<S>(v);
 }
+
+#ifdef BA_TIMING   /* debug build: shader clocks of the Schur kernel's phases (wavefront 0 of every 16th window's workgroups) */
+__device__ unsigned long long ba_times[16];
+extern "C" int tb_debug_ba_times(unsigned long long* out, int reset) {
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ba_times), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(ba_times), z, sizeof z); }
+    return 0;
+}
+#define BA_TK(i) do { const unsigned long long t1_ = __builtin_readcyclecounter(); tk_[i] += t1_ - t0_; t0_ = t1_; } while (0)
+#else
+#define BA_TK(i) do { } while (0)
+#endif
 
 /* one prefetched Schur group */
 struct BaPreC {
@@ -730,87 +799,175 @@ struct BaPreC {
     int4 nxt;          /* the group it fetches next */
 };
 
-/* Block product of a group's tile for a pattern of K keyframes, result into C as 4x4 blocks of the lower triangle:
- * block (rb >= cb) at C[16 (rb (rb + 1) / 2 + cb)], row major. C may alias the tile (it is written after the last read). */
+/* Block product of a group's tile for a pattern of K keyframes. Result into C in the layout the dense accumulators
+ * read: 6 x 6 block (sa >= sb) of the pattern's keyframe slots at C[BA_CB (sa (sa + 1) / 2 + sb)], row major, diagonal
+ * blocks with both halves; the rhs (row 6 K) at C[ba_c_rhs(K)].
+ * C may alias the tile: it is written after the last operand read. Patterns of up to BA_KMFMA = 5 keyframes come here (at
+ * most 10 accumulators); the accumulators of larger ones (25 at K = 8) would set the kernel's register allocation for
+ * every path, so those take the direct form in the kernel.
+ * Where an accumulator's 64 entries go depends only on (K, accumulator, lane): BaCGeom<K>::where() is that map, evaluated
+ * once per workgroup into an LDS table (ba_c_build_table) -- computing it per group cost more than the products
+ * (divisions by 6, triangular indices: ~35 instructions per accumulator against one table read and two stores). */
+template <int K> struct BaCGeom {
+    static constexpr int NB = ba_c_nb(K), LD = ba_c_ld(K), NVF = NB / 4, REM = NB % 4;
+    static constexpr int LASTROW = 4 * NB - 1;
+    static constexpr int NV = NVF + ((REM > 1) ? 1 : 0);  /* operands with four row blocks: the full tiles, then the partial one */
+    static constexpr int NAF = 3 * NVF + 2 * NVF * (NVF - 1); /* accumulators of the full tile rows */
+    static constexpr int NACC = NAF + REM * (NVF + 1);
+    static_assert(NACC <= 12 && NACC > 0 && NACC == ba_c_nacc(K), "accumulators of a pattern on the MFMA path");
+    __host__ __device__ static constexpr int aofs(int m) { return 3 * m + 2 * m * (m - 1); } /* first accumulator of tile row m */
+    /* destination of accumulator t's entry in this lane: main | mirror << 16, in doubles from the start of the wavefront's
+     * LDS; 0xffff for entries that are not part of the result */
+    __host__ __device__ static constexpr unsigned where(int t, int lane) {
+        constexpr int trash = 0xffff;
+        /* result lane 16 i + 4 q + j = entry (i, j) of position q's block */
+        const int i = lane >> 4, q = (lane >> 2) & 3, j = lane & 3;
+        int row = 0, col = 0;
+        bool ok = true;
+        if (t < NAF) {
+            int m = 0;
+            while (m + 1 < NVF && aofs(m + 1) <= t) m++;
+            const int u = t - aofs(m);                 /* 0..2: the diagonal tile's rotations; then four per tile left of it */
+            const int mp = (u < 3) ? m : (u - 3) >> 2, sr = (u < 3) ? u : (u - 3) & 3;
+            row = 16 * m + 4 * ((q + sr) & 3) + i;     /* rot_sr brings this block to position q */
+            col = 16 * mp + 4 * q + j;
+            if (u == 2) ok = q < 2;                    /* positions 2, 3 repeat 0, 1 transposed */
+        } else {
+            const int r = (t - NAF) / (NVF + 1), mp = (t - NAF) % (NVF + 1);
+            row = 4 * (4 * NVF + r) + i;
+            if (mp < NVF) col = 16 * mp + 4 * q + j;
+            else { col = 4 * (4 * NVF + ((REM > 1) ? q : r)) + j; ok = (REM > 1) ? (q <= r) : (q == 0); }
+        }
+        /* a wrapped position holds the transposed upper block; the upper half of a diagonal 4 x 4 block repeats the lower */
+        const int rr = row > col ? row : col, cc = row > col ? col : row;
+        const int sa = rr / 6, sb = cc / 6, ii = rr - 6 * sa, jj = cc - 6 * sb;
+        const int blk = BA_CB * (sa * (sa + 1) / 2 + sb);
+        unsigned mainw = (unsigned)trash, mirr = (unsigned)trash;
+        if (ok && rr < 6 * K) {
+            mainw = (unsigned)(blk + 6 * ii + jj);
+            if (sa == sb) mirr = (unsigned)(blk + 6 * jj + ii);
+        }
+        if (ok && rr == 6 * K) mainw = (unsigned)(ba_c_rhs(K) + cc);
+        return mainw | (mirr << 16);
+    }
+};
+__host__ __device__ constexpr int ba_c_tab_ofs(int k) { /* first table row of pattern size k */
+    int o = 0;
+    if (k > 1) o += BaCGeom<1>::NACC;
+    if (k > 2) o += BaCGeom<2>::NACC;
+    if (k > 3) o += BaCGeom<3>::NACC;
+    if (k > 4) o += BaCGeom<4>::NACC;
+    if (k > 5) o += BaCGeom<5>::NACC;
+    return o;
+}
+#define BA_CTAB_ROWS (ba_c_tab_ofs(BA_KMFMA + 1))
+struct BaCWhere { unsigned v[BA_CTAB_ROWS * 64]; };
 template <int K>
-__device__ __forceinline__ void ba_c_product(const double* __restrict__ Zt, double* __restrict__ C, int nks, int lane) {
-    constexpr int NB = ba_c_nb(K), LD = ba_c_ld(K), NVF = NB / 4, REM = NB % 4;
-    constexpr int NACC = 3 * NVF + 2 * NVF * (NVF - 1) + REM * (NVF + 1);
-    constexpr int LASTROW = 4 * NB - 1;
-    double acc[NACC];
-#pragma unroll
-    for (int i = 0; i < NACC; i++) acc[i] = 0;
+__host__ __device__ constexpr void ba_c_where_rows(BaCWhere& t) {
+    for (int a = 0; a < BaCGeom<K>::NACC; a++)
+        for (int l = 0; l < 64; l++) t.v[(ba_c_tab_ofs(K) + a) * 64 + l] = BaCGeom<K>::where(a, l);
+}
+__host__ __device__ constexpr BaCWhere ba_c_where_table() {
+    BaCWhere t = {};
+    ba_c_where_rows<1>(t); ba_c_where_rows<2>(t); ba_c_where_rows<3>(t); ba_c_where_rows<4>(t); ba_c_where_rows<5>(t);
+    return t;
+}
+__device__ const BaCWhere ba_cwhere = ba_c_where_table(); /* evaluated by the compiler; every workgroup copies it into LDS */
+
+#define BA_CACC 12 /* accumulators of the MFMA path (the largest pattern on it needs 10) */
+/* acc += block product of the tile (nks k-steps). The accumulators are the caller's: consecutive groups of one pattern
+ * keep adding into them, the compact result is written once per run (ba_c_store). */
+template <int K>
+__device__ __forceinline__ void ba_c_mac(double (&acc)[BA_CACC], const double* __restrict__ Zt, int nks, int lane) {
+    typedef BaCGeom<K> G;
+    constexpr int NVF = G::NVF, REM = G::REM, NV = G::NV, NAF = G::NAF, LD = G::LD;
+    /* the operand offsets below depend only on the lane: left alone, the compiler computes them for all five patterns ahead
+     * of the group loop and keeps ~25 registers alive through the linearisation, the kernel's register peak */
+    asm volatile("" : "+v"(lane));
     const int kq = lane >> 4, r16 = lane & 15;
-    int vofs[NVF + 1], wofs[REM + 1];
+    int vofs[NV + 1], wofs[REM + 1];
 #pragma unroll
-    for (int m = 0; m <= NVF; m++) vofs[m] = min(16 * m + r16, LASTROW) * LD + kq; /* m = NVF: the partial tile, rows clamped (unused blocks) */
+    for (int m = 0; m < NV; m++) vofs[m] = min(16 * m + r16, G::LASTROW) * LD + kq; /* the partial tile's rows are clamped (unused blocks) */
 #pragma unroll
     for (int r = 0; r < REM; r++) wofs[r] = (4 * (4 * NVF + r) + (lane & 3)) * LD + kq;
-    for (int ks = 0; ks < nks; ks++) {
-        const double* z = Zt + 4 * ks;
-        double V[NVF + 1];
-#pragma unroll
-        for (int m = 0; m < NVF; m++) V[m] = z[vofs[m]];
+    auto step = [&](const double (&V)[NV + 1], const double (&W)[REM + 1]) {
 #pragma unroll
         for (int m = 0; m < NVF; m++) {
+            const int o = G::aofs(m);
             const double r1 = ba_rot<1>(V[m]), r2 = ba_rot<2>(V[m]);
-            acc[3 * m] = __builtin_amdgcn_mfma_f64_4x4x4f64(V[m], V[m], acc[3 * m], 0, 0, 0);
-            acc[3 * m + 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(r1, V[m], acc[3 * m + 1], 0, 0, 0);
-            acc[3 * m + 2] = __builtin_amdgcn_mfma_f64_4x4x4f64(r2, V[m], acc[3 * m + 2], 0, 0, 0);
+            acc[o] = __builtin_amdgcn_mfma_f64_4x4x4f64(V[m], V[m], acc[o], 0, 0, 0);
+            acc[o + 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(r1, V[m], acc[o + 1], 0, 0, 0);
+            acc[o + 2] = __builtin_amdgcn_mfma_f64_4x4x4f64(r2, V[m], acc[o + 2], 0, 0, 0);
             if (m > 0) {
                 const double r3 = ba_rot<3>(V[m]);
 #pragma unroll
                 for (int mp = 0; mp < m; mp++) {
-                    const int o = 3 * NVF + 4 * (m * (m - 1) / 2 + mp);
-                    acc[o] = __builtin_amdgcn_mfma_f64_4x4x4f64(V[m], V[mp], acc[o], 0, 0, 0);
-                    acc[o + 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(r1, V[mp], acc[o + 1], 0, 0, 0);
-                    acc[o + 2] = __builtin_amdgcn_mfma_f64_4x4x4f64(r2, V[mp], acc[o + 2], 0, 0, 0);
-                    acc[o + 3] = __builtin_amdgcn_mfma_f64_4x4x4f64(r3, V[mp], acc[o + 3], 0, 0, 0);
+                    const int p = o + 3 + 4 * mp;
+                    acc[p] = __builtin_amdgcn_mfma_f64_4x4x4f64(V[m], V[mp], acc[p], 0, 0, 0);
+                    acc[p + 1] = __builtin_amdgcn_mfma_f64_4x4x4f64(r1, V[mp], acc[p + 1], 0, 0, 0);
+                    acc[p + 2] = __builtin_amdgcn_mfma_f64_4x4x4f64(r2, V[mp], acc[p + 2], 0, 0, 0);
+                    acc[p + 3] = __builtin_amdgcn_mfma_f64_4x4x4f64(r3, V[mp], acc[p + 3], 0, 0, 0);
                 }
             }
         }
         if (REM > 0) {
-            double W[REM + 1];
-#pragma unroll
-            for (int r = 0; r < REM; r++) W[r] = z[wofs[r]];
-            const double VP = (REM > 1) ? z[vofs[NVF]] : W[0]; /* one trailing block: every position of W[0] x W[0] is that block */
+            const double VP = (REM > 1) ? V[NV - 1] : W[0]; /* one trailing block: every position of W[0] x W[0] is that block */
 #pragma unroll
             for (int r = 0; r < REM; r++) {
-                const int o = 3 * NVF + 2 * NVF * (NVF - 1) + r * (NVF + 1);
+                const int o = NAF + r * (NVF + 1);
 #pragma unroll
                 for (int mp = 0; mp < NVF; mp++) acc[o + mp] = __builtin_amdgcn_mfma_f64_4x4x4f64(W[r], V[mp], acc[o + mp], 0, 0, 0);
                 acc[o + NVF] = __builtin_amdgcn_mfma_f64_4x4x4f64(W[r], VP, acc[o + NVF], 0, 0, 0);
             }
         }
-    }
-    ba_wave_lds_fence();
-    /* result lane 16 i + 4 q + j = entry (i, j) of position q's block */
-    const int i = lane >> 4, q = (lane >> 2) & 3, j = lane & 3;
-    auto put = [&](int bA, int bB, double v, bool ok) {
-        const int rb = max(bA, bB), cb = min(bA, bB);
-        const int ri = (bA >= bB) ? i : j, ci = (bA >= bB) ? j : i; /* a wrapped position holds the transposed upper block */
-        if (ok) C[16 * (rb * (rb + 1) / 2 + cb) + 4 * ri + ci] = v;
     };
+    auto fetch = [&](double (&V)[NV + 1], double (&W)[REM + 1], int ks) {
+        const double* z = Zt + 4 * ks;
 #pragma unroll
-    for (int m = 0; m < NVF; m++) {
-        put(4 * m + q, 4 * m + q, acc[3 * m], true);
-        put(4 * m + ((q + 1) & 3), 4 * m + q, acc[3 * m + 1], true);
-        put(4 * m + ((q + 2) & 3), 4 * m + q, acc[3 * m + 2], q < 2); /* positions 2, 3 repeat 0, 1 transposed */
+        for (int m = 0; m < NV; m++) V[m] = z[vofs[m]];
 #pragma unroll
-        for (int mp = 0; mp < m; mp++) {
-            const int o = 3 * NVF + 4 * (m * (m - 1) / 2 + mp);
-#pragma unroll
-            for (int s = 0; s < 4; s++) put(4 * m + ((q + s) & 3), 4 * mp + q, acc[o + s], true);
-        }
+        for (int r = 0; r < REM; r++) W[r] = z[wofs[r]];
+    };
+    /* three operand sets in turn: the reads of k-steps ks + 1 and ks + 2 are in flight during the products of k-step ks --
+     * with two wavefronts per SIMD and eight per CU on the LDS, one k-step of products (80-160 clocks) does not cover a
+     * read. The reads behind the last k-step stay inside the wavefront's LDS and are never used. */
+    double Va[NV + 1], Wa[REM + 1], Vb[NV + 1], Wb[REM + 1], Vc[NV + 1], Wc[REM + 1];
+    fetch(Va, Wa, 0);
+    fetch(Vb, Wb, 1);
+    int ks = 0;
+    for (; ks + 2 < nks; ks += 3) {
+        fetch(Vc, Wc, ks + 2);
+        step(Va, Wa);
+        fetch(Va, Wa, ks + 3);
+        step(Vb, Wb);
+        fetch(Vb, Wb, ks + 4);
+        step(Vc, Wc);
     }
+    if (ks < nks) step(Va, Wa);
+    if (ks + 1 < nks) step(Vb, Wb);
+    ba_wave_lds_fence();
+    asm volatile("; end of ba_c_mac<%0>" : : "n"(K)); /* see ba_c_store */
+}
+/* accumulators -> compact result, and clear them: destination pair of every entry from the table (0xffff: not part of the
+ * result) */
+template <int K>
+__device__ __forceinline__ void ba_c_store(double (&acc)[BA_CACC], double* __restrict__ C, const unsigned* __restrict__ tab, int lane) {
+    constexpr int NACC = BaCGeom<K>::NACC;
+    unsigned wh[NACC];
 #pragma unroll
-    for (int r = 0; r < REM; r++) {
-        const int o = 3 * NVF + 2 * NVF * (NVF - 1) + r * (NVF + 1);
+    for (int t = 0; t < NACC; t++) wh[t] = tab[(ba_c_tab_ofs(K) + t) * 64 + lane];
 #pragma unroll
-        for (int mp = 0; mp < NVF; mp++) put(4 * NVF + r, 4 * mp + q, acc[o + mp], true);
-        put(4 * NVF + r, 4 * NVF + ((REM > 1) ? q : r), acc[o + NVF], (REM > 1) ? (q <= r) : (q == 0));
+    for (int t = 0; t < NACC; t++) {
+        /* predicated: 60 lanes storing to ONE spare address would serialise in its bank */
+        if ((wh[t] & 0xffffu) != 0xffffu) C[wh[t] & 0xffffu] = acc[t];
+        if ((wh[t] >> 16) != 0xffffu) C[wh[t] >> 16] = acc[t];
+        acc[t] = 0;
     }
     ba_wave_lds_fence();
+    /* a different statement per pattern size: the compiler otherwise merges the tails of the callers' switch cases ("store
+     * and clear the LAST accumulator" of every size) into one block behind a pointer phi, and the accumulators it selects
+     * between -- five of them -- live in scratch memory from then on, loaded and stored around every MFMA */
+    asm volatile("; end of ba_c_store<%0>" : : "n"(K));
 }
 
 template <int R> /* 16-row tiles of the dense pose block; NF = free keyframes this instantiation holds */
@@ -818,35 +975,51 @@ __global__ void __launch_bounds__(BA_T, 2)
 k_ba_schur_c(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, BaState* __restrict__ states) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
     __shared__ double sRtf[BA_SMALL_MAXF * 12]; /* free keyframes at the linearisation state: R, t */
+    __shared__ unsigned ctab[BA_CTAB_ROWS * 64]; /* where the block products' accumulator entries go (BaCGeom::where) */
     constexpr int NF = (R == 1) ? 2 : (R == 2) ? 5 : (R == 3) ? 8 : BA_SMALL_MAXF;
     constexpr int NPAIR = NF * (NF + 1) / 2;
+#ifdef BA_TIMING
+    const unsigned long long tstart_ = __builtin_readcyclecounter();
+#endif
     const int w = blockIdx.y, g0 = blockIdx.x, tid = threadIdx.x;
     const BaState st = states[w];
-    if (st.status) return;
+    const int Gw = d.Gbase + (w < d.Gextra ? 1 : 0); /* this window's workgroups */
+    if (st.status || g0 >= Gw) return;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     double* Zt = lds + (size_t)wave * d.schurWaveLds;          /* the group's tile, then its compact result */
-    double* Hi = Zt + (d.schurWaveLds - BA_RECS_LDS);           /* the group's point records */
+    double* Hi = Zt + (d.schurWaveLds - BA_RECS_LDS - BA_ZERO_LDS); /* the group's point records, then a block of zeros */
+    const int zeroOfs = d.schurWaveLds - BA_ZERO_LDS;
     double* D = dw + (size_t)w * d.wstride;
     const int* I = iw + (size_t)w * d.istride;
     for (int k = tid; k < d.nfree; k += BA_T) ba_pose_to_Rt(D + d.oT + ((size_t)st.cur * d.nkf + d.nfixed + k) * 7, sRtf + k * 12);
-    double S[NPAIR]; /* dense accumulators: register p = block pair (a >= b), lane 6 i + j = entry (i, j) */
+    /* dense accumulators: lane p < NPAIR = block pair (a >= b) of free keyframes, register 6 i + j = entry (i, j) of its
+     * 6 x 6 block -- a group's compact blocks are added with one LDS read per register at a per-lane base address */
+    double S[36];
 #pragma unroll
-    for (int p = 0; p < NPAIR; p++) S[p] = 0;
+    for (int e = 0; e < 36; e++) S[e] = 0;
     double rhs = 0;  /* lane = dense row */
+    int pa = 0;      /* this lane's pair: p = pa (pa + 1) / 2 + pb */
+    while ((pa + 1) * (pa + 2) / 2 <= lane) pa++;
+    const int pb = lane - pa * (pa + 1) / 2;
+    if (lane < BA_ZERO_LDS) Zt[zeroOfs + lane] = 0;
+    for (int i = tid; i < BA_CTAB_ROWS * 64; i += BA_T) ctab[i] = ba_cwhere.v[i];
     __syncthreads();
     const double delta = (double)sqrtf(5.991f);
     const int ng = I[d.oGDesc + 4 * (size_t)d.npt];
-    const int stride = d.G * 4, pf = 2 * stride;
-    const int lastG = ng - 1, lastE = d.obs_pitch - 1;
+    const int lastE = d.obs_pitch - 1;
     const double* Hq = D + d.oHq;
     const int4* KPs = reinterpret_cast<const int4*>(I + d.oKPs);
     const int4* GD = reinterpret_cast<const int4*>(I + d.oGDesc);
     const unsigned lastQ = (unsigned)d.npt * BA_REC - 1u;
+    /* every wavefront takes a contiguous run of groups: the groups are in pattern order, so consecutive ones mostly share
+     * their pattern and keep adding into the same product accumulators */
+    const int nwv = Gw * 4, wv = g0 * 4 + wave;
+    const int gBeg = I[d.oGCut + wv], gEnd = I[d.oGCut + wv + 1], lastG = gEnd - 1;
     auto range = [&](BaPreC& X, int g) {
-        X.nxt = GD[min(g, lastG)];
+        X.nxt = GD[min(g, max(lastG, 0))];
         if (g > lastG) X.nxt.w = 0; /* past the end: an empty group */
     };
-    auto preload = [&](BaPreC& X, int g) { /* X.nxt = descriptor of group g (fetched one fill earlier); then the one of g + pf */
+    auto preload = [&](BaPreC& X, int g) { /* X.nxt = descriptor of group g (fetched one fill earlier); then the one of g + 2 */
         const int4 gd = X.nxt;
         const int4 r = KPs[(unsigned)min(gd.y + lane, lastE)];
         X.key = (lane < gd.w * __popc(gd.z)) ? r.x : -1;
@@ -857,12 +1030,51 @@ k_ba_schur_c(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, BaSt
         X.r2 = Hq[min(qb + 128u, lastQ)];
         X.r3 = Hq[min(qb + 192u, lastQ)];
         X.cur = gd;
-        range(X, g + pf);
+        range(X, g + 2);
     };
-    const int li = min(lane, 35), ei = li / 6, ej = li - 6 * ei; /* entry of a 6 x 6 block this lane accumulates */
+#ifdef BA_TIMING
+    unsigned long long tk_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}, t0_ = __builtin_readcyclecounter();
+    tk_[4] = t0_ - tstart_; /* prologue */
+#endif
+    double acc[BA_CACC]; /* block products of the pattern `pend` that are not in the dense accumulators yet */
+#pragma unroll
+    for (int i = 0; i < BA_CACC; i++) acc[i] = 0;
+    int pend = 0;
+    /* products of pattern m: accumulators -> compact result -> dense accumulators. Block pair (a >= b) of the pattern is
+     * the compact block of the two keyframes' slots; pairs the pattern does not have read the zeros. A dozen reads in
+     * flight at a time. */
+    auto finish = [&](int m) {
+        const int k = __popc(m);
+        switch (k) {
+            case 1: ba_c_store<1>(acc, Zt, ctab, lane); break;
+            case 2: ba_c_store<2>(acc, Zt, ctab, lane); break;
+            case 3: if constexpr (NF >= 3) ba_c_store<3>(acc, Zt, ctab, lane); break;
+            case 4: if constexpr (NF >= 4) ba_c_store<4>(acc, Zt, ctab, lane); break;
+            default: if constexpr (NF >= 5) ba_c_store<5>(acc, Zt, ctab, lane); break;
+        }
+        const bool has = lane < NPAIR && ((m >> pa) & 1) && ((m >> pb) & 1);
+        const int sa = __popc(m & ((1 << pa) - 1)), sb = __popc(m & ((1 << pb) - 1));
+        const int ra = min(lane / 6, NF - 1), i6 = lane - 6 * (lane / 6);
+        const bool hasr = lane < 6 * NF && ((m >> ra) & 1);
+        const double* cb = Zt + (has ? BA_CB * (sa * (sa + 1) / 2 + sb) : zeroOfs);
+#pragma unroll
+        for (int e0 = 0; e0 < 36; e0 += 12) {
+            double t[12];
+#pragma unroll
+            for (int e = 0; e < 12; e++) t[e] = cb[e0 + e];
+#pragma unroll
+            for (int e = 0; e < 12; e++) S[e0 + e] += t[e];
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        rhs += Zt[hasr ? BA_CB * (k * (k + 1) / 2) + 6 * __popc(m & ((1 << ra) - 1)) + i6 : zeroOfs];
+        ba_wave_lds_fence();
+    };
     auto group = [&](BaPreC& X, int g) {
+        BA_TK(5);
         const int mask = __builtin_amdgcn_readfirstlane(X.cur.z), npts = __builtin_amdgcn_readfirstlane(X.cur.w);
         const int k = __popc(mask), ld = ba_ctab.ld[k];
+        if (pend != 0 && pend != mask) { finish(pend); pend = 0; } /* the compact result goes through the tile's storage: before the tile is rewritten */
+        BA_TK(3);
         Hi[lane] = X.r0;
         Hi[64 + lane] = X.r1;
         Hi[128 + lane] = X.r2;
@@ -885,16 +1097,16 @@ k_ba_schur_c(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, BaSt
 #pragma unroll
             for (int r = 0; r < 2; r++) {
                 JU[3 * r] = L.Jl[3 * r] * u00;
-                JU[3 * r + 1] = L.Jl[3 * r] * u01 + L.Jl[3 * r + 1] * u11;
-                JU[3 * r + 2] = L.Jl[3 * r] * u02 + L.Jl[3 * r + 1] * u12 + L.Jl[3 * r + 2] * u22;
+                JU[3 * r + 1] = fma(L.Jl[3 * r], u01, L.Jl[3 * r + 1] * u11);
+                JU[3 * r + 2] = fma(L.Jl[3 * r], u02, fma(L.Jl[3 * r + 1], u12, L.Jl[3 * r + 2] * u22));
             }
             double* z = Zt + (6 * slot) * ld + 3 * pl;
 #pragma unroll
             for (int a = 0; a < 6; a++) {
                 const double p0w = L.ww * Jp[a], p1w = L.ww * Jp[6 + a];
-                z[a * ld] = p0w * JU[0] + p1w * JU[3];
-                z[a * ld + 1] = p0w * JU[1] + p1w * JU[4];
-                z[a * ld + 2] = p0w * JU[2] + p1w * JU[5];
+                z[a * ld] = fma(p0w, JU[0], p1w * JU[3]);
+                z[a * ld + 1] = fma(p0w, JU[1], p1w * JU[4]);
+                z[a * ld + 2] = fma(p0w, JU[2], p1w * JU[5]);
             }
             if (slot == 0) { /* the rhs row: U^T bl of the point under its three columns */
                 double* zr = Zt + (6 * k) * ld + 3 * pl;
@@ -908,83 +1120,89 @@ k_ba_schur_c(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, BaSt
                 if (ncol + c < 4 * nks) Zt[lane * ld + ncol + c] = 0;
         }
         ba_wave_lds_fence();
-        /* this set is free again: issue the loads of the group it holds next, before the MFMA phase */
-        preload(X, g + pf);
-        switch (k) {
-            case 1: ba_c_product<1>(Zt, Zt, nks, lane); break;
-            case 2: ba_c_product<2>(Zt, Zt, nks, lane); break;
-            case 3: if constexpr (NF >= 3) ba_c_product<3>(Zt, Zt, nks, lane); break;
-            case 4: if constexpr (NF >= 4) ba_c_product<4>(Zt, Zt, nks, lane); break;
-            case 5: if constexpr (NF >= 5) ba_c_product<5>(Zt, Zt, nks, lane); break;
-            case 6: if constexpr (NF >= 6) ba_c_product<6>(Zt, Zt, nks, lane); break;
-            case 7: if constexpr (NF >= 7) ba_c_product<7>(Zt, Zt, nks, lane); break;
-            case 8: if constexpr (NF >= 8) ba_c_product<8>(Zt, Zt, nks, lane); break;
-            case 9: if constexpr (NF >= 9) ba_c_product<9>(Zt, Zt, nks, lane); break;
-            case 10: if constexpr (NF >= 10) ba_c_product<10>(Zt, Zt, nks, lane); break;
-            default: break;
-        }
-        /* compact result -> dense accumulators: block pair (a >= b) of the pattern sits at rows 6 slot(a).., columns
-         * 6 slot(b).. of the compact triangle; a diagonal pair reads its upper half from the mirrored entry */
-#pragma unroll
-        for (int a = 0; a < NF; a++) {
-            if (!((mask >> a) & 1)) continue;
-            const int sa = __popc(mask & ((1 << a) - 1));
-#pragma unroll
-            for (int b = 0; b <= a; b++) {
-                if (!((mask >> b) & 1)) continue;
-                const int sb = __popc(mask & ((1 << b) - 1));
-                int row = 6 * sa + ei, col = 6 * sb + ej;
-                if (a == b && col > row) { const int t = row; row = col; col = t; }
-                const int rb = row >> 2, cb = col >> 2;
-                S[a * (a + 1) / 2 + b] += Zt[16 * (rb * (rb + 1) / 2 + cb) + 4 * (row & 3) + (col & 3)];
+        BA_TK(0);
+        /* this set is free again: issue the loads of the group it holds next, before the products */
+        preload(X, g + 2);
+        BA_TK(1);
+        if (k <= BA_KMFMA) {
+            switch (k) {
+                case 1: ba_c_mac<1>(acc, Zt, nks, lane); break;
+                case 2: ba_c_mac<2>(acc, Zt, nks, lane); break;
+                case 3: if constexpr (NF >= 3) ba_c_mac<3>(acc, Zt, nks, lane); break;
+                case 4: if constexpr (NF >= 4) ba_c_mac<4>(acc, Zt, nks, lane); break;
+                default: if constexpr (NF >= 5) ba_c_mac<5>(acc, Zt, nks, lane); break;
             }
-        }
-        {   /* rhs: row 6 k of the compact triangle, scattered to the dense rows of the pattern's keyframes */
-            const int a = min(lane / 6, NF - 1), i6 = lane - 6 * (lane / 6);
-            const int col = 6 * __popc(mask & ((1 << a) - 1)) + i6, row = 6 * k;
-            const int rb = row >> 2, cb = col >> 2;
-            if (lane < 6 * NF && ((mask >> a) & 1)) rhs += Zt[16 * (rb * (rb + 1) / 2 + cb) + 4 * (row & 3) + (col & 3)];
-        }
-        ba_wave_lds_fence();
-    };
-    if (ng > 0) {
-        BaPreC A, B;
-        int g = g0 * 4 + wave;
-        range(A, g);
-        range(B, g + stride);
-        preload(A, g);
-        preload(B, g + stride);
-        for (; g + stride < ng; g += 2 * stride) {
-            group(A, g);
-            group(B, g + stride);
-        }
-        if (g < ng) group(A, g);
-    }
-    __syncthreads();
-    /* sum the four waves' accumulators through LDS in wave order (fixed shape), then one partial per block in the
-     * 64 x 64 layout k_ba_solve reads: lower triangle at [row][col], reduced rhs in column np */
-    double* sum = lds; /* reuses the tile storage: every wave is past its last tile read */
-    for (int wv = 0; wv < 4; wv++) {
-        if (wave == wv) {
-            if (lane < 36) {
+            pend = mask;
+        } else if constexpr (NF > BA_KMFMA) {
+            /* patterns of more than BA_KMFMA keyframes: the 6 x 6 block products on the vector ALU, straight into the
+             * dense accumulators -- lane = block pair, per tile column six values of either keyframe's rows and 36
+             * multiply-adds; no compact result, no extra registers. About 1.5 x the time of the dense-tile kernel of round 2
+             * on windows where every keyframe sees every point, the price of keeping the common sparse case lean. */
+            const bool has = lane < NPAIR && ((mask >> pa) & 1) && ((mask >> pb) & 1);
+            const int sa = __popc(mask & ((1 << pa) - 1)), sb = __popc(mask & ((1 << pb) - 1));
+            const int ra = min(lane / 6, NF - 1), i6 = lane - 6 * (lane / 6);
+            const bool hasr = lane < 6 * NF && ((mask >> ra) & 1);
+            const int sr = __popc(mask & ((1 << ra) - 1));
+            if (has) {
+                const double* za = Zt + 6 * sa * ld;
+                const double* zb = Zt + 6 * sb * ld;
+#pragma unroll 1
+                for (int c = 0; c < ncol; c++, za++, zb++) {
+                    double bv[6];
 #pragma unroll
-                for (int a = 0; a < NF; a++)
+                    for (int j = 0; j < 6; j++) bv[j] = zb[j * ld];
 #pragma unroll
-                    for (int b = 0; b <= a; b++) {
-                        const int idx = (6 * a + ei) * 64 + 6 * b + ej;
-                        sum[idx] = (wv == 0) ? S[a * (a + 1) / 2 + b] : sum[idx] + S[a * (a + 1) / 2 + b];
+                    for (int i = 0; i < 6; i++) {
+                        const double av = za[i * ld];
+#pragma unroll
+                        for (int j = 0; j < 6; j++) S[6 * i + j] = fma(av, bv[j], S[6 * i + j]);
                     }
+                }
+            }
+            if (hasr) {
+                const double* zr = Zt + (6 * sr + i6) * ld;
+                const double* zu = Zt + 6 * k * ld;
+#pragma unroll 1
+                for (int c = 0; c < ncol; c++) rhs = fma(zr[c], zu[c], rhs);
             }
             ba_wave_lds_fence();
-            if (lane < d.np) sum[lane * 64 + d.np] = (wv == 0) ? rhs : sum[lane * 64 + d.np] + rhs;
         }
-        __syncthreads();
+        BA_TK(2);
+#ifdef BA_TIMING
+        tk_[6] += 1; tk_[7] += (unsigned long long)npts;
+#endif
+    };
+    if (gBeg < gEnd) {
+        BaPreC A, B;
+        int g = gBeg;
+        range(A, g);
+        range(B, g + 1);
+        preload(A, g);
+        preload(B, g + 1);
+        for (; g + 1 < gEnd; g += 2) {
+            group(A, g);
+            group(B, g + 1);
+        }
+        if (g < gEnd) group(A, g);
+        if (pend != 0) finish(pend);
     }
-    double* out = D + d.oPartS + (size_t)g0 * 64 * 64;
-    for (int i = tid; i < 64 * 64; i += BA_T) {
-        const int r = i >> 6, c = i & 63;
-        if (r < d.np && (c <= r || c == d.np)) out[i] = sum[i];
+#ifdef BA_TIMING
+    BA_TK(8); /* first preload + tail of the loop */
+#endif
+    /* every wavefront writes its own partial system in the 64 x 64 layout k_ba_solve reads (lower triangle at [row][col],
+     * reduced rhs in column np): lane = block pair, its 36 entries; k_ba_solve adds the 4 G partials of the window in
+     * wavefront order. (Rounds 1-2 summed the four wavefronts through LDS first: a barrier -- every wavefront waiting for
+     * the slowest -- and four serial passes, 8 % of the kernel.) */
+    double* out = D + d.oPartS + (size_t)wv * 64 * 64;
+    if (lane < NPAIR) {
+#pragma unroll
+        for (int e = 0; e < 36; e++) out[(6 * pa + e / 6) * 64 + 6 * pb + e % 6] = S[e];
     }
+    if (lane < d.np) out[lane * 64 + d.np] = rhs;
+#ifdef BA_TIMING
+    BA_TK(9); /* epilogue */
+    if (tid == 0 && (w & 15) == 0) { for (int i = 0; i < 10; i++) atomicAdd(&ba_times[i], tk_[i]); atomicAdd(&ba_times[10], 1ull); }
+#endif
 }
 
 /* ---- E: assemble S (lower triangle), Cholesky in registers, pose update */
@@ -997,7 +1215,7 @@ k_ba_solve(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) {
     BaState* st = states + w;
     if (st->status) return;
     double* D = dw + (size_t)w * d.wstride;
-    const int np = d.np, nPart = d.G;
+    const int np = d.np, nPart = 4 * (d.Gbase + (w < d.Gextra ? 1 : 0)); /* one partial system per Schur wavefront */
     const double lambda = st->lambda;
     for (int i = tid; i < np * np; i += BA_T) {
         const int r = i / np, c = i - r * np;
@@ -1163,15 +1381,15 @@ __device__ __forceinline__ void ba_edge_z(const double* __restrict__ sRtf, const
 #pragma unroll
     for (int k = 0; k < 2; k++) {
         JU[3 * k] = L.Jl[3 * k] * u00;
-        JU[3 * k + 1] = L.Jl[3 * k] * u01 + L.Jl[3 * k + 1] * u11;
-        JU[3 * k + 2] = L.Jl[3 * k] * u02 + L.Jl[3 * k + 1] * u12 + L.Jl[3 * k + 2] * u22;
+        JU[3 * k + 1] = fma(L.Jl[3 * k], u01, L.Jl[3 * k + 1] * u11);
+        JU[3 * k + 2] = fma(L.Jl[3 * k], u02, fma(L.Jl[3 * k + 1], u12, L.Jl[3 * k + 2] * u22));
     }
 #pragma unroll
     for (int a = 0; a < 6; a++) {
         const double p0w = L.ww * Jp[a], p1w = L.ww * Jp[6 + a];
-        z[3 * a] = p0w * JU[0] + p1w * JU[3];
-        z[3 * a + 1] = p0w * JU[1] + p1w * JU[4];
-        z[3 * a + 2] = p0w * JU[2] + p1w * JU[5];
+        z[3 * a] = fma(p0w, JU[0], p1w * JU[3]);
+        z[3 * a + 1] = fma(p0w, JU[1], p1w * JU[4]);
+        z[3 * a + 2] = fma(p0w, JU[2], p1w * JU[5]);
     }
 }
 
@@ -1508,9 +1726,9 @@ k_ba_update(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
                 const double* xp = sx + 6 * (o.kf - d.nfixed);
                 double s0 = 0, s1 = 0;
 #pragma unroll
-                for (int a = 0; a < 6; a++) { s0 += Jp[a] * xp[a]; s1 += Jp[6 + a] * xp[a]; }
+                for (int a = 0; a < 6; a++) { s0 = fma(Jp[a], xp[a], s0); s1 = fma(Jp[6 + a], xp[a], s1); }
 #pragma unroll
-                for (int c = 0; c < 3; c++) r[c] -= L.ww * (L.Jl[c] * s0 + L.Jl[3 + c] * s1);
+                for (int c = 0; c < 3; c++) r[c] = fma(-L.ww, fma(L.Jl[c], s0, L.Jl[3 + c] * s1), r[c]);
             }
             const double t0 = u00 * r[0], t1 = u01 * r[0] + u11 * r[1], t2 = u02 * r[0] + u12 * r[1] + u22 * r[2]; /* U^T r */
             xl[0] = u00 * t0 + u01 * t1 + u02 * t2;
@@ -1605,16 +1823,23 @@ k_ba_finish(BaDims d, const double* __restrict__ dw, const BaState* __restrict__
     }
 }
 
-static void ba_dims(BaDims& d, int W, const double K[4], int nkf, int nfixed, int npt, int obs_pitch, int iters) {
+static void ba_dims(BaDims& d, int num_cu, int W, const double K[4], int nkf, int nfixed, int npt, int obs_pitch, int iters) {
     memset(&d, 0, sizeof d);
     d.W = W; d.nkf = nkf; d.nfixed = nfixed; d.nfree = nkf - nfixed; d.np = 6 * d.nfree; d.npt = npt; d.obs_pitch = obs_pitch;
     d.iters = iters;
     d.nblkP = (npt + BA_T - 1) / BA_T;
     d.kfChunks = (obs_pitch + BA_KFCH - 1) / BA_KFCH;
     d.nChunks = 0;
-    /* Schur workgroups per window: up to 4 resident per CU over the batch, no more than one per ~64 points (a group holds
-     * ~13), and at most 32 -- k_ba_solve adds the workgroups' partial systems in order */
-    d.G = std::min(std::min(std::max(1024 / std::max(W, 1), 1), 32), std::max((npt / 16 + 3) / 4, 1));
+    /* Schur workgroups: the kernel holds two per CU (226 registers per lane, ~62 KB of LDS), so the batch gets 2 num_cu of
+     * them -- ONE resident round (855 workgroups for 171 windows ran as 1.67 rounds: the second, two-thirds full, cost as much
+     * as the first) -- dealt to the windows as Gbase or Gbase + 1 each. At most 32 per window (k_ba_solve adds the
+     * workgroups' partial systems in order) and no more than one per ~256 points. */
+    {
+        const int slots = 2 * std::max(num_cu, 1), cap = std::min(32, std::max((npt / 64 + 3) / 4, 1));
+        d.Gbase = std::min(std::max(slots / std::max(W, 1), 1), cap);
+        d.Gextra = (d.Gbase < cap && slots > d.Gbase * W) ? std::min(slots - d.Gbase * W, W) : 0;
+        d.G = d.Gbase + (d.Gextra > 0 ? 1 : 0);
+    }
     d.big = d.nfree > BA_SMALL_MAXF;
     d.schurWaveLds = d.big ? 0 : ba_c_wave_lds(d.nfree);
     d.npairs = d.nfree * (d.nfree + 1) / 2;
@@ -1632,7 +1857,7 @@ static void ba_dims(BaDims& d, int W, const double K[4], int nkf, int nfixed, in
     d.oXp = take(std::max(64, d.np));
     d.oPartKF = take(27ull * std::max(d.nfree, 1) * d.kfChunks);
     d.oPartP = take(4ull * d.nblkP);
-    d.oPartS = take(d.big ? 0 : 4096ull * d.G);
+    d.oPartS = take(d.big ? 0 : 4096ull * 4 * d.G);
     d.oBigA = take(d.big ? (unsigned long long)(d.np + 1) * d.np + 32 : 0); /* + BA_PB: the last panel's row loads */
     d.wstride = o;
     unsigned long long io = 0;
@@ -1649,16 +1874,18 @@ static void ba_dims(BaDims& d, int W, const double K[4], int nkf, int nfixed, in
     d.oPermB = itake(d.big ? 0 : npt);
     d.oKPs = itake(d.big ? 0 : 4ull * obs_pitch);
     d.oGDesc = itake(d.big ? 0 : 4ull * npt + 4);
+    d.oGCost = itake(d.big ? 0 : (unsigned long long)npt + 1);
+    d.oGCut = itake(d.big ? 0 : 4ull * d.G + 1);
     d.oPairStart = itake(d.big ? d.npairs + 1 : 0);
     d.oPairCnt = itake(d.big ? d.npairs : 0);
     d.oPairItems = itake(d.big ? 2 * d.maxItems : 0);
     d.istride = io;
 }
 
-size_t tbk_local_ba_work_bytes(int W, int nkf, int nfixed, int npt, int obs_pitch) {
+size_t tbk_local_ba_work_bytes(const tb_ctx* ctx, int W, int nkf, int nfixed, int npt, int obs_pitch) {
     BaDims d;
     const double K[4] = {1, 1, 0, 0};
-    ba_dims(d, W, K, nkf, nfixed, npt, obs_pitch, 1);
+    ba_dims(d, ctx->num_cu, W, K, nkf, nfixed, npt, obs_pitch, 1);
     return (size_t)W * (d.wstride * sizeof(double) + d.istride * sizeof(int) + sizeof(BaState) + sizeof(int)) + 4096;
 }
 
@@ -1675,16 +1902,15 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
         return tb_fail(ctx, TB_EUNSUPPORTED, "local BA: large window with more than 2^31 / (free keyframes + 1) observations");
     if (iters > 99) return tb_fail(ctx, TB_EUNSUPPORTED, "local BA: more than 99 LM iterations (one still-running counter per trial, 1000 of them)");
     BaDims d;
-    ba_dims(d, W, K, nkf, nfixed, npt, obs_pitch, iters);
-    if (tbk_local_ba_work_bytes(W, nkf, nfixed, npt, obs_pitch) > work_bytes) return tb_fail(ctx, TB_ENOMEM, "local BA workspace too small");
+    ba_dims(d, ctx->num_cu, W, K, nkf, nfixed, npt, obs_pitch, iters);
+    if (tbk_local_ba_work_bytes(ctx, W, nkf, nfixed, npt, obs_pitch) > work_bytes) return tb_fail(ctx, TB_ENOMEM, "local BA workspace too small");
     char* base = (char*)d_work;
     double* dw = (double*)base;
     int* iw = (int*)(base + (size_t)W * d.wstride * sizeof(double));
     BaState* states = (BaState*)((char*)iw + (size_t)W * d.istride * sizeof(int));
     int* running = (int*)((char*)states + (size_t)W * sizeof(BaState));
     hipStream_t s = ctx->stream;
-    /* Schur kernel: four wavefronts' tiles, reused for the 64 x 64 sum of their accumulators */
-    const size_t schur_lds = std::max<size_t>(4 * (size_t)d.schurWaveLds, 64 * 64) * sizeof(double);
+    const size_t schur_lds = 4 * (size_t)d.schurWaveLds * sizeof(double); /* Schur kernel: four wavefronts' tiles */
     /* behind the states: one still-running counter per round (no memset node between the rounds), then one
      * rejected-input flag per window; zeroed together before the setup kernel */
     const int ring = 1000;

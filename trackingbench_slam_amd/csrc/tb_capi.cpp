@@ -128,6 +128,10 @@ int tb_create(int device, tb_ctx** out) {
     tb_ctx* ctx = new (std::nothrow) tb_ctx();
     if (!ctx) return TB_ENOMEM;
     ctx->device = device;
+    {
+        int ncu = 0;
+        if (hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && ncu > 0) ctx->num_cu = ncu;
+    }
     if (hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking) != hipSuccess) {
         delete ctx;
         return TB_EDEVICE;
@@ -1334,7 +1338,7 @@ int tb_local_ba_batch_dev(tb_ctx* ctx, int nwindows, const double K[4], int nkf,
         nfixed > nkf || iters < 0)
         return TB_EINVAL;
     if (nwindows == 0) return TB_OK;
-    const size_t wb = tbk_local_ba_work_bytes(nwindows, nkf, nfixed, npt, obs_pitch);
+    const size_t wb = tbk_local_ba_work_bytes(ctx, nwindows, nkf, nfixed, npt, obs_pitch);
     void* dwork;
     int rc = tb_scratch(ctx, 6, wb, &dwork);
     if (rc) return rc;

@@ -18,6 +18,7 @@
 
 struct tb_ctx {
     int device = 0;
+    int num_cu = 256;   /* compute units of the device (tb_create): launch shapes that aim at one resident round */
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::string err;
@@ -195,7 +196,7 @@ int tbk_pose_batch(tb_ctx* ctx, int nproblems, const double K[4], const float* T
 int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixed, float* d_poses, int npt, float* d_pts,
                        const tb_ba_obs* d_obs, const int32_t* d_counts, int obs_pitch, int iters, double* d_stats, void* d_work,
                        size_t work_bytes);
-size_t tbk_local_ba_work_bytes(int W, int nkf, int nfixed, int npt, int obs_pitch);
+size_t tbk_local_ba_work_bytes(const tb_ctx* ctx, int W, int nkf, int nfixed, int npt, int obs_pitch);
 int tbk_clahe(tb_ctx* ctx, int nimg, const uint8_t* d_src, int w, int h, int stride, size_t spitch, double clip_limit, int tiles_x,
               int tiles_y, uint8_t* d_dst, int dstride, size_t dpitch, uint8_t* d_lut);
 int tbk_flow_accept(tb_ctx* ctx, int npairs, const float* d_cur, uint8_t* d_status, const int32_t* d_counts, int pts_pitch, int width,
