@@ -37,6 +37,7 @@ from trackingbench_slam_amd import synth  # noqa: E402
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6.3 TB/s is the guide's achievable figure
 F64_MFMA_PEAK_TFLOPS = 78.6  # FP64 matrix peak = half the 157.3 TFLOP/s FP32 matrix peak of the guide's chip table
 KITTI_K = (718.856, 718.856, 607.1928, 185.2157)  # hard-coded in the reference, LocalBA.cpp:356-359
+KITTI_BF = 386.1448                                # fx * baseline of that camera (what AddMapPointsByStereo takes as bf)
 EXTRACTOR_KERNELS = ("k_resize", "k_fast_cells", "k_octree", "k_describe")
 
 
@@ -149,13 +150,14 @@ def cpu_model():
 
 def _cpu_frame(inp, args):
     import oracle
-    L, R, (_, Ti, obs), ba = inp
+    L, R, ba = inp
     lvL, sf = oracle.pyramid(L, args.levels, args.scale)
     lvR, _ = oracle.pyramid(R, args.levels, args.scale)
     k1, d1, _ = oracle.orb_extract(lvL, sf, args.target, args.init_th, args.min_th)
     k2, d2, _ = oracle.orb_extract(lvR, sf, args.target, args.init_th, args.min_th)
     m = oracle.search_by_bf(d1, d2, 10.0, 30.0)
-    oracle.pose_opt(KITTI_K, Ti, obs[:max(len(m), 0)])
+    obs = oracle.stereo_tracks_to_obs(k1, k2, m, KITTI_K, KITTI_BF, oracle.scale_factors(args.levels, args.scale)[3])
+    oracle.pose_opt(KITTI_K, np.eye(4, dtype=np.float32), obs)
     if ba is not None:
         Pt, Pi, Xt, Xi, bo = ba
         oracle.local_ba(KITTI_K, Pi, 2, Xi, bo, args.ba_iters)
@@ -172,7 +174,7 @@ def cpu_baseline(args, seconds=20.0):
     for i in range(4):  # input generation is not part of the path: prepared before the clock starts
         L, R = synth.frame(i, args.width, args.height, stereo=True)
         ba = None if args.no_ba else synth.ba_problem(i, args.ba_kf, args.ba_pts, KITTI_K)
-        inputs.append((L, R, synth.pose_problem(i, args.target + 100, KITTI_K), ba))
+        inputs.append((L, R, ba))
     budget = max(seconds / 2.0, 1.0)
     done, t0 = 0, time.perf_counter()
     while True:
@@ -211,23 +213,23 @@ def cpu_baseline(args, seconds=20.0):
 
 
 def measure_copy_bandwidth(dev, nbytes=1 << 30, reps=10):
-    """Device-to-device copy of `nbytes` (read + write = 2 x nbytes of HBM traffic per copy), HIP events on the copy's
-    stream: the MEASURED streaming bandwidth of this GPU, reported beside the 8 TB/s spec peak."""
+    """Device-to-device copy of `nbytes` (read + write = 2 x nbytes of HBM traffic per copy) with the library's own
+    16-byte-per-lane kernel (tb_measure_copy_seconds; HIP events on the context's stream): the MEASURED streaming bandwidth
+    of this GPU, comparable with the hardware guide's 6.29 TB/s float4 copy, reported beside the 8 TB/s spec peak.
+    Round 2 timed torch.Tensor.copy_ here (5.2 TB/s), which flattered every "fraction of the measured copy" by ~20 %."""
+    from trackingbench_slam_amd import capi
+    dev = torch.device("cuda", dev) if isinstance(dev, int) else dev
     st = torch.cuda.Stream(device=dev)
+    ctx = capi.Context(dev.index if dev.index is not None else 0, stream=st.cuda_stream)
     with torch.cuda.stream(st):
         a = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         b = torch.empty(nbytes, dtype=torch.uint8, device=dev)
         a.fill_(1)
-        b.copy_(a)
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record(st)
-        for _ in range(reps):
-            b.copy_(a)
-        e1.record(st)
-    e1.synchronize()
-    ms = e0.elapsed_time(e1) / reps
+    st.synchronize()
+    sec = ctx.measure_copy_seconds(a.data_ptr(), b.data_ptr(), nbytes, reps)
+    ctx.close()
     del a, b
-    return 2.0 * nbytes / 1e9 / (ms / 1e3)
+    return 2.0 * nbytes / 1e9 / sec
 
 
 # ------------------------------------------------------------------ launcher (python bench.py --gpus N, WORLD_SIZE unset)
@@ -602,8 +604,10 @@ def report(args, pipe, prof, el, world, n_joined, dev):
                                                args.init_th, args.min_th,
                                                "" if args.no_ba else ", %d-KF/%d-pt local BA x%d iters" %
                                                (args.ba_kf, args.ba_pts, args.ba_iters)),
-                   "composition": "independent stages on synthetic inputs: pose-opt runs a seeded synthetic problem truncated to "
-                                  "#matches rows, local BA runs seeded synthetic windows; neither consumes the extracted tracks",
+                   "composition": "extract -> searchByBF L<->R -> stereo depth of every matched key (bf / |dx|, LocalBA.cpp:60-64) -> "
+                                  "PoseOptimization from the identity on those tracks (map point = left key at its depth, observed "
+                                  "at the right key's pixel: it finds the right camera). Local BA runs seeded synthetic 10-keyframe "
+                                  "windows -- the reference has no multi-keyframe map to build them from (SURVEY D1)",
                    "frames_per_gpu_per_step": args.frames, "distinct_synthetic_pairs": min(args.distinct, args.frames),
                    "distinct_ba_windows": 0 if args.no_ba else min(args.ba_distinct, args.frames),
                    "ba_partitions": len(pipe.bas),

@@ -37,6 +37,13 @@ int tb_synchronize(tb_ctx* ctx);
  * figure needs the dominant kernel's average launch duration over the timed region). enable(1) resets the
  * accumulators; report() synchronises and writes one line per kernel: "name calls total_ms\n". */
 int tb_profile_enable(tb_ctx* ctx, int on);
+/* Measurement helper: copies `bytes` (a multiple of 16, 16-byte aligned device pointers) with a 16-byte-per-lane
+ * kernel and returns the average seconds per copy over `reps` (HIP events on the context's stream, one untimed copy first). The
+ * streaming bandwidth of the device is 2 * bytes / seconds. */
+int tb_measure_copy_seconds(tb_ctx* ctx, const void* d_src, void* d_dst, size_t bytes, int reps, double* seconds);
+/* Test hook: on != 0 sends every block of the cell-wise FAST kernel down its any-density path (no candidate lists; the
+ * results are the same). A context setting, not an environment variable: nothing outside the caller changes which kernels run. */
+int tb_debug_force_dense_fast(tb_ctx* ctx, int on);
 int tb_profile_report(tb_ctx* ctx, char* buf, int cap);
 
 /* ---------------------------------------------------------------- a1/a2/a3: host-side scalar set-up
@@ -202,6 +209,20 @@ int tb_search_by_violence_batch_dev(tb_ctx* ctx, int npairs, const tb_keypoint* 
                                     int min_level, int max_level, float radius, int th_low, float nratio, int histo_len,
                                     int check_orientation, tb_match* out, int cap, int32_t* out_counts, int32_t* flags);
 
+/* Stereo tracks -> PoseOptimization's inputs, batched and device-resident (round 3). For frame f and each of its
+ * match_counts[f] left <-> right matches (queryIdx = left key, trainIdx = right key; the output of
+ * tb_search_by_bf_batch_dev): Depth = bf / |x_right - x_left| (LocalBA::AddMapPointsByStereo, LocalBA.cpp:60-64), the map
+ * point = the left key back-projected with that depth (test/test_vo.cpp:257-267), observed at the right key's pixel with
+ * invSigma2[octave of the right key] (LocalBA.cpp:333-363) -- one tb_obs row per match, in match order; matches without
+ * disparity or with an octave outside the table are dropped. keys_left / keys_right: [nframes][key_pitch] records; K = fx, fy,
+ * cx, cy; inv_sigma2: nlevels floats (host; tb_scale_factors). obs [nframes][obs_pitch], obs_counts [nframes]. Device
+ * pointers except K / inv_sigma2; asynchronous on the context's stream. PoseOptimization started at the identity on these rows
+ * finds the right camera's pose. */
+int tb_stereo_tracks_to_obs_batch_dev(tb_ctx* ctx, int nframes, const tb_keypoint* keys_left, const tb_keypoint* keys_right,
+                                      int key_pitch, const tb_match* matches, const int32_t* match_counts, int match_pitch,
+                                      const float K[4], float bf, const float* inv_sigma2, int nlevels, tb_obs* obs, int obs_pitch,
+                                      int32_t* obs_counts);
+
 /* ---------------------------------------------------------------- pose optimisation / local BA
  * LocalBA::PoseOptimization, LocalBA.cpp:291-490. K = fx,fy,cx,cy. Tcw_in/out: row-major 4x4.
  * outlier: n in/out flags (Frame::GetOutlier/SetOutlier). *n_inliers = nInitialCorrespondences - nBad.
@@ -263,7 +284,8 @@ int tb_optical_flow_pyr_lk_batch_dev(tb_ctx* ctx, int npairs, const uint8_t* pre
  * tb_find_fundamental_ransac replaces cv::findFundamentalMat(pts1, pts2, cv::FM_RANSAC, thresh, conf, mask) as
  * Matcher::rejectWithF calls it (matcher.cpp:872): *ok = 1 and mask (n bytes) / F (9 doubles row-major, nullable) / *iters
  * (nullable: RANSAC iterations run) when a mask comes back, *ok = 0 when OpenCV returns none (fewer than 7 points, no model).
- * 8..14 points take OpenCV's LMedS branch: TB_EUNSUPPORTED. OpenCV 3.3 routine restated, PARITY UNPINNED: the sampling
+ * As in OpenCV, 8..14 points go to the LMedS registrator (fixed iteration count, smallest median error, inliers within
+ * sigma; *iters = its iteration count), 15 and more to RANSAC -- host and batched entry points alike. OpenCV 3.3 routines restated, PARITY UNPINNED: the sampling
  * (cv::RNG((uint64)-1), getSubset, collinearity retries), error measure, model update and iteration budget follow OpenCV's
  * structure; the 7-point solver's null space and cubic roots are computed with + - * / sqrt only (oracle/oracle_fund.cpp).
  * tb_reject_with_f replaces Matcher::rejectWithF(cur_pts, last_pts, status) (matcher.cpp:853-881): n (x, y) pairs each,
@@ -272,6 +294,12 @@ int tb_optical_flow_pyr_lk_batch_dev(tb_ctx* ctx, int npairs, const uint8_t* pre
 int tb_find_fundamental_ransac(tb_ctx* ctx, const float* pts1, const float* pts2, int n, double thresh, double conf, uint8_t* mask,
                                double* F, int* iters, int* ok);
 int tb_reject_with_f(tb_ctx* ctx, const float* cur_pts, const float* last_pts, int n, uint8_t* status);
+/* Batched, device-resident Matcher::rejectWithF: pair p has counts[p] keys (all pts_pitch of them when counts is null);
+ * cur_pts / last_pts [npairs][pts_pitch][2] floats, status [npairs][pts_pitch] in/out. One workgroup per pair; every pair
+ * takes the branch the host form takes for its number of tracked points (none / seven-point / LMedS / RANSAC).
+ * Asynchronous on the context's stream. */
+int tb_reject_with_f_batch_dev(tb_ctx* ctx, int npairs, const float* cur_pts, const float* last_pts, const int32_t* counts,
+                               int pts_pitch, uint8_t* status);
 /* LocalBA::AddMapPointsByStereo(current_frame, stereo_frame, bf, fx), LocalBA.cpp:46-68: searchByOPFlow(stereo, current,
  * pts, equalized = true, reject = true), then depth[i] = bf / fabsf(pts[i].x - key[i].x) for the surviving keys i of the
  * current frame and -1 for the others (fx is unused by the reference; its drawing and imshow are dropped). img_stereo /

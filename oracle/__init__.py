@@ -325,6 +325,18 @@ def search_by_projection_map(Tcw1, cam1, img1_w, img1_h, k1, d1, taken1, mps, mp
     return out[:n].copy()
 
 
+def stereo_tracks_to_obs(kl, kr, matches, K, bf, inv_sigma2):
+    """The composition of the timed configuration: left <-> right matches -> PoseOptimization rows (stereo depth of the left key,
+    LocalBA.cpp:60-64, observed at the right key's pixel, LocalBA.cpp:333-363)."""
+    kl = np.ascontiguousarray(kl, KEYPOINT); kr = np.ascontiguousarray(kr, KEYPOINT)
+    m = np.ascontiguousarray(matches, MATCH)
+    Kf = np.ascontiguousarray(K, np.float32)
+    sig = np.ascontiguousarray(inv_sigma2, np.float32)
+    out = np.zeros(max(len(m), 1), OBS)
+    n = _chk(lib().orc_stereo_tracks_to_obs(_p(kl), _p(kr), _p(m), len(m), _p(Kf), C.c_float(bf), _p(sig), len(sig), _p(out), len(out)))
+    return out[:n].copy()
+
+
 def pose_opt(K, Tcw, obs, outlier=None):
     K = np.ascontiguousarray(K, np.float64)
     Tcw = np.ascontiguousarray(Tcw, np.float32).reshape(16)
@@ -398,7 +410,7 @@ def find_fundamental_ransac(pts1, pts2, thresh=1.0, conf=0.99):
     it = C.c_int(0)
     rc = lib().orc_find_fundamental_ransac(_p(p1), _p(p2), n, C.c_double(thresh), C.c_double(conf), _p(mask), _p(F), C.byref(it))
     if rc < 0:
-        raise OracleError("find_fundamental_ransac: %d points take OpenCV's LMedS branch (not restated)" % n)
+        raise OracleError("find_fundamental_ransac: error %d" % rc)
     return rc, mask[:n], F.reshape(3, 3), it.value
 
 
@@ -410,7 +422,7 @@ def reject_with_f(cur_pts, last_pts, status):
     assert len(cur) == len(last) == len(st)
     rc = lib().orc_reject_with_f(_p(cur), _p(last), len(st), _p(st))
     if rc < 0:
-        raise OracleError("reject_with_f: LMedS branch (8..14 tracked points) not restated")
+        raise OracleError("reject_with_f: error %d" % rc)
     return st
 
 

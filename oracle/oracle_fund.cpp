@@ -16,7 +16,7 @@
  *   - run7Point: the 7 x 9 epipolar system, its two-dimensional null space {f1, f2}, det(lambda f1 + (1 - lambda) f2) = 0
  *     as a cubic in lambda, F scaled to F[8] = 1;
  *   - findFundamentalMat's dispatch: fewer than 7 points -> nothing; exactly 7 -> the 7-point solver, every point an
- *     inlier; 8..14 -> OpenCV switches to LMedS (not restated: reported as unsupported); 15 and more -> RANSAC.
+ *     inlier; 8..14 -> LMeDSPointSetRegistrator (restated in round 3, see orc_find_fundamental_ransac); 15 and more -> RANSAC.
  * Two numerical routines are NOT OpenCV's, on purpose: they are built from + - * / sqrt only, so that the HIP kernel
  * reproduces them bit for bit (libm's acos / cos / pow differ between host and device):
  *   - the null space comes from Gauss-Jordan elimination with row pivoting (OpenCV: Jacobi SVD whose last two right
@@ -180,7 +180,7 @@ int run_7point(const float* m1, const float* m2, double* F) {
 }
 
 /* FMEstimatorCallback::computeError + findInliers for one model */
-int find_inliers(const float* m1, const float* m2, int n, const double* F, float t, uint8_t* mask) {
+int find_inliers(const float* m1, const float* m2, int n, const double* F, float t, uint8_t* mask, float* errs = nullptr) {
     int good = 0;
     for (int i = 0; i < n; i++) {
         const double x1 = m1[2 * i], y1 = m1[2 * i + 1], x2 = m2[2 * i], y2 = m2[2 * i + 1];
@@ -189,7 +189,8 @@ int find_inliers(const float* m1, const float* m2, int n, const double* F, float
         a = F[0] * x2 + F[3] * y2 + F[6]; b = F[1] * x2 + F[4] * y2 + F[7]; c = F[2] * x2 + F[5] * y2 + F[8];
         const double s1 = 1. / (a * a + b * b), d1 = x1 * a + y1 * b + c;
         const double e1 = d1 * d1 * s1, e2 = d2 * d2 * s2;
-        const float err = (float)(e1 > e2 ? e1 : e2);
+        const float err = (float)std::max(e1, e2);  /* std::max(a, b) = (a < b) ? b : a: decides the NaN cases */
+        if (errs) errs[i] = err;
         const int f = err <= t;
         mask[i] = (uint8_t)f;
         good += f;
@@ -218,7 +219,7 @@ extern "C" {
 
 /* cv::findFundamentalMat(pts1, pts2, FM_RANSAC, thresh, conf, mask): returns 1 and fills mask (n bytes) / F (9 doubles,
  * nullable) / *iters (nullable: RANSAC iterations executed) when a mask comes back, 0 when OpenCV returns none (fewer than
- * 7 points, or no model), -2 for 8..14 points (OpenCV's LMedS branch, not restated). */
+ * 7 points, or no model). 8..14 points: the LMedS registrator, 15 and more: RANSAC, as fundam.cpp dispatches. */
 int orc_find_fundamental_ransac(const float* pts1, const float* pts2, int n, double thresh, double conf, uint8_t* mask, double* Fout,
                                 int* iters) {
     if (iters) *iters = 0;
@@ -231,13 +232,18 @@ int orc_find_fundamental_ransac(const float* pts1, const float* pts2, int n, dou
         if (Fout) memcpy(Fout, F, 9 * sizeof(double));
         return 1;
     }
-    if (n < 15) return -2;
     if (thresh <= 0) thresh = 3;
     if (conf < DBL_EPSILON || conf > 1 - DBL_EPSILON) conf = 0.99;
     const float t = (float)(thresh * thresh);
     CvRng rng((uint64_t)-1);
-    int niters = 1000, maxGood = 0, iter = 0;
+    /* fundam.cpp: RANSAC needs 15 points; 8..14 go to LMeDSPointSetRegistrator(cb, 7, conf, 1000)::run -- the same getSubset /
+     * runKernel, a fixed number of iterations, the model with the smallest median error (errors converted to float and
+     * sorted as integers; an even count averages the two middle floats), then inliers within sigma */
+    const bool lmeds = n < 15;
+    int niters = lmeds ? std::max(update_num_iters(conf, 0.45, 7, 1000), 3) : 1000, maxGood = 0, iter = 0;
+    double minMedian = DBL_MAX;
     std::vector<uint8_t> cur(n), best(n, 0);
+    std::vector<float> errs(n);
     double bestF[9] = {0};
     float ms1[14], ms2[14];
     int idx[7];
@@ -268,6 +274,16 @@ int orc_find_fundamental_ransac(const float* pts1, const float* pts2, int n, dou
         const int nm = run_7point(ms1, ms2, F);
         if (nm <= 0) continue;
         for (int k = 0; k < nm; k++) {
+            if (lmeds) {
+                find_inliers(pts1, pts2, n, F + 9 * k, t, cur.data(), errs.data());
+                std::vector<int32_t> bits(n);
+                memcpy(bits.data(), errs.data(), (size_t)n * 4);
+                std::sort(bits.begin(), bits.end());          /* std::sort(errf.ptr<int>(), errf.ptr<int>() + count) */
+                memcpy(errs.data(), bits.data(), (size_t)n * 4);
+                const double median = n % 2 != 0 ? (double)errs[n / 2] : (double)(errs[n / 2 - 1] + errs[n / 2]) * 0.5;
+                if (median < minMedian) { minMedian = median; memcpy(bestF, F + 9 * k, sizeof bestF); }
+                continue;
+            }
             const int good = find_inliers(pts1, pts2, n, F + 9 * k, t, cur.data());
             if (good > std::max(maxGood, 6)) {
                 std::swap(cur, best);
@@ -278,6 +294,14 @@ int orc_find_fundamental_ransac(const float* pts1, const float* pts2, int n, dou
         }
     }
     if (iters) *iters = iter;
+    if (lmeds) {
+        if (!(minMedian < DBL_MAX)) return 0;
+        double sigma = 2.5 * 1.4826 * (1 + 5. / (n - 7)) * sqrt(minMedian);
+        sigma = sigma > 0.001 ? sigma : 0.001;
+        find_inliers(pts1, pts2, n, bestF, (float)(sigma * sigma), mask);
+        if (Fout) memcpy(Fout, bestF, sizeof bestF);
+        return 1;
+    }
     if (maxGood <= 0) return 0;
     memcpy(mask, best.data(), n);
     if (Fout) memcpy(Fout, bestF, sizeof bestF);
@@ -285,7 +309,7 @@ int orc_find_fundamental_ransac(const float* pts1, const float* pts2, int n, dou
 }
 
 /* Matcher::rejectWithF (matcher.cpp:853-881): status[i] of the n keys; cur / last: n (x, y) pairs. Returns the number of
- * flags cleared, or -2 (8..14 tracked points: LMedS, not restated; flags untouched). */
+ * flags cleared. */
 int orc_reject_with_f(const float* cur_pts, const float* last_pts, int n, uint8_t* status) {
     std::vector<int> id;
     std::vector<float> p1, p2;
@@ -299,7 +323,6 @@ int orc_reject_with_f(const float* cur_pts, const float* last_pts, int n, uint8_
     const int m = (int)id.size();
     std::vector<uint8_t> fund(m > 0 ? m : 1, 1);
     const int rc = orc_find_fundamental_ransac(p1.data(), p2.data(), m, 1.0, 0.99, fund.data(), nullptr, nullptr);
-    if (rc == -2) return -2;
     if (rc != 1) return 0;                       /* no mask came back */
     int cleared = 0;
     for (int i = 0; i < m; i++)

@@ -482,4 +482,27 @@ int orc_search_by_bow(const tb_keypoint* k1, const uint8_t* d1, int n1, const ui
     return (int)good.size();
 }
 
+
+/* Stereo tracks -> PoseOptimization's inputs (the composition bench.py times; see k_stereo_obs in k_match.hip): per left <->
+ * right match Depth = bf / |x_right - x_left| (LocalBA.cpp:60-64), X = ((x - cx) / fx, (y - cy) / fy, 1) * Depth of the LEFT key
+ * (test/test_vo.cpp:257-267), observed at the RIGHT key's pixel with invSigma2[octave] (LocalBA.cpp:333-363). Rows in match
+ * order; matches without disparity or with an octave outside the table are dropped. Returns the number of rows. */
+int orc_stereo_tracks_to_obs(const tb_keypoint* kl, const tb_keypoint* kr, const tb_match* matches, int nmatches, const float K[4],
+                             float bf, const float* inv_sigma2, int nlevels, tb_obs* obs, int cap) {
+    int n = 0;
+    for (int i = 0; i < nmatches; i++) {
+        const tb_keypoint a = kl[matches[i].queryIdx], b = kr[matches[i].trainIdx];
+        const float depth = bf / fabsf(b.x - a.x);
+        const float nx = (a.x - K[2]) / K[0], ny = (a.y - K[3]) / K[1];
+        if (!std::isfinite(depth) || b.octave < 0 || b.octave >= nlevels) continue;
+        if (n >= cap) break;
+        tb_obs o;
+        o.u = b.x; o.v = b.y;
+        o.X = nx * depth; o.Y = ny * depth; o.Z = depth;
+        o.inv_sigma2 = inv_sigma2[b.octave];
+        obs[n++] = o;
+    }
+    return n;
+}
+
 }  // extern "C"

@@ -296,12 +296,14 @@ def test_orb_extract_aligned_device_frames_with_padding(ctx):
     ex.close()
 
 
-def test_cell_candidates_forced_dense_path(ctx, kitti_pair, monkeypatch):
-    """TB_FAST_DENSE=1 sends every block down the list-free path: it must reproduce the ordinary path's output."""
-    monkeypatch.setenv("TB_FAST_DENSE", "1")
-    _cand_vs_oracle(ctx, kitti_pair[0], 5, 0.8, 80, 30)
-    _cand_vs_oracle(ctx, synth.frame(68, 640, 480), 8, 0.8, 20, 7)
-    monkeypatch.delenv("TB_FAST_DENSE")
+def test_cell_candidates_forced_dense_path(ctx, kitti_pair):
+    """tb_debug_force_dense_fast sends every block down the list-free path: it must reproduce the ordinary path's output."""
+    ctx.force_dense_fast(True)
+    try:
+        _cand_vs_oracle(ctx, kitti_pair[0], 5, 0.8, 80, 30)
+        _cand_vs_oracle(ctx, synth.frame(68, 640, 480), 8, 0.8, 20, 7)
+    finally:
+        ctx.force_dense_fast(False)
     _cand_vs_oracle(ctx, kitti_pair[0], 5, 0.8, 80, 30)
 
 

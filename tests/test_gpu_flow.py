@@ -182,9 +182,42 @@ def test_find_fundamental_dispatch(ctx):
     ok, mask, F, _ = ctx.find_fundamental_ransac(p1[:7], p2[:7])
     oko, masko, Fo, _ = oracle.find_fundamental_ransac(p1[:7], p2[:7])
     assert ok == oko and np.array_equal(mask, masko) and (not ok or np.array_equal(F.view(np.uint64), Fo.view(np.uint64)))
-    with pytest.raises(capi.TBError) as e:
-        ctx.find_fundamental_ransac(p1[:12], p2[:12])
-    assert e.value.code == capi.TB_EUNSUPPORTED
+    for n in range(8, 15):  # 8..14 points: cv::findFundamentalMat's LMedS branch (fixed 300 iterations at conf 0.99)
+        ok, mask, F, it = ctx.find_fundamental_ransac(p1[:n], p2[:n])
+        oko, masko, Fo, ito = oracle.find_fundamental_ransac(p1[:n], p2[:n])
+        assert ok == oko == 1 and it == ito == 300
+        assert np.array_equal(mask, masko) and np.array_equal(F.view(np.uint64), Fo.view(np.uint64))
+
+
+@pytest.mark.parametrize("n,seed,outliers,noise", [(8, 21, 0, 0.0), (9, 22, 2, 0.3), (11, 23, 3, 0.2), (13, 24, 0, 0.5), (14, 25, 4, 0.1), (14, 26, 0, 0.0)])
+def test_find_fundamental_lmeds_vs_oracle(ctx, n, seed, outliers, noise):
+    """8..14 points: LMeDSPointSetRegistrator::run restated (oracle_fund.cpp) -- mask, matrix and iteration count bit for bit."""
+    p1, p2 = _stereo_pts(n, seed, outliers, noise)
+    ok, mask, F, it = oracle.find_fundamental_ransac(p1, p2)
+    okg, maskg, Fg, itg = ctx.find_fundamental_ransac(p1, p2)
+    assert okg == ok and itg == it and np.array_equal(maskg, mask)
+    if ok:
+        assert np.array_equal(Fg.view(np.uint64), F.view(np.uint64))
+
+
+def test_reject_with_f_batch_pair_in_the_lmeds_range(ctx):
+    """A batch whose pairs have 5, 7, 11, 14, 15 and 300 tracked points: every pair takes the branch the host form takes
+    (the batched path used to leave 8..14-point pairs unfiltered without saying so)."""
+    import torch
+    dev = torch.device("cuda", 0)
+    live = [5, 7, 11, 14, 15, 300]
+    npts = 320
+    cur = np.zeros((len(live), npts, 2), np.float32)
+    keys = np.zeros((len(live), npts, 2), np.float32)
+    status = np.zeros((len(live), npts), np.uint8)
+    for i, m in enumerate(live):
+        p1, p2 = _stereo_pts(npts, 40 + i, outliers=npts // 5, noise=0.2)
+        cur[i], keys[i] = p1, p2
+        status[i, np.random.default_rng(i).permutation(npts)[:m]] = 1
+    exp = np.stack([oracle.reject_with_f(cur[i], keys[i], status[i]) for i in range(len(live))])
+    got = ctx.reject_with_f_batch(torch.from_numpy(cur).to(dev), torch.from_numpy(keys).to(dev), torch.from_numpy(status).to(dev))
+    assert np.array_equal(got.cpu().numpy(), exp)
+    assert (exp[2] != status[2]).any() or (exp[3] != status[3]).any() or True  # the LMedS pairs may or may not lose points
 
 
 def test_reject_with_f_vs_oracle(ctx):

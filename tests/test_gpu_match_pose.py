@@ -1,5 +1,7 @@
 """GPU parity tests (pytest -m gpu): Hamming matchers (bit-exact) and pose optimisation (1e-6 relative,
 the tolerance BASELINE.json's north_star states for BA pose / reprojection error)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 
@@ -160,3 +162,59 @@ def test_search_by_bow_edges(ctx):
     with pytest.raises(capi.TBError):                                           # a feature index outside the frame
         bad = dict(fv1); bad[next(iter(bad))] = [10 ** 6]
         ctx.search_by_bow(k1, d1, bad, k2, d2, fv2, **kw)
+
+
+def test_pose_from_stereo_tracks_finds_the_baseline(ctx):
+    """tb_stereo_tracks_to_obs_batch_dev + PoseOptimization from the identity, the composition bench.py times: keys of a left
+    frame with known depths, their right-frame images one baseline along x (plus pixel noise and a few gross mismatches), a
+    match per key -> observation rows == oracle bit for bit, ragged counts, dropped zero-disparity rows, and the pose found
+    from them is the right camera's (t = -baseline along x)."""
+    import torch
+    from trackingbench_slam_amd.pipeline import KITTI_BF, KITTI_K
+    dev = torch.device("cuda", 0)
+    fx, fy, cx, cy = KITTI_K
+    F, cap = 3, 700
+    isig2 = oracle.scale_factors(8, 0.8)[3]
+    rng = np.random.default_rng(17)
+    KL = np.zeros((F, cap), capi.KEYPOINT); KR = np.zeros((F, cap), capi.KEYPOINT)
+    M = np.zeros((F, cap), capi.MATCH); MC = np.zeros(F, np.int32)
+    for f, n in enumerate((600, 257, 2)):
+        depth = rng.uniform(6.0, 60.0, n).astype(np.float32)
+        KL[f, :n]["x"] = rng.uniform(100, 1100, n); KL[f, :n]["y"] = rng.uniform(40, 340, n)
+        KL[f, :n]["octave"] = rng.integers(0, 8, n)
+        KR[f, :n] = KL[f, :n]
+        KR[f, :n]["x"] = KL[f, :n]["x"] - np.float32(KITTI_BF) / depth + rng.normal(0, 0.3, n).astype(np.float32)
+        KR[f, :n]["y"] = KL[f, :n]["y"] + rng.normal(0, 0.3, n).astype(np.float32)
+        bad = rng.permutation(n)[:n // 12]
+        KR["y"][f, bad] += 40.0                                   # gross mismatches: pose-opt must flag them
+        perm = rng.permutation(n)                                 # matches in an order of their own, right keys shuffled
+        inv = np.argsort(perm)
+        KR[f, :n] = KR[f, :n][perm]
+        M[f, :n]["queryIdx"] = np.arange(n); M[f, :n]["trainIdx"] = inv; M[f, :n]["imgIdx"] = -1
+        if n > 10:
+            KR[f, inv[5]]["x"] = KL[f, 5]["x"]                    # no disparity: the row is dropped
+        MC[f] = n
+    t = lambda a, dt: torch.from_numpy(a.view(dt).reshape(F, cap, -1)).to(dev)
+    dKL, dKR, dM = t(KL, np.float32), t(KR, np.float32), t(M, np.int32)
+    dMC = torch.from_numpy(MC).to(dev)
+    obs = torch.zeros((F, cap, 6), dtype=torch.float32, device=dev)
+    oc = torch.zeros(F, dtype=torch.int32, device=dev)
+    Kf = np.ascontiguousarray(KITTI_K, np.float32)
+    L = capi.lib()
+    ctx.check(L.tb_stereo_tracks_to_obs_batch_dev(ctx._h, F, C.c_void_p(dKL.data_ptr()), C.c_void_p(dKR.data_ptr()), cap,
+                                                  C.c_void_p(dM.data_ptr()), C.c_void_p(dMC.data_ptr()), cap,
+                                                  Kf.ctypes.data_as(C.c_void_p), C.c_float(KITTI_BF), isig2.ctypes.data_as(C.c_void_p), 8,
+                                                  C.c_void_p(obs.data_ptr()), cap, C.c_void_p(oc.data_ptr())))
+    ctx.synchronize()
+    for f in range(F):
+        n = int(MC[f])
+        exp = oracle.stereo_tracks_to_obs(KL[f], KR[f], M[f, :n], KITTI_K, KITTI_BF, isig2)
+        assert int(oc[f].item()) == len(exp) == (n - 1 if n > 10 else n)
+        got = obs[f, :len(exp)].cpu().numpy().reshape(-1).view(capi.OBS)
+        assert np.array_equal(got, exp)
+        ninl, T, outl, _ = ctx.pose_opt(KITTI_K, np.eye(4, dtype=np.float32), got)
+        no, To, oo, _ = oracle.pose_opt(KITTI_K, np.eye(4, dtype=np.float32), exp)
+        assert ninl == no and np.array_equal(outl, oo) and np.allclose(T, To, rtol=1e-6, atol=1e-6)
+        if n > 10:
+            assert abs(T[0, 3] + KITTI_BF / fx) < 0.02 and np.abs(T[:3, :3] - np.eye(3)).max() < 5e-3
+            assert n // 12 <= outl.sum() < n // 6

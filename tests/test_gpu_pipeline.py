@@ -32,9 +32,11 @@ def test_pipeline_matches_oracle_720p():
         assert np.array_equal(kr, kro) and np.array_equal(dr, dro)
         mo = oracle.search_by_bf(do, dro, 10.0, 30.0)
         assert np.array_equal(m, mo)
-        _, Ti, obs = synth.pose_problem(5 * 1000 + f, p.kp_cap, KITTI_K)
-        n, To, oo, _ = oracle.pose_opt(KITTI_K, Ti, obs[:len(mo)])
-        assert ninl == n and np.array_equal(outl[:len(mo)], oo)
+        from trackingbench_slam_amd.pipeline import KITTI_BF
+        obs = oracle.stereo_tracks_to_obs(ko, kro, mo, KITTI_K, KITTI_BF, oracle.scale_factors(8, 0.8)[3])
+        assert np.array_equal(p.obs[f, :len(obs)].cpu().numpy().reshape(-1).view(capi.OBS), obs)
+        n, To, oo, _ = oracle.pose_opt(KITTI_K, np.eye(4, dtype=np.float32), obs)
+        assert ninl == n and np.array_equal(outl[:len(obs)], oo)
         assert np.allclose(T, To, rtol=1e-6, atol=1e-6)
     # track records copied for the gather
     import torch

@@ -29,6 +29,17 @@ def _close(a, b, tol=1e-6):
     assert np.allclose(a, b, rtol=tol, atol=tol * max(1.0, float(np.abs(b).max()))), float(np.abs(a - b).max())
 
 
+
+
+def _oracle_pose_from_tracks(ko, kro, mo):
+    """The timed configuration's pose stage on the CPU: left <-> right matches -> stereo-depth observations -> PoseOptimization
+    from the identity (the composition of pipeline.TrackingPipeline.extract_chain)."""
+    from trackingbench_slam_amd.pipeline import KITTI_BF, KITTI_K
+    obs = oracle.stereo_tracks_to_obs(ko, kro, mo, KITTI_K, KITTI_BF, oracle.scale_factors(8, 0.8)[3])
+    n, To, oo, _ = oracle.pose_opt(KITTI_K, np.eye(4, dtype=np.float32), obs)
+    return obs, n, To, oo
+
+
 def _check_pipeline(p, L, R, seed, oracle_cache):
     from trackingbench_slam_amd.pipeline import KITTI_K
     F = p.F
@@ -40,16 +51,21 @@ def _check_pipeline(p, L, R, seed, oracle_cache):
             ko, do, _ = oracle.orb_extract(lvL, sf, 2000, 80, 30)
             kro, dro, _ = oracle.orb_extract(lvR, sf, 2000, 80, 30)
             mo = oracle.search_by_bf(do, dro, 10.0, 30.0)
-            _, Ti, obs = synth.pose_problem(seed * 1000 + f, p.kp_cap, KITTI_K)
-            n, To, oo, _ = oracle.pose_opt(KITTI_K, Ti, obs[:len(mo)])
-            oracle_cache[f] = (ko, do, kro, dro, mo, n, To, oo)
-        ko, do, kro, dro, mo, n, To, oo = oracle_cache[f]
+            obs, n, To, oo = _oracle_pose_from_tracks(ko, kro, mo)
+            oracle_cache[f] = (ko, do, kro, dro, mo, n, To, oo, obs)
+        ko, do, kro, dro, mo, n, To, oo, obs = oracle_cache[f]
         _eq_struct(kl, ko); _eq_struct(kr, kro)
         assert np.array_equal(dl, do) and np.array_equal(dr, dro)
         _eq_struct(m, mo)
-        assert ninl == n and np.array_equal(outl[:len(mo)], oo)
-        assert not outl[len(mo):].any()          # flags beyond the problem's rows stay clear from step to step
+        # the observations are the tracks': bit for bit the oracle's rows, and the pose found from them
+        assert int(p.obs_counts[f].item()) == len(obs)
+        assert np.array_equal(p.obs[f, :len(obs)].cpu().numpy().reshape(-1).view(capi.OBS), obs)
+        assert ninl == n and np.array_equal(outl[:len(obs)], oo)
+        assert not outl[len(obs):].any()          # flags beyond the problem's rows stay clear from step to step
         _close(T, To)
+        # (searchByBF's filter d < min(ratio * d_min, minTh) keeps few pairs of these synthetic frames: a rectangle copied
+        # with its disparity matches itself exactly, d_min = 0. The geometry of the composition -- the right camera sits one
+        # baseline along -x -- has its own test on dense tracks: test_pose_from_stereo_tracks_finds_the_baseline.)
         # the records handed to the exchange step are the same data
         n0 = int(p.trk_counts[f].item())
         assert n0 == len(kl)
@@ -122,9 +138,8 @@ def test_pipeline_batches_of_64_images_and_more():
         _eq_struct(kl, ko); _eq_struct(kr, kro)
         assert np.array_equal(dl, do) and np.array_equal(dr, dro)
         _eq_struct(m, mo)
-        _, Ti, obs = synth.pose_problem(seed * 1000 + f, p.kp_cap, KITTI_K)
-        n, To, oo, _ = oracle.pose_opt(KITTI_K, Ti, obs[:len(mo)])
-        assert ninl == n and np.array_equal(outl[:len(mo)], oo)
+        obs, n, To, oo = _oracle_pose_from_tracks(ko, kro, mo)
+        assert ninl == n and np.array_equal(outl[:len(obs)], oo)
         _close(T, To)
     cache = {}
     for ba, _, _ in p.bas:

@@ -89,7 +89,7 @@ def main():
         if not (ro[0] == rg[0] and ro[3] == rg[3] and np.array_equal(ro[1], rg[1]) and (not ro[0] or np.array_equal(ro[2].view(np.uint64), rg[2].view(np.uint64)))):
             fail("find_fundamental_ransac", n=nr_, nbad=nbad, iters=(rg[3], ro[3]), inliers=(int(rg[1].sum()), int(ro[1].sum())))
         st = (rng.uniform(size=nr_) < 0.8).astype(np.uint8)
-        if st.sum() >= 15 or st.sum() <= 7:
+        if True:
             if not np.array_equal(ctx.reject_with_f(p2, p1, st), oracle.reject_with_f(p2, p1, st)):
                 fail("reject_with_f", n=nr_, live=int(st.sum()))
         if len(k1) >= 40 and it % 2 == 0:   # the whole optical-flow matcher with the RANSAC stage, and the stereo depths

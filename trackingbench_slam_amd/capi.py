@@ -28,7 +28,7 @@ TB_OK, TB_EINVAL, TB_ENOMEM, TB_ECAPACITY, TB_EUNSUPPORTED, TB_EDEVICE, TB_ESTAT
 # every symbol include/tb_capi.h declares (checked by tests/test_capi_exports.py)
 EXPORTS = [
     "tb_create", "tb_destroy", "tb_last_error", "tb_strerror", "tb_version", "tb_set_stream", "tb_synchronize",
-    "tb_profile_enable", "tb_profile_report",
+    "tb_profile_enable", "tb_profile_report", "tb_debug_force_dense_fast", "tb_measure_copy_seconds",
     "tb_scale_factors", "tb_pyramid_sizes", "tb_orb_quotas",
     "tb_extractor_create", "tb_extractor_destroy", "tb_extractor_set_images_host", "tb_extractor_set_images_dev",
     "tb_extractor_set_levels_host", "tb_extractor_build_pyramid", "tb_extractor_get_level_host", "tb_extractor_orb",
@@ -38,9 +38,9 @@ EXPORTS = [
     "tb_descriptor_distance", "tb_three_maxima", "tb_match_bf", "tb_search_by_bf", "tb_search_by_bf_batch_dev",
     "tb_search_by_violence", "tb_search_by_bow", "tb_search_by_projection", "tb_search_by_projection_map", "tb_frame_grid_batch_dev",
     "tb_search_by_projection_batch_dev", "tb_search_by_projection_map_batch_dev",
-    "tb_search_by_violence_batch_dev", "tb_pose_opt", "tb_pose_opt_batch_dev", "tb_local_ba", "tb_local_ba_batch_dev",
+    "tb_search_by_violence_batch_dev", "tb_stereo_tracks_to_obs_batch_dev", "tb_pose_opt", "tb_pose_opt_batch_dev", "tb_local_ba", "tb_local_ba_batch_dev",
     "tb_clahe", "tb_clahe_dev", "tb_optical_flow_pyr_lk", "tb_optical_flow_pyr_lk_dev", "tb_optical_flow_pyr_lk_batch_dev", "tb_search_by_opflow", "tb_search_by_opflow_batch_dev",
-    "tb_find_fundamental_ransac", "tb_reject_with_f", "tb_add_map_points_by_stereo", "tb_add_map_points_by_stereo_batch_dev",
+    "tb_find_fundamental_ransac", "tb_reject_with_f", "tb_reject_with_f_batch_dev", "tb_add_map_points_by_stereo", "tb_add_map_points_by_stereo_batch_dev",
     "tb_batch_run",
 ]
 
@@ -205,6 +205,16 @@ class Context:
 
     def profile_enable(self, on=True):
         self.check(lib().tb_profile_enable(self._h, int(on)))
+
+    def measure_copy_seconds(self, src_ptr, dst_ptr, nbytes, reps=10):
+        """Average seconds per device-to-device copy of nbytes with the library's 16-byte-per-lane kernel."""
+        sec = C.c_double(0)
+        self.check(lib().tb_measure_copy_seconds(self._h, C.c_void_p(src_ptr), C.c_void_p(dst_ptr), C.c_size_t(nbytes), int(reps), C.byref(sec)))
+        return sec.value
+
+    def force_dense_fast(self, on=True):
+        """Test hook: every FAST block takes the any-density path (same results)."""
+        self.check(lib().tb_debug_force_dense_fast(self._h, int(on)))
 
     def profile_report(self):
         """{kernel name: (calls, total_ms)} accumulated since profile_enable(True)."""
@@ -422,6 +432,17 @@ class Context:
         assert len(cur) == len(last) == len(st)
         self.check(lib().tb_reject_with_f(self._h, _p(cur), _p(last), len(st), _p(st)))
         return st
+
+    def reject_with_f_batch(self, cur, last, status, counts=None):
+        """tb_reject_with_f_batch_dev on torch tensors of this context's device: cur / last float32 [P, N, 2], status uint8
+        [P, N] (updated in place and returned), counts int32 [P] or None. Asynchronous on the context's stream."""
+        P, N = status.shape
+        assert cur.shape == (P, N, 2) and last.shape == (P, N, 2) and cur.is_contiguous() and last.is_contiguous() and status.is_contiguous()
+        self.check(lib().tb_reject_with_f_batch_dev(self._h, P, C.c_void_p(cur.data_ptr()), C.c_void_p(last.data_ptr()),
+                                                    C.c_void_p(counts.data_ptr()) if counts is not None else None, N,
+                                                    C.c_void_p(status.data_ptr())))
+        self.synchronize()
+        return status
 
     def add_map_points_by_stereo(self, img_stereo, img_current, cam_stereo, keys_xy, bf):
         """LocalBA::AddMapPointsByStereo(current_frame, stereo_frame, bf, fx) (reference LocalBA.cpp:46-68): depth per key."""

@@ -793,9 +793,8 @@ int tbk_fast_cells(tb_extractor* ex, int n, int init_th, int min_th) {
     const int by_image = n >= 64 ? 1 : 0;
     const dim3 grid = by_image ? dim3((unsigned)ex->nBlocksTotal * 8u * (unsigned)((n + 7) / 8)) : dim3(ex->nBlocksTotal, n);
     static_assert(FB_LDS_BYTES - FB_PAD_LDS <= 32 * 1024, "five blocks per CU");
-    /* test hook: TB_FAST_DENSE=1 sends every block down the any-density path (same results, no lists) */
-    const char* fd_env = getenv("TB_FAST_DENSE");
-    const int force_dense = (fd_env && fd_env[0] == '1') ? 1 : 0;
+    /* test hook (tb_debug_force_dense_fast): every block down the any-density path (same results, no lists) */
+    const int force_dense = ctx->dbg_fast_dense;
     tb_prof_begin(ctx, "k_fast_cells");
     hipLaunchKernelGGL(k_fast_blocks, grid, dim3(FB_NT), FB_LDS_BYTES, ctx->stream, ex->g, ex->d_slab, ex->d_blocks, ex->nBlocksTotal,
                        n, by_image, ex->d_cand, ex->d_candCount, init_th, min_th, force_dense);

@@ -846,3 +846,64 @@ int tbk_bow_search(tb_ctx* ctx, int nq, const void* d_queries, const uint8_t* d_
     TB_HIP(ctx, hipGetLastError());
     return TB_OK;
 }
+
+/* ---- stereo tracks -> pose-optimisation observations (round 3; SURVEY 3.5 / LocalBA.cpp:46-68, :333-363).
+ * The reference's per-frame flow is stereo depth -> map points -> PoseOptimization (test/test_vo.cpp:716,761,800): a key of
+ * the current frame gets Depth = bf / |x_other - x_key| (LocalBA.cpp:60-64), the test back-projects it through the pinhole
+ * model (test_vo.cpp:257-267: norm = ((u - cx) / fx, (v - cy) / fy, 1), X = norm * depth), and PoseOptimization reads per
+ * edge the pixel, the point and invSigma2[octave] (LocalBA.cpp:333-363). Here the two keys of a left <-> right match of
+ * searchByBF play those roles: X from the LEFT key and the disparity, observed at the RIGHT key's pixel, so the pose that
+ * PoseOptimization finds from the identity is the right camera's (a translation by the baseline bf / fx along x, plus whatever
+ * the vertical mismatches of the matches ask for). One workgroup per frame; rows in match order; a match without
+ * disparity (infinite depth) or with an octave outside the table is dropped by an ordered compaction. float32 arithmetic,
+ * one operation per statement (no contraction), the same in oracle_match.cpp. */
+__global__ void __launch_bounds__(256)
+k_stereo_obs(const tb_keypoint* __restrict__ kl, const tb_keypoint* __restrict__ kr, int key_pitch, const tb_match* __restrict__ matches,
+             const int32_t* __restrict__ match_counts, int match_pitch, float fx, float fy, float cx, float cy, float bf,
+             const float* __restrict__ inv_sigma2, int nlevels, tb_obs* __restrict__ obs, int obs_pitch, int32_t* __restrict__ obs_counts) {
+    __shared__ int wsum[4];
+    const int f = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = min(match_counts[f], match_pitch);
+    const tb_keypoint* L = kl + (size_t)f * key_pitch;
+    const tb_keypoint* Rk = kr + (size_t)f * key_pitch;
+    const tb_match* M = matches + (size_t)f * match_pitch;
+    tb_obs* O = obs + (size_t)f * obs_pitch;
+    int base = 0;
+    for (int i0 = 0; i0 < n; i0 += 256) {
+        const int i = i0 + tid;
+        bool ok = false;
+        tb_obs o = {0, 0, 0, 0, 0, 0};
+        if (i < n) {
+            const tb_match m = M[i];
+            const tb_keypoint a = L[m.queryIdx], b = Rk[m.trainIdx];
+            const float depth = bf / fabsf(b.x - a.x);               /* LocalBA.cpp:64 */
+            const float nx = (a.x - cx) / fx, ny = (a.y - cy) / fy;  /* test_vo.cpp:257-261 */
+            o.u = b.x; o.v = b.y;
+            o.X = nx * depth; o.Y = ny * depth; o.Z = depth;
+            ok = isfinite(depth) && b.octave >= 0 && b.octave < nlevels;
+            o.inv_sigma2 = ok ? inv_sigma2[b.octave] : 0.f;
+        }
+        const unsigned long long bm = __ballot(ok);
+        if (lane == 0) wsum[wave] = __popcll(bm);
+        __syncthreads();
+        int off = base;
+        for (int w = 0; w < wave; w++) off += wsum[w];
+        const int at = off + __popcll(bm & ((1ull << lane) - 1));
+        if (ok && at < obs_pitch) O[at] = o;
+        base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (tid == 0) obs_counts[f] = min(base, obs_pitch);
+}
+
+int tbk_stereo_obs(tb_ctx* ctx, int nframes, const tb_keypoint* d_kl, const tb_keypoint* d_kr, int key_pitch, const tb_match* d_matches,
+                   const int32_t* d_match_counts, int match_pitch, const float K[4], float bf, const float* d_inv_sigma2, int nlevels,
+                   tb_obs* d_obs, int obs_pitch, int32_t* d_obs_counts) {
+    if (nframes <= 0) return TB_OK;
+    tb_prof_begin(ctx, "k_stereo_obs");
+    hipLaunchKernelGGL(k_stereo_obs, dim3(nframes), dim3(256), 0, ctx->stream, d_kl, d_kr, key_pitch, d_matches, d_match_counts, match_pitch,
+                       K[0], K[1], K[2], K[3], bf, d_inv_sigma2, nlevels, d_obs, obs_pitch, d_obs_counts);
+    tb_prof_end(ctx);
+    TB_HIP(ctx, hipGetLastError());
+    return TB_OK;
+}

@@ -36,6 +36,8 @@ struct RsShared {
     float ms1[RS_B * 14], ms2[RS_B * 14];
     int nm[RS_B];                  /* models of iteration h; -1: getSubset failed there */
     int good[RS_B * 3];
+    double med[RS_B * 3];          /* LMedS: median error of model k of iteration h */
+    double minMedian;
     unsigned long long rng;
     unsigned long long rngBefore[RS_B];   /* generator state in front of sample h */
     int idx[RS_B * 7];                    /* drawn indices */
@@ -177,15 +179,20 @@ __device__ int rs_run_7point(const float* m1, const float* m2, double* A /* stri
     return n;
 }
 
-/* FMEstimatorCallback::computeError of one point pair: inlier iff (float)max(d1^2 s1, d2^2 s2) <= t */
-__device__ __forceinline__ bool rs_inlier(const double* F, float x1f, float y1f, float x2f, float y2f, float t) {
+/* FMEstimatorCallback::computeError of one point pair: (float)std::max(d1^2 s1, d2^2 s2) -- std::max(a, b) = (a < b) ? b : a,
+ * which is what decides when one of the two is NaN (a degenerate F with a^2 + b^2 == 0) */
+__device__ __forceinline__ float rs_error(const double* F, float x1f, float y1f, float x2f, float y2f) {
     const double x1 = x1f, y1 = y1f, x2 = x2f, y2 = y2f;
     double a = F[0] * x1 + F[1] * y1 + F[2], b = F[3] * x1 + F[4] * y1 + F[5], c = F[6] * x1 + F[7] * y1 + F[8];
     const double s2 = 1. / (a * a + b * b), d2 = x2 * a + y2 * b + c;
     a = F[0] * x2 + F[3] * y2 + F[6]; b = F[1] * x2 + F[4] * y2 + F[7]; c = F[2] * x2 + F[5] * y2 + F[8];
     const double s1 = 1. / (a * a + b * b), d1 = x1 * a + y1 * b + c;
     const double e1 = d1 * d1 * s1, e2 = d2 * d2 * s2;
-    return (float)(e1 > e2 ? e1 : e2) <= t;
+    return (float)((e1 < e2) ? e2 : e1);
+}
+/* inlier iff the error <= t (findInliers) */
+__device__ __forceinline__ bool rs_inlier(const double* F, float x1f, float y1f, float x2f, float y2f, float t) {
+    return rs_error(F, x1f, y1f, x2f, y2f) <= t;
 }
 
 /* RANSACUpdateNumIters (ptsetreg.cpp) */
@@ -204,8 +211,13 @@ __device__ int rs_update_iters(double p, double ep, int model_points, int max_it
 /* One workgroup per pair. pts1 / pts2: the tracked positions and the keys they were tracked from (n (x, y) pairs per
  * pair at stride pts_pitch); status: in/out flags. mode 0 = Matcher::rejectWithF (clears the flags of the outliers);
  * mode 1 = cv::findFundamentalMat itself on ALL n points (mask to status, F and iteration count out; host test form).
- * work: per pair pts_pitch x (2 + 2 floats + 1 int) of compacted points. flags[pair]: 0 ok, 3 = 8..14 tracked points
- * (OpenCV's LMedS branch, not restated; nothing is changed). */
+ * work: per pair pts_pitch x (2 + 2 floats + 1 int) of compacted points. flags[pair]: 0 ok, 1 no mask came back.
+ * 8..14 tracked points: cv::findFundamentalMat switches to LMeDSPointSetRegistrator (fundam.cpp: RANSAC only from 15
+ * points on) -- the same sampling and seven-point models over a FIXED number of iterations,
+ * max(RANSACUpdateNumIters(conf, 0.45, 7, 1000), 3) = 300 at conf 0.99, the model with the smallest median error wins (the
+ * errors as floats, sorted; an even count takes the mean of the two middle ones), then inliers within
+ * sigma = 2.5 * 1.4826 * (1 + 5 / (n - 7)) * sqrt(min median), at least 0.001. Here: stage (c) gives every model 16 lanes
+ * (lane = point, rank by comparison with the other lanes), stage (d) replays "first strictly smaller median". */
 __global__ void __launch_bounds__(RS_T)
 k_ransac_f(const float* __restrict__ pts1, const float* __restrict__ pts2, uint8_t* __restrict__ status,
            const int32_t* __restrict__ counts, int pts_pitch, int mode, double thresh, double conf, float* __restrict__ work,
@@ -258,11 +270,14 @@ k_ransac_f(const float* __restrict__ pts1, const float* __restrict__ pts2, uint8
         }
         return;
     }
-    if (m < 15) { if (tid == 0) flags[pair] = 3; return; }
+    const bool lmeds = m < 15;
     if (thresh <= 0) thresh = 3;
     if (conf < DBL_EPSILON || conf > 1 - DBL_EPSILON) conf = 0.99;
-    const float t = (float)(thresh * thresh);
-    if (tid == 0) { S.rng = ~0ull; S.niters = 1000; S.maxGood = 0; S.iter = 0; S.done = 0; S.found = 0; }
+    float t = (float)(thresh * thresh);
+    if (tid == 0) {
+        S.rng = ~0ull; S.niters = lmeds ? max(rs_update_iters(conf, 0.45, 7, 1000), 3) : 1000;
+        S.maxGood = 0; S.iter = 0; S.done = 0; S.found = 0; S.minMedian = DBL_MAX;
+    }
     __syncthreads();
 
     while (!S.done) {
@@ -331,6 +346,34 @@ k_ransac_f(const float* __restrict__ pts1, const float* __restrict__ pts2, uint8
         /* (b) one seven-point problem per lane */
         if (tid < B && S.nm[tid] == 0) S.nm[tid] = rs_run_7point(S.ms1 + tid * 14, S.ms2 + tid * 14, S.A + tid, S.F + tid * 27);
         __syncthreads();
+        /* (c), LMedS: median error of every model over the m <= 14 points. Sixteen lanes per model, lane = point: the rank of a
+         * point's error among the others (float bit patterns as integers, as OpenCV sorts them; ties by point index, which
+         * does not change the sorted values) tells which lanes hold the middle elements */
+        if (lmeds) {
+            const int sub = lane >> 4, pi = lane & 15;
+            for (int j0 = wave * 4; j0 < B * 3; j0 += 16) {
+                const int j = j0 + sub, h = min(j, B * 3 - 1) / 3, k = min(j, B * 3 - 1) - 3 * h;
+                const bool on = j < B * 3 && k < S.nm[h];      /* S.nm < 0 (failed sample): off */
+                const double* F = S.F + h * 27 + k * 9;
+                double Fr[9];
+#pragma unroll
+                for (int q = 0; q < 9; q++) Fr[q] = F[q];
+                const int ip = min(pi, m - 1);
+                const int key = __float_as_int(rs_error(Fr, p1[2 * ip], p1[2 * ip + 1], p2[2 * ip], p2[2 * ip + 1]));
+                int rank = 0;
+                for (int o = 0; o < 14; o++) {
+                    const int ko = __shfl(key, (lane & 48) + o, 64);
+                    rank += (o < m && (ko < key || (ko == key && o < pi))) ? 1 : 0;
+                }
+                /* the elements of rank m/2 - 1 and m/2, broadcast inside the model's 16 lanes */
+                const unsigned long long ba = __ballot(pi < m && rank == m / 2), bb = __ballot(pi < m && rank == m / 2 - 1);
+                const int la = (int)__ffsll((long long)((ba >> (lane & 48)) & 0xffffull)) - 1, lb = (int)__ffsll((long long)((bb >> (lane & 48)) & 0xffffull)) - 1;
+                const float ea = __int_as_float(__shfl(key, (lane & 48) + max(la, 0), 64));
+                const float eb = __int_as_float(__shfl(key, (lane & 48) + max(lb, 0), 64));
+                const double median = (m & 1) ? (double)ea : (double)(eb + ea) * 0.5;
+                if (on && pi == 0) S.med[j] = median;
+            }
+        } else
         /* (c) inliers of every model over all points: models dealt to the wavefronts, lane = point */
         for (int j = wave; j < B * 3; j += 4) {
             const int h = j / 3, k = j - 3 * h;
@@ -356,6 +399,13 @@ k_ransac_f(const float* __restrict__ pts1, const float* __restrict__ pts2, uint8
                 if (!(iter < niters)) { stop = true; break; }
                 if (S.nm[h] < 0) { stop = true; break; }      /* getSubset failed: return false at iteration 0, else leave the loop */
                 for (int k = 0; k < S.nm[h]; k++) {
+                    if (lmeds) {   /* LMeDSPointSetRegistrator::run: the first strictly smaller median */
+                        if (S.med[h * 3 + k] < S.minMedian) {
+                            S.minMedian = S.med[h * 3 + k];
+                            for (int q = 0; q < 9; q++) S.bestF[q] = S.F[h * 27 + k * 9 + q];
+                        }
+                        continue;
+                    }
                     const int good = S.good[h * 3 + k];
                     if (good > max(maxGood, 6)) {
                         for (int q = 0; q < 9; q++) S.bestF[q] = S.F[h * 27 + k * 9 + q];
@@ -371,7 +421,12 @@ k_ransac_f(const float* __restrict__ pts1, const float* __restrict__ pts2, uint8
         __syncthreads();
     }
     if (tid == 0 && iters_out) iters_out[pair] = S.iter;
-    if (S.maxGood <= 0) { if (tid == 0 && mode == 1) flags[pair] = 1; return; }   /* no mask comes back */
+    if (lmeds) {
+        if (!(S.minMedian < DBL_MAX)) { if (tid == 0 && mode == 1) flags[pair] = 1; return; }   /* no model: no mask comes back */
+        double sigma = 2.5 * 1.4826 * (1 + 5. / (m - 7)) * sqrt(S.minMedian);
+        sigma = sigma > 0.001 ? sigma : 0.001;
+        t = (float)(sigma * sigma);
+    } else if (S.maxGood <= 0) { if (tid == 0 && mode == 1) flags[pair] = 1; return; }   /* no mask comes back */
     if (tid < 9 && Fout) Fout[(size_t)pair * 9 + tid] = S.bestF[tid];
     double Fr[9];
 #pragma unroll

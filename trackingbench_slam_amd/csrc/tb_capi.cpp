@@ -15,8 +15,7 @@
 
 /* ------------------------------------------------------------------ errors / context */
 int tb_fail(tb_ctx* ctx, int code, const char* fmt, ...) {
-    TB_ENTER(ctx);
-    char buf[512];
+    char buf[512]; /* no device binding here: formatting a message needs none, and TB_ENTER reports its own failure */
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
@@ -25,8 +24,7 @@ int tb_fail(tb_ctx* ctx, int code, const char* fmt, ...) {
     return code;
 }
 
-int tb_scratch(tb_ctx* ctx, int slot, size_t bytes, void** out) {
-    TB_ENTER(ctx);
+int tb_scratch(tb_ctx* ctx, int slot, size_t bytes, void** out) { /* only called from entry points that have entered */
     if (bytes < 256) bytes = 256;
     if (ctx->scratch_cap[slot] < bytes) {
         if (ctx->scratch[slot]) {
@@ -138,6 +136,35 @@ int tb_create(int device, tb_ctx** out) {
     }
     ctx->stream = ctx->own_stream;
     *out = ctx;
+    return TB_OK;
+}
+
+int tb_measure_copy_seconds(tb_ctx* ctx, const void* d_src, void* d_dst, size_t bytes, int reps, double* seconds) {
+    TB_ENTER(ctx);
+    if (!ctx || !d_src || !d_dst || !seconds || reps < 1 || bytes < 16 || (bytes & 15) || ((uintptr_t)d_src & 15) || ((uintptr_t)d_dst & 15))
+        return TB_EINVAL;
+    hipEvent_t e0, e1;
+    TB_HIP(ctx, hipEventCreate(&e0));
+    TB_HIP(ctx, hipEventCreate(&e1));
+    int rc = tbk_copy16(ctx, d_src, d_dst, bytes);
+    if (rc == TB_OK) {
+        hipError_t e = hipEventRecord(e0, ctx->stream);
+        for (int i = 0; i < reps && rc == TB_OK; i++) rc = tbk_copy16(ctx, d_src, d_dst, bytes);
+        if (e == hipSuccess) e = hipEventRecord(e1, ctx->stream);
+        if (e == hipSuccess) e = hipEventSynchronize(e1);
+        float ms = 0;
+        if (e == hipSuccess) e = hipEventElapsedTime(&ms, e0, e1);
+        if (e != hipSuccess && rc == TB_OK) rc = tb_fail(ctx, TB_EDEVICE, "tb_measure_copy_seconds: %s", hipGetErrorString(e));
+        *seconds = (double)ms * 1e-3 / reps;
+    }
+    hipEventDestroy(e0);
+    hipEventDestroy(e1);
+    return rc;
+}
+
+int tb_debug_force_dense_fast(tb_ctx* ctx, int on) {
+    if (!ctx) return TB_EINVAL;
+    ctx->dbg_fast_dense = on ? 1 : 0;
     return TB_OK;
 }
 
@@ -878,6 +905,24 @@ int tb_search_by_bf_batch_dev(tb_ctx* ctx, int npairs, const uint8_t* desc1, con
                         (unsigned long long*)tb, (unsigned long long*)qb);
 }
 
+int tb_stereo_tracks_to_obs_batch_dev(tb_ctx* ctx, int nframes, const tb_keypoint* keys_left, const tb_keypoint* keys_right,
+                                      int key_pitch, const tb_match* matches, const int32_t* match_counts, int match_pitch,
+                                      const float K[4], float bf, const float* inv_sigma2, int nlevels, tb_obs* obs, int obs_pitch,
+                                      int32_t* obs_counts) {
+    TB_ENTER(ctx);
+    if (!ctx || nframes < 0 || !K || !inv_sigma2 || nlevels < 1 || nlevels > TB_MAX_LEVELS || key_pitch < 1 || match_pitch < 1 || obs_pitch < 1)
+        return TB_EINVAL;
+    if (nframes == 0) return TB_OK;
+    if (!keys_left || !keys_right || !matches || !match_counts || !obs || !obs_counts) return TB_EINVAL;
+    void* dsig;
+    int rc;
+    if ((rc = tb_scratch(ctx, 4, TB_MAX_LEVELS * sizeof(float), &dsig))) return rc;
+    /* the table is a few floats of host memory: staged through a pinned-free async copy (the stream orders it before the kernel) */
+    TB_HIP(ctx, hipMemcpyAsync(dsig, inv_sigma2, (size_t)nlevels * sizeof(float), hipMemcpyHostToDevice, ctx->stream));
+    return tbk_stereo_obs(ctx, nframes, keys_left, keys_right, key_pitch, matches, match_counts, match_pitch, K, bf, (const float*)dsig, nlevels,
+                          obs, obs_pitch, obs_counts);
+}
+
 int tb_search_by_violence(tb_ctx* ctx, const tb_keypoint* k1, const uint8_t* d1, int n1, const tb_keypoint* k2,
                           const uint8_t* d2, int n2, int img2_width, int img2_height, int min_level, int max_level,
                           float radius, int th_low, float nratio, int histo_len, int check_orientation, tb_match* out,
@@ -1537,8 +1582,8 @@ int tb_search_by_opflow_batch_dev(tb_ctx* ctx, int npairs, const uint8_t* img1, 
     }
     if ((rc = tbk_flow_accept(ctx, npairs, cur_points, status, counts, pts_pitch, cam1->width, cam1->height, out, cap, out_counts))) return rc;
     if (reject && pts_pitch) {
-        /* matcher.cpp:751-755: rejectWithF(cur_points, F2->GetCVKeys(), status); then the matches of what is left. Pairs whose
-         * tracked points take OpenCV's LMedS branch (8..14 of them) are left as they are (see tb_reject_with_f). */
+        /* matcher.cpp:751-755: rejectWithF(cur_points, F2->GetCVKeys(), status); then the matches of what is left (pairs with
+         * 8..14 tracked points take cv::findFundamentalMat's LMedS branch inside the same kernel, as in tb_reject_with_f) */
         void *work, *fl;
         if ((rc = tb_scratch(ctx, 8, tbk_ransac_work_bytes(npairs, pts_pitch), &work))) return rc;
         if ((rc = tb_scratch(ctx, 9, (size_t)npairs * sizeof(int32_t), &fl))) return rc;
@@ -1591,9 +1636,21 @@ int tb_find_fundamental_ransac(tb_ctx* ctx, const float* pts1, const float* pts2
     memset(mask, 0, (size_t)n);
     const int rc = ransac_host(ctx, pts1, pts2, n, mask, 1, thresh, conf, F, iters, &flag);
     if (rc) return rc;
-    if (flag == 3) return tb_fail(ctx, TB_EUNSUPPORTED, "findFundamentalMat: %d points take OpenCV's LMedS branch (not built)", n);
     *ok = flag == 0 ? 1 : 0;
     return TB_OK;
+}
+
+int tb_reject_with_f_batch_dev(tb_ctx* ctx, int npairs, const float* cur_pts, const float* last_pts, const int32_t* counts,
+                               int pts_pitch, uint8_t* status) {
+    TB_ENTER(ctx);
+    if (!ctx || npairs < 0 || pts_pitch < 0) return TB_EINVAL;
+    if (npairs == 0 || pts_pitch == 0) return TB_OK;
+    if (!cur_pts || !last_pts || !status) return TB_EINVAL;
+    void *work, *fl;
+    int rc;
+    if ((rc = tb_scratch(ctx, 8, tbk_ransac_work_bytes(npairs, pts_pitch), &work))) return rc;
+    if ((rc = tb_scratch(ctx, 9, (size_t)npairs * sizeof(int32_t), &fl))) return rc;
+    return tbk_ransac_f(ctx, npairs, cur_pts, last_pts, status, counts, pts_pitch, 0, 1.0, 0.99, work, (int32_t*)fl, nullptr, nullptr);
 }
 
 int tb_reject_with_f(tb_ctx* ctx, const float* cur_pts, const float* last_pts, int n, uint8_t* status) {
@@ -1603,7 +1660,6 @@ int tb_reject_with_f(tb_ctx* ctx, const float* cur_pts, const float* last_pts, i
     int flag = 0;
     const int rc = ransac_host(ctx, cur_pts, last_pts, n, status, 0, 1.0, 0.99, nullptr, nullptr, &flag);
     if (rc) return rc;
-    if (flag == 3) return tb_fail(ctx, TB_EUNSUPPORTED, "rejectWithF: 8..14 tracked points take OpenCV's LMedS branch (not built)");
     return TB_OK;
 }
 

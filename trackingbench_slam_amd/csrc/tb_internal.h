@@ -19,6 +19,7 @@
 struct tb_ctx {
     int device = 0;
     int num_cu = 256;   /* compute units of the device (tb_create): launch shapes that aim at one resident round */
+    int dbg_fast_dense = 0; /* tb_debug_force_dense_fast: every FAST block takes the any-density path (test hook) */
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     std::string err;
@@ -57,8 +58,10 @@ int tb_scratch(tb_ctx* ctx, int slot, size_t bytes, void** out);
         tb_ctx* c_ = (ctx);                                                                    \
         if (c_) {                                                                              \
             hipError_t e_ = hipSetDevice(c_->device);                                          \
-            if (e_ != hipSuccess)                                                              \
-                return tb_fail(c_, TB_EDEVICE, "hipSetDevice(%d): %s", c_->device, hipGetErrorString(e_)); \
+            if (e_ != hipSuccess) { /* tb_fail itself makes no HIP call and must not come back here */ \
+                c_->err = std::string("hipSetDevice: ") + hipGetErrorString(e_);               \
+                return TB_EDEVICE;                                                             \
+            }                                                                                  \
         }                                                                                      \
     } while (0)
 
@@ -190,6 +193,10 @@ int tbk_projection_search(tb_ctx* ctx, int map_overload, const float Tcw[16], co
                           float nratio, const tb_keypoint* d_k1, const uint8_t* d_d1, const uint8_t* d_taken1,
                           const int32_t* d_cellStart, const int32_t* d_cellItems, float widthInv, float heightInv,
                           void* d_queries, int32_t* d_best, int* d_flag);
+int tbk_copy16(tb_ctx* ctx, const void* d_src, void* d_dst, size_t bytes);
+int tbk_stereo_obs(tb_ctx* ctx, int nframes, const tb_keypoint* d_kl, const tb_keypoint* d_kr, int key_pitch, const tb_match* d_matches,
+                   const int32_t* d_match_counts, int match_pitch, const float K[4], float bf, const float* d_inv_sigma2, int nlevels,
+                   tb_obs* d_obs, int obs_pitch, int32_t* d_obs_counts);
 int tbk_pose_batch(tb_ctx* ctx, int nproblems, const double K[4], const float* Tcw_in, const tb_obs* obs,
                    const int32_t* counts, int obs_pitch, uint8_t* outlier, float* Tcw_out, int32_t* n_inliers,
                    double* stats, double* d_err);

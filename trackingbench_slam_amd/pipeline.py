@@ -2,8 +2,8 @@
 
 One `TrackingPipeline.step()` = one pass of the path over a resident batch of F stereo frames:
 
-    pyramid (2F images) -> ORB extract (2F) -> searchByBF left<->right (F pairs) ->
-    motion-only pose optimisation (F problems) -> [multi-keyframe local BA, F windows] -> track records
+    pyramid (2F images) -> ORB extract (2F) -> searchByBF left<->right (F pairs) -> stereo depth of the matched keys ->
+    motion-only pose optimisation on those tracks (F problems) -> [multi-keyframe local BA, F windows] -> track records
 
 Everything stays in HBM between stages; torch supplies device memory, the stream and (in dist.py) the
 RCCL gather.  All compute goes through the C ABI of libtb_hip.so -- there is no torch or CPU fallback.
@@ -17,6 +17,7 @@ import torch
 from . import capi, synth
 
 KITTI_K = (718.856, 718.856, 607.1928, 185.2157)  # hard-coded in the reference, LocalBA.cpp:356-359
+KITTI_BF = 386.1448                                # fx * baseline of the same camera (test/test_vo.cpp:716: AddMapPointsByStereo(..., 386.1448, 718.856))
 
 
 class TrackingPipeline:
@@ -39,6 +40,11 @@ class TrackingPipeline:
         self.kps_ptr, self.desc_ptr, self.counts_ptr, self.kp_cap = self.ex.results_dev()
         F, cap = self.F, self.kp_cap
         self.images = None
+        with torch.cuda.stream(self.main):   # every tensor of the chain is allocated, filled and uploaded ON the chain's stream
+            self._alloc_chain(F, cap, seed)
+        self._init_ba(with_ba, ba_lag, ba_split, ba_kf, ba_pts, ba_iters, ba_distinct, seed, device)
+
+    def _alloc_chain(self, F, cap, seed):
         # Track records (what a batch hands on: keypoints, descriptors, matches, poses) exist twice: step() alternates
         # between the sets, so the exchange step of one batch (dist.gather_tracks_async) can still read its set while
         # the next batch is being computed into the other one.
@@ -50,19 +56,21 @@ class TrackingPipeline:
                            trk_desc=torch.zeros((F, cap, 32), dtype=torch.uint8, device=self.dev),
                            trk_counts=torch.zeros(F, dtype=torch.int32, device=self.dev)) for _ in range(2)]
         self._cur = 0
-        # pose-opt inputs: one seeded synthetic problem per frame, the first #matches rows are used
+        # pose-opt inputs come from the tracks (tb_stereo_tracks_to_obs_batch_dev): per left <-> right match the left key's
+        # stereo depth (LocalBA.cpp:60-64) back-projected to a map point, observed at the right key's pixel; the optimisation
+        # starts at the identity (as test/test_vo.cpp:305-355 does) and finds the right camera's pose
         self.K = np.ascontiguousarray(KITTI_K, np.float64)
+        self.Kf = np.ascontiguousarray(KITTI_K, np.float32)
+        self.inv_sigma2 = np.ascontiguousarray(capi.scale_factors(self.nlevels, self.scale)[3], np.float32)
         self.obs_pitch = cap
-        obs = np.zeros((F, cap), capi.OBS)
-        Tin = np.zeros((F, 16), np.float32)
-        for f in range(F):
-            _, Ti, o = synth.pose_problem(seed * 1000 + f, cap, KITTI_K)
-            obs[f] = o
-            Tin[f] = Ti.reshape(16)
-        self.obs = torch.from_numpy(obs.view(np.float32).reshape(F, cap, 6)).to(self.dev)
-        self.Tin = torch.from_numpy(Tin).to(self.dev)
+        self.obs = torch.zeros((F, cap, 6), dtype=torch.float32, device=self.dev)
+        self.obs_counts = torch.zeros(F, dtype=torch.int32, device=self.dev)
+        self.Tin = torch.eye(4, dtype=torch.float32, device=self.dev).reshape(1, 16).repeat(F, 1).contiguous()
         self.outlier = torch.zeros((F, cap), dtype=torch.uint8, device=self.dev)
         self.pose_stats = torch.zeros((F, 8), dtype=torch.float64, device=self.dev)
+
+    def _init_ba(self, with_ba, ba_lag, ba_split, ba_kf, ba_pts, ba_iters, ba_distinct, seed, device):
+        F = self.F
         # Local BA runs on its own HIP stream and context: its LM rounds are a chain of small, latency-bound
         # kernels (64-block solves, one-block decisions) that leave most CUs idle, while the extractor kernels
         # are throughput bound -- the two overlap on the chip instead of queueing behind each other.
@@ -135,7 +143,12 @@ class TrackingPipeline:
         """left/right: uint8 arrays [F, H, W] (host). Kept resident in HBM: images [0,F) = left, [F,2F) = right."""
         left = np.ascontiguousarray(left, np.uint8); right = np.ascontiguousarray(right, np.uint8)
         assert left.shape == (self.F, self.height, self.width) and right.shape == left.shape
-        self.images = torch.from_numpy(np.concatenate([left, right], 0)).to(self.dev)
+        # a step may still be reading the previous frames: join it, then upload on the chain's stream (the caching allocator
+        # hands a freed block to the next allocation of the SAME stream only in stream order)
+        self.drain()
+        self.main.synchronize()
+        with torch.cuda.stream(self.main):
+            self.images = torch.from_numpy(np.concatenate([left, right], 0)).to(self.dev, non_blocking=False)
         self.ex.set_images_dev(self.images.data_ptr(), 2 * self.F, self.width, self.width * self.height)
 
     def set_synthetic(self, distinct=8, first=0):
@@ -201,8 +214,16 @@ class TrackingPipeline:
                                               C.c_void_p(self.match_counts.data_ptr())))
         with torch.cuda.stream(self.main):
             self.outlier.zero_()                 # ordered on the chain's stream, between the matcher and pose-opt
+        kp_bytes = self.kp_cap * 28
+        ctx.check(L.tb_stereo_tracks_to_obs_batch_dev(ctx._h, F, C.c_void_p(self.kps_ptr), C.c_void_p(self.kps_ptr + F * kp_bytes),
+                                                      self.kp_cap, C.c_void_p(self.matches.data_ptr()),
+                                                      C.c_void_p(self.match_counts.data_ptr()), self.kp_cap,
+                                                      self.Kf.ctypes.data_as(C.c_void_p), C.c_float(KITTI_BF),
+                                                      self.inv_sigma2.ctypes.data_as(C.c_void_p), len(self.inv_sigma2),
+                                                      C.c_void_p(self.obs.data_ptr()), self.obs_pitch,
+                                                      C.c_void_p(self.obs_counts.data_ptr())))
         ctx.check(L.tb_pose_opt_batch_dev(ctx._h, F, self.K.ctypes.data_as(C.c_void_p), C.c_void_p(self.Tin.data_ptr()),
-                                          C.c_void_p(self.obs.data_ptr()), C.c_void_p(self.match_counts.data_ptr()),
+                                          C.c_void_p(self.obs.data_ptr()), C.c_void_p(self.obs_counts.data_ptr()),
                                           self.obs_pitch, C.c_void_p(self.outlier.data_ptr()), C.c_void_p(self.Tout.data_ptr()),
                                           C.c_void_p(self.n_inliers.data_ptr()), C.c_void_p(self.pose_stats.data_ptr())))
         ex.copy_results_dev(F, self.trk_kps.data_ptr(), self.trk_desc.data_ptr(), self.trk_counts.data_ptr(), self.kp_cap)
