@@ -323,6 +323,10 @@ def parse_args(argv=None):
     ap.add_argument("--ba-iters", type=int, default=10)
     ap.add_argument("--no-ba", action="store_true", help="diagnostic only: drop the local-BA stage")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--region-events", choices=("auto", "on", "off"), default="auto",
+                    help="per-kernel HIP events inside the timed region (auto: on above 64 frames per GPU; below, two event "
+                         "records per ~5 us kernel are a third of the step and keep the local-BA call from replaying its HIP "
+                         "graph: the per-kernel figures then come from the isolated passes right after the region)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--ba-split", type=int, default=0,
                     help="partitions of the BA windows, one stream + host thread each (0 = by batch size: 1 up to 64 frames, else 3)")
@@ -406,7 +410,8 @@ def main(argv=None):
     for _ in range(args.warmup):
         one_step()
     fence()
-    if gpu:
+    region_events = gpu and (args.region_events == "on" or (args.region_events == "auto" and args.frames > 64))
+    if region_events:
         pipe.profile_enable(True)
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -414,7 +419,7 @@ def main(argv=None):
     fence()
     el = time.perf_counter() - t0
     prof = {}
-    if gpu:
+    if region_events:
         prof = pipe.profile_report()
         pipe.profile_enable(False)
     t = torch.tensor([el], dtype=torch.float64, device="cuda" if gpu else "cpu")
@@ -529,10 +534,16 @@ def report(args, pipe, prof, el, world, n_joined, dev):
     calls, tot_ms = prof.get(name, (0, 0.0))
     launches_per_step = max(calls // max(args.steps, 1), 1)
     in_region_launch_ms = tot_ms / max(calls, 1)
+    events_note = ("HIP events on the kernel's stream over the timed region; other streams share the GPU then, "
+                   "so it includes waiting for CU slots -- `isolated` is the same launch with its chain alone")
+    if not prof:   # --region-events off (small batches): the isolated pass right after the region is the only per-kernel timing
+        in_region_launch_ms = iso.get(name, 0.0)
+        launches_per_step = max(int(round(iso_step.get(name, 0.0) / in_region_launch_ms)), 1) if in_region_launch_ms else 1
+        events_note = ("per-kernel events were OFF in the timed region (small batch: see --region-events); this is the isolated "
+                       "pass taken right after it, HIP events on the kernel's stream, its chain alone on the GPU")
     common = {"kernel": name, "launches_per_step": launches_per_step,
               "avg_launch_ms": round(in_region_launch_ms, 5),
-              "avg_launch_ms_note": "HIP events on the kernel's stream over the timed region; other streams share the GPU then, "
-                                    "so it includes waiting for CU slots -- `isolated` is the same launch with its chain alone",
+              "avg_launch_ms_note": events_note,
               "hbm_copy_measured_GBs": round(copy_gbs, 1), "extractor": ext,
               "kernels_ms_per_step_in_region": kern_ms,
               "isolated_kernels_ms_per_step": {k: round(v, 4) for k, v in sorted(iso_step.items())}}

@@ -26,6 +26,7 @@
  * reproducible run to run.  Bound: the FP64 units (matrix + vector work, same datapath on CDNA4) for D, FP64
  * VALU / latency for the rest; bench.py reports both roofs of D.
  */
+#include <mutex>
 #include <type_traits>
 #include "tb_internal.h"
 #include "tb_device.h"
@@ -36,6 +37,7 @@
 #define BA_KFBLK 4            /* workgroups per keyframe in the keyframe pass */
 #define BA_BIG_MAXF 64        /* free keyframes of a large window (6 bits of the free-edge key) */
 #define BA_SMALL_MAXF 10      /* free keyframes of a window on the MFMA path (visibility patterns are 10-bit masks) */
+#define BA_SORT_LDS 8192      /* points of a window whose pattern sort runs in LDS (k_ba_groups) */
 #ifndef BA_EMAX
 #define BA_EMAX 64            /* free-keyframe edges of a Schur group at most: one lane each */
 #endif
@@ -69,7 +71,9 @@ struct BaDims {
     unsigned long long oPtMask, oPermA, oPermB, oPtRank, oKPs, oGDesc;
     unsigned long long oGCost;   /* ints: cost estimate of the groups before group g (exclusive prefix, total at [ng]) */
     unsigned long long oGCut;    /* ints: first group of Schur wavefront v of the window (4 G + 1 entries) */
-    int schurWaveLds, pad1;      /* doubles of LDS per Schur wavefront (host: ba_c_wave_lds(nfree)) */
+    int schurWaveLds;            /* doubles of LDS per Schur wavefront (host: ba_c_wave_lds(nfree)) */
+    int wgReduce;                /* Schur workgroups add their four wavefronts' partial systems through LDS (small batches: many
+                                    workgroups per window, and k_ba_solve -- one workgroup per window -- adds them all) */
 };
 
 typedef double ba_d4 __attribute__((ext_vector_type(4)));
@@ -667,6 +671,7 @@ __device__ __forceinline__ void ba_stable_split(int n, int* tmp, const int* src,
 __global__ void __launch_bounds__(BA_T)
 k_ba_groups(BaDims d, int* __restrict__ iw, const int* __restrict__ errflag) {
     __shared__ int cntb[1 << BA_SMALL_MAXF], bst[1 << BA_SMALL_MAXF], ebin[1 << BA_SMALL_MAXF], tmp[16];
+    __shared__ unsigned short sortbuf[3 * BA_SORT_LDS];
     const int w = blockIdx.x, tid = threadIdx.x;
     if (errflag[w]) return; /* observations rejected by k_ba_setup: k_ba_points ends the window before anything reads the tables */
     int* I = iw + (size_t)w * d.istride;
@@ -679,17 +684,56 @@ k_ba_groups(BaDims d, int* __restrict__ iw, const int* __restrict__ errflag) {
         int m = 0;
         for (int e = e0; e < e1; e++) m |= 1 << (KP[e].x & 63);
         I[d.oPtMask + p] = m;
-        I[d.oPermA + p] = p;
+        if (d.npt > BA_SORT_LDS) I[d.oPermA + p] = p;
         atomicAdd(&cntb[m], 1); /* counts only: the order of the adds does not matter */
     }
     __threadfence_block();
     __syncthreads();
-    /* LSD sort of the points by mask, one stable split per free keyframe: equal masks end up adjacent, in point order */
+    /* LSD sort of the points by mask, one stable split per free keyframe: equal masks end up adjacent, in point order.
+     * Windows of up to BA_SORT_LDS points keep the masks and both permutation buffers in LDS (16-bit entries): a pass is
+     * two sweeps of LDS reads instead of two chains of dependent global loads (the kernel is one workgroup per window, pure
+     * latency: 190 -> ~40 us). Larger windows sort through the global buffers. */
     int* src = I + d.oPermA;
     int* dst = I + d.oPermB;
-    for (int b = 0; b < d.nfree; b++) {
-        ba_stable_split(d.npt, tmp, src, dst, [&](int p) { return ((I[d.oPtMask + p] >> b) & 1) == 0; });
-        int* t = src; src = dst; dst = t;
+    if (d.npt <= BA_SORT_LDS) {
+        unsigned short* mk = sortbuf;                  /* mask of point p */
+        unsigned short* pa_ = sortbuf + BA_SORT_LDS;   /* permutation, ping */
+        unsigned short* pb_ = sortbuf + 2 * BA_SORT_LDS;
+        for (int p = tid; p < d.npt; p += BA_T) { mk[p] = (unsigned short)I[d.oPtMask + p]; pa_[p] = (unsigned short)p; }
+        __syncthreads();
+        const int wave = tid >> 6, lane = tid & 63;
+        const int q = (((d.npt + 3) >> 2) + 63) & ~63, lo = min(wave * q, d.npt), hi = min(lo + q, d.npt);
+        const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        for (int b = 0; b < d.nfree; b++) {
+            int cnt = 0;
+            for (int e = lo + lane; e < hi; e += 64) cnt += ((mk[pa_[e]] >> b) & 1) ? 0 : 1;
+            cnt = tb_wave_sum(cnt);
+            if (lane == 0) tmp[wave] = cnt;
+            __syncthreads();
+            int z = 0;
+            for (int v = 0; v < wave; v++) z += tmp[v];
+            int o = (tmp[0] + tmp[1] + tmp[2] + tmp[3]) + (lo - z);
+            for (int e0 = lo; e0 < hi; e0 += 64) {
+                const int e = e0 + lane;
+                const bool valid = e < hi;
+                const int v = valid ? pa_[e] : 0;
+                const bool f = valid && !((mk[v] >> b) & 1);
+                const unsigned long long m0 = __ballot(f), m1 = __ballot(valid && !f);
+                if (valid) pb_[f ? z + __popcll(m0 & lt) : o + __popcll(m1 & lt)] = (unsigned short)v;
+                z += __popcll(m0);
+                o += __popcll(m1);
+            }
+            __syncthreads();
+            unsigned short* t = pa_; pa_ = pb_; pb_ = t;
+        }
+        for (int r = tid; r < d.npt; r += BA_T) src[r] = pa_[r]; /* the later stages read the order from the global buffer */
+        __threadfence_block();
+        __syncthreads();
+    } else {
+        for (int b = 0; b < d.nfree; b++) {
+            ba_stable_split(d.npt, tmp, src, dst, [&](int p) { return ((I[d.oPtMask + p] >> b) & 1) == 0; });
+            int* t = src; src = dst; dst = t;
+        }
     }
     for (int r = tid; r < d.npt; r += BA_T) I[d.oPtRank + src[r]] = r;
     /* first rank and first pattern-ordered edge of every pattern */
@@ -1192,13 +1236,38 @@ k_ba_schur_c(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, BaSt
     /* every wavefront writes its own partial system in the 64 x 64 layout k_ba_solve reads (lower triangle at [row][col],
      * reduced rhs in column np): lane = block pair, its 36 entries; k_ba_solve adds the 4 G partials of the window in
      * wavefront order. (Rounds 1-2 summed the four wavefronts through LDS first: a barrier -- every wavefront waiting for
-     * the slowest -- and four serial passes, 8 % of the kernel.) */
-    double* out = D + d.oPartS + (size_t)wv * 64 * 64;
-    if (lane < NPAIR) {
+     * the slowest -- and four serial passes, 8 % of the kernel. Small batches still do: with tens of workgroups per window
+     * the single workgroup of k_ba_solve would add four times as many partial systems.) */
+    if (d.wgReduce) {
+        __syncthreads(); /* every wave is past its last tile read: the tile storage becomes the 64 x 64 sum */
+        double* sum = lds;
+        for (int wq = 0; wq < 4; wq++) {
+            if (wave == wq) {
+                if (lane < NPAIR) {
 #pragma unroll
-        for (int e = 0; e < 36; e++) out[(6 * pa + e / 6) * 64 + 6 * pb + e % 6] = S[e];
+                    for (int e = 0; e < 36; e++) {
+                        const int idx = (6 * pa + e / 6) * 64 + 6 * pb + e % 6;
+                        sum[idx] = (wq == 0) ? S[e] : sum[idx] + S[e];
+                    }
+                }
+                ba_wave_lds_fence();
+                if (lane < d.np) sum[lane * 64 + d.np] = (wq == 0) ? rhs : sum[lane * 64 + d.np] + rhs;
+            }
+            __syncthreads();
+        }
+        double* out = D + d.oPartS + (size_t)g0 * 64 * 64;
+        for (int i = tid; i < 64 * 64; i += BA_T) {
+            const int r = i >> 6, c = i & 63;
+            if (r < d.np && (c <= r || c == d.np)) out[i] = sum[i];
+        }
+    } else {
+        double* out = D + d.oPartS + (size_t)wv * 64 * 64;
+        if (lane < NPAIR) {
+#pragma unroll
+            for (int e = 0; e < 36; e++) out[(6 * pa + e / 6) * 64 + 6 * pb + e % 6] = S[e];
+        }
+        if (lane < d.np) out[lane * 64 + d.np] = rhs;
     }
-    if (lane < d.np) out[lane * 64 + d.np] = rhs;
 #ifdef BA_TIMING
     BA_TK(9); /* epilogue */
     if (tid == 0 && (w & 15) == 0) { for (int i = 0; i < 10; i++) atomicAdd(&ba_times[i], tk_[i]); atomicAdd(&ba_times[10], 1ull); }
@@ -1206,6 +1275,15 @@ k_ba_schur_c(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, BaSt
 }
 
 /* ---- E: assemble S (lower triangle), Cholesky in registers, pose update */
+/* 1 / sqrt(x) for x > 0: v_rsq_f64 refined by two Newton steps (relative error ~1e-16). The Cholesky below needs a square
+ * root and a reciprocal per column, on its critical path: the IEEE sqrt and division sequences are ~40 instructions each. */
+__device__ __forceinline__ double ba_rsqrt(double x) {
+    double r = __builtin_amdgcn_rsq(x);
+    const double h = 0.5 * x;
+    r = fma(r, fma(-h * r, r, 0.5), r);
+    r = fma(r, fma(-h * r, r, 0.5), r);
+    return r;
+}
 template <int NS> /* padded system size: np rounded up to 16 */
 __global__ void __launch_bounds__(BA_T)
 k_ba_solve(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) {
@@ -1215,30 +1293,58 @@ k_ba_solve(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) {
     BaState* st = states + w;
     if (st->status) return;
     double* D = dw + (size_t)w * d.wstride;
-    const int np = d.np, nPart = 4 * (d.Gbase + (w < d.Gextra ? 1 : 0)); /* one partial system per Schur wavefront */
+    const int Gw = d.Gbase + (w < d.Gextra ? 1 : 0);
+    const int np = d.np, nPart = d.wgReduce ? Gw : 4 * Gw; /* one partial system per Schur workgroup or per wavefront */
     const double lambda = st->lambda;
-    for (int i = tid; i < np * np; i += BA_T) {
-        const int r = i / np, c = i - r * np;
-        if (c > r) continue;
-        double s = 0;
-#pragma unroll 6
-        for (int g = 0; g < nPart; g++) s += D[d.oPartS + (size_t)g * 4096 + r * 64 + c]; /* ordered sum, loads in flight together */
-        double h = 0;
-        if (r / 6 == c / 6) h = D[d.oHpp + (size_t)(r / 6) * 36 + (r % 6) * 6 + (c % 6)];
-        if (r == c) h += lambda;
-        A[r * 65 + c] = h - s;
+    /* the lower triangle: every thread owns up to BA_SOLVE_E entries and adds the partial systems in order -- the entries are
+     * the INNER loop, so one trip over the partials keeps BA_SOLVE_E x 4 independent loads in flight (one entry per trip
+     * with the partials inside waited out a memory latency per 16 loads; 80 partials at a batch of 8 windows) */
+    constexpr int BA_SOLVE_E = (NS * (NS + 1) / 2 + BA_T - 1) / BA_T;
+    {
+        int er[BA_SOLVE_E], ec[BA_SOLVE_E];
+        const double* ps[BA_SOLVE_E];
+        double acc[BA_SOLVE_E];
+        const int ne = np * (np + 1) / 2;
+#pragma unroll
+        for (int k = 0; k < BA_SOLVE_E; k++) {
+            const int e = min(tid + k * BA_T, ne - 1);
+            int r = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+            while ((r + 1) * (r + 2) / 2 <= e) r++;
+            while (r * (r + 1) / 2 > e) r--;
+            er[k] = r; ec[k] = e - r * (r + 1) / 2;
+            ps[k] = D + d.oPartS + er[k] * 64 + ec[k];
+            acc[k] = 0;
+        }
+#pragma unroll 4
+        for (int g = 0; g < nPart; g++) {
+#pragma unroll
+            for (int k = 0; k < BA_SOLVE_E; k++) acc[k] += ps[k][(size_t)g * 4096];
+        }
+#pragma unroll
+        for (int k = 0; k < BA_SOLVE_E; k++) {
+            if (tid + k * BA_T >= ne) continue;
+            const int r = er[k], c = ec[k];
+            double h = 0;
+            if (r / 6 == c / 6) h = D[d.oHpp + (size_t)(r / 6) * 36 + (r % 6) * 6 + (c % 6)];
+            if (r == c) h += lambda;
+            A[r * 65 + c] = h - acc[k];
+        }
     }
     for (int r = tid; r < np; r += BA_T) {
+        const double* ps = D + d.oPartS + r * 64 + np;
         double s = 0;
-#pragma unroll 6
-        for (int g = 0; g < nPart; g++) s += D[d.oPartS + (size_t)g * 4096 + r * 64 + np];
+#pragma unroll 16
+        for (int g = 0; g < nPart; g++) s += ps[(size_t)g * 4096];
         rhs[r] = D[d.oBp + r] - s;
     }
     __syncthreads();
     /* One wave factorises and substitutes with the matrix in REGISTERS: lane i holds row i of the 64 x 64
      * system (rows >= np are identity, so the padded part factors to itself); column j of L is broadcast
      * with compile-time lane indices (v_readlane), so the O(n^3) loop is straight-line FMA code with no
-     * LDS round trips and no barriers. Right-looking Cholesky on the lower triangle. */
+     * LDS round trips and no barriers. Right-looking Cholesky on the lower triangle. Round 3: one refined v_rsq_f64 per
+     * column instead of an IEEE square root and a division, fused multiply-adds in the update, and the back-substitution
+     * on a register copy of L^T (lane i = column i, transposed once through LDS) -- a wave-wide sum per column cost 48 x 12
+     * LDS permutes; the kernel went from 54 to ~25 us per launch, the latency a small batch's LM trial waits for. */
     if (tid < 64) {
         const int i = tid;
         double row[NS];
@@ -1250,14 +1356,13 @@ k_ba_solve(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) {
         for (int j = 0; j < NS; j++) {
             const double dj = ba_readlane(row[j], j);
             if (!(dj > 0) || !isfinite(dj)) good = false;
-            const double sj = sqrt(good ? dj : 1.0);
-            const double isj = 1.0 / sj;
+            const double isj = ba_rsqrt(good ? dj : 1.0), sj = (good ? dj : 1.0) * isj;
             if (i == j) dinv = isj;
             row[j] = (i == j) ? sj : row[j] * isj; /* lanes i < j hold unused upper-triangle values */
 #pragma unroll
             for (int k = j + 1; k < NS; k++) {
                 const double lkj = ba_readlane(row[j], k); /* L[k][j] */
-                row[k] -= row[j] * lkj;                    /* only lanes i >= k are ever read back */
+                row[k] = fma(-row[j], lkj, row[k]);        /* only lanes i >= k are ever read back */
             }
         }
         double xi = (i < np) ? rhs[i] : 0.0;
@@ -1265,13 +1370,22 @@ k_ba_solve(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) {
         for (int j = 0; j < NS; j++) { /* forward: L y = rhs */
             const double yj = ba_readlane(xi, j) * ba_readlane(dinv, j);
             if (i == j) xi = yj;
-            else if (i > j) xi -= row[j] * yj;
+            else if (i > j) xi = fma(-row[j], yj, xi);
         }
+        /* L^T into registers: lane i gets column i of L */
+        if (i < NS) {
 #pragma unroll
-        for (int j = NS - 1; j >= 0; j--) { /* backward: L^T x = y; L[k][j] sits in lane k, register j */
-            const double sum = po_wave_sum((i > j && i < NS) ? row[j] * xi : 0.0); /* sum_{k>j} L[k][j] x_k, fixed tree */
-            const double xj = (ba_readlane(xi, j) - sum) * ba_readlane(dinv, j);
+            for (int k = 0; k < NS; k++) A[i * 65 + k] = (k <= i) ? row[k] : 0.0;
+        }
+        ba_wave_lds_fence();
+        double col[NS];
+#pragma unroll
+        for (int k = 0; k < NS; k++) col[k] = A[k * 65 + min(i, NS - 1)]; /* L[k][i], zero for k < i */
+#pragma unroll
+        for (int j = NS - 1; j >= 0; j--) { /* backward: L^T x = y; lane i < j subtracts L[j][i] x_j as soon as x_j is known */
+            const double xj = ba_readlane(xi, j) * ba_readlane(dinv, j);
             if (i == j) xi = xj;
+            else if (i < j) xi = fma(-col[j], xj, xi);
         }
         if (!good) xi = 0;
         double term = 0.0;
@@ -1759,14 +1873,20 @@ k_ba_update(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
 }
 
 /* ---- G: accept / reject (g2o OptimizationAlgorithmLevenberg::solve), one thread per window */
-__global__ void k_ba_decide(BaDims d, const double* __restrict__ dw, BaState* __restrict__ states, int* __restrict__ running) {
-    const int w = blockIdx.x * blockDim.x + threadIdx.x;
-    if (w >= d.W) return;
+__global__ void __launch_bounds__(64)
+k_ba_decide(BaDims d, const double* __restrict__ dw, BaState* __restrict__ states, int* __restrict__ running) {
+    /* one wavefront per window: the lanes fetch the point blocks' partial sums together and add them in a fixed tree (a
+     * single thread walking 2 x nblkP dependent loads made this trivial kernel 8 us of every LM trial) */
+    const int w = blockIdx.x, lane = threadIdx.x;
     BaState* st = states + w;
     if (st->status) return;
     const double* D = dw + (size_t)w * d.wstride;
-    double tempChi = 0, scale = st->scale_p;
-    for (int b = 0; b < d.nblkP; b++) { tempChi += D[d.oPartP + (size_t)b * 4 + 2]; scale += D[d.oPartP + (size_t)b * 4 + 3]; }
+    double tc = 0, sc = 0;
+    for (int b = lane; b < d.nblkP; b += 64) { tc += D[d.oPartP + (size_t)b * 4 + 2]; sc += D[d.oPartP + (size_t)b * 4 + 3]; }
+    tc = po_wave_sum(tc);
+    sc = po_wave_sum(sc);
+    if (lane != 0) return;
+    double tempChi = tc, scale = st->scale_p + sc;
     if (!st->ok2) tempChi = 1.7976931348623157e308;
     scale += 1e-3;
     const double rho = (st->currentChi - tempChi) / scale;
@@ -1823,6 +1943,11 @@ k_ba_finish(BaDims d, const double* __restrict__ dw, const BaState* __restrict__
     }
 }
 
+__global__ void k_ba_zero(int* __restrict__ p, int n) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < n) p[i] = 0;
+}
+
 static void ba_dims(BaDims& d, int num_cu, int W, const double K[4], int nkf, int nfixed, int npt, int obs_pitch, int iters) {
     memset(&d, 0, sizeof d);
     d.W = W; d.nkf = nkf; d.nfixed = nfixed; d.nfree = nkf - nfixed; d.np = 6 * d.nfree; d.npt = npt; d.obs_pitch = obs_pitch;
@@ -1839,6 +1964,7 @@ static void ba_dims(BaDims& d, int num_cu, int W, const double K[4], int nkf, in
         d.Gbase = std::min(std::max(slots / std::max(W, 1), 1), cap);
         d.Gextra = (d.Gbase < cap && slots > d.Gbase * W) ? std::min(slots - d.Gbase * W, W) : 0;
         d.G = d.Gbase + (d.Gextra > 0 ? 1 : 0);
+        d.wgReduce = d.Gbase > 4 ? 1 : 0;
     }
     d.big = d.nfree > BA_SMALL_MAXF;
     d.schurWaveLds = d.big ? 0 : ba_c_wave_lds(d.nfree);
@@ -1910,68 +2036,66 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
     BaState* states = (BaState*)((char*)iw + (size_t)W * d.istride * sizeof(int));
     int* running = (int*)((char*)states + (size_t)W * sizeof(BaState));
     hipStream_t s = ctx->stream;
-    const size_t schur_lds = 4 * (size_t)d.schurWaveLds * sizeof(double); /* Schur kernel: four wavefronts' tiles */
+    /* Schur kernel: four wavefronts' tiles (small batches reuse them for the 64 x 64 sum of the wavefronts' systems) */
+    const size_t schur_lds = std::max<size_t>(4 * (size_t)d.schurWaveLds, d.wgReduce ? 64 * 64 : 0) * sizeof(double);
     /* behind the states: one still-running counter per round (no memset node between the rounds), then one
      * rejected-input flag per window; zeroed together before the setup kernel */
     const int ring = 1000;
     int* errflag = running + ring;
-    TB_HIP(ctx, hipMemsetAsync(running, 0, (size_t)(ring + W) * sizeof(int), s));
-    tb_prof_begin(ctx, "k_ba_setup");
-    hipLaunchKernelGGL(k_ba_setup, dim3(nkf + 2, W), dim3(BA_T), 0, s, d, d_poses, d_pts, d_obs, d_counts, dw, iw, states, errflag);
-    tb_prof_end(ctx);
-    TB_HIP(ctx, hipGetLastError());
     const size_t big_lds = (size_t)(d.np + 1) * BA_PLD * sizeof(double);
-    if (!d.big) {
-        const int R = (d.np + 15) >> 4;
-        const void* ks = R == 1 ? (const void*)k_ba_schur_c<1> : R == 2 ? (const void*)k_ba_schur_c<2> : R == 3 ? (const void*)k_ba_schur_c<3> : (const void*)k_ba_schur_c<4>;
-        TB_HIP(ctx, hipFuncSetAttribute(ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_lds));
-        tb_prof_begin(ctx, "k_ba_groups");
-        hipLaunchKernelGGL(k_ba_groups, dim3(W), dim3(BA_T), 0, s, d, iw, errflag);
+    const int R = (d.np + 15) >> 4;
+    typedef void (*schur_t)(BaDims, double*, const int*, BaState*);
+    const schur_t ks = R == 1 ? (schur_t)k_ba_schur_c<1> : R == 2 ? (schur_t)k_ba_schur_c<2> : R == 3 ? (schur_t)k_ba_schur_c<3> : (schur_t)k_ba_schur_c<4>;
+    if (!d.big) TB_HIP(ctx, hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_lds));
+    else TB_HIP(ctx, hipFuncSetAttribute((const void*)k_ba_solve_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
+    /* once per call: LM state, CSR tables, pattern groups (block-pair lists for large windows) */
+    auto enqueue_head = [&]() -> int {
+        /* a kernel, not hipMemsetAsync: as a memset NODE of a replayed graph the fill came back as stale pointer-sized
+         * values on one of three contexts replaying from their own host threads (ROCm 7.2), the windows then read a set
+         * rejected-input flag and returned their input */
+        hipLaunchKernelGGL(k_ba_zero, dim3((ring + W + 255) / 256), dim3(256), 0, s, running, ring + W);
+        tb_prof_begin(ctx, "k_ba_setup");
+        hipLaunchKernelGGL(k_ba_setup, dim3(nkf + 2, W), dim3(BA_T), 0, s, d, d_poses, d_pts, d_obs, d_counts, dw, iw, states, errflag);
         tb_prof_end(ctx);
+        if (!d.big) {
+            tb_prof_begin(ctx, "k_ba_groups");
+            hipLaunchKernelGGL(k_ba_groups, dim3(W), dim3(BA_T), 0, s, d, iw, errflag);
+            tb_prof_end(ctx);
+        } else {
+            /* block-pair item lists of the large-window Schur kernel: count, scan, fill */
+            tb_prof_begin(ctx, "k_ba_pairs");
+            hipLaunchKernelGGL(k_ba_pairs<false>, dim3(d.nfree, W), dim3(64), 0, s, d, d_obs, iw, errflag);
+            hipLaunchKernelGGL(k_ba_pair_scan, dim3(W), dim3(BA_T), 0, s, d, iw, errflag);
+            hipLaunchKernelGGL(k_ba_pairs<true>, dim3(d.nfree, W), dim3(64), 0, s, d, d_obs, iw, errflag);
+            tb_prof_end(ctx);
+        }
         TB_HIP(ctx, hipGetLastError());
-    }
-    if (d.big) {
-        /* block-pair item lists of the large-window Schur kernel: count, scan, fill */
-        TB_HIP(ctx, hipFuncSetAttribute((const void*)k_ba_solve_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
-        tb_prof_begin(ctx, "k_ba_pairs");
-        hipLaunchKernelGGL(k_ba_pairs<false>, dim3(d.nfree, W), dim3(64), 0, s, d, d_obs, iw, errflag);
-        hipLaunchKernelGGL(k_ba_pair_scan, dim3(W), dim3(BA_T), 0, s, d, iw, errflag);
-        hipLaunchKernelGGL(k_ba_pairs<true>, dim3(d.nfree, W), dim3(64), 0, s, d, d_obs, iw, errflag);
+        return TB_OK;
+    };
+    /* one LM trial of every window: eight launches */
+    auto enqueue_round = [&](int round) -> int {
+        tb_prof_begin(ctx, "k_ba_points");
+        hipLaunchKernelGGL(k_ba_points, dim3(d.nblkP, W), dim3(BA_T), (size_t)d.nkf * 12 * sizeof(double), s, d, d_obs, dw, iw, states, errflag);
         tb_prof_end(ctx);
-        TB_HIP(ctx, hipGetLastError());
-    }
-    int host_running = 1, rounds = 0;
-    const int max_rounds = std::min(iters * 10 + 1, 1000); /* ring size below */
-    int batch = iters + 1;
-    while (host_running > 0 && rounds < max_rounds) {
-        for (int r = 0; r < batch && rounds < max_rounds; r++, rounds++) {
-            tb_prof_begin(ctx, "k_ba_points");
-            hipLaunchKernelGGL(k_ba_points, dim3(d.nblkP, W), dim3(BA_T), (size_t)d.nkf * 12 * sizeof(double), s, d, d_obs, dw, iw, states, errflag);
+        tb_prof_begin(ctx, "k_ba_kf");
+        hipLaunchKernelGGL(k_ba_kf, dim3(std::min(BA_KFBLK, d.kfChunks), d.nfree, W), dim3(BA_T), 0, s, d, d_obs, dw, iw, states);
+        tb_prof_end(ctx);
+        tb_prof_begin(ctx, "k_ba_reduce");
+        hipLaunchKernelGGL(k_ba_reduce, dim3(W), dim3(BA_T), 0, s, d, dw, iw, states);
+        tb_prof_end(ctx);
+        tb_prof_begin(ctx, "k_ba_hinv");
+        hipLaunchKernelGGL(k_ba_hinv, dim3(d.nblkP, W), dim3(BA_T), 0, s, d, dw, iw, states);
+        tb_prof_end(ctx);
+        if (d.big) {
+            tb_prof_begin(ctx, "k_ba_schur_pairs");
+            hipLaunchKernelGGL(k_ba_schur_pairs, dim3((d.npairs + 3) / 4, W), dim3(BA_T), 0, s, d, dw, iw, states);
             tb_prof_end(ctx);
-            tb_prof_begin(ctx, "k_ba_kf");
-            hipLaunchKernelGGL(k_ba_kf, dim3(std::min(BA_KFBLK, d.kfChunks), d.nfree, W), dim3(BA_T), 0, s, d, d_obs, dw, iw, states);
+            tb_prof_begin(ctx, "k_ba_solve_big");
+            hipLaunchKernelGGL(k_ba_solve_big, dim3(W), dim3(BA_ST), big_lds, s, d, dw, states);
             tb_prof_end(ctx);
-            tb_prof_begin(ctx, "k_ba_reduce");
-            hipLaunchKernelGGL(k_ba_reduce, dim3(W), dim3(BA_T), 0, s, d, dw, iw, states);
-            tb_prof_end(ctx);
-            tb_prof_begin(ctx, "k_ba_hinv");
-            hipLaunchKernelGGL(k_ba_hinv, dim3(d.nblkP, W), dim3(BA_T), 0, s, d, dw, iw, states);
-            tb_prof_end(ctx);
-            if (d.big) {
-                tb_prof_begin(ctx, "k_ba_schur_pairs");
-                hipLaunchKernelGGL(k_ba_schur_pairs, dim3((d.npairs + 3) / 4, W), dim3(BA_T), 0, s, d, dw, iw, states);
-                tb_prof_end(ctx);
-                tb_prof_begin(ctx, "k_ba_solve_big");
-                hipLaunchKernelGGL(k_ba_solve_big, dim3(W), dim3(BA_ST), big_lds, s, d, dw, states);
-                tb_prof_end(ctx);
-            } else {
+        } else {
             tb_prof_begin(ctx, "k_ba_schur");
-            {
-                const int R = (d.np + 15) >> 4;
-                typedef void (*schur_t)(BaDims, double*, const int*, BaState*);
-                const schur_t ks = R == 1 ? (schur_t)k_ba_schur_c<1> : R == 2 ? (schur_t)k_ba_schur_c<2> : R == 3 ? (schur_t)k_ba_schur_c<3> : (schur_t)k_ba_schur_c<4>;
-                hipLaunchKernelGGL(ks, dim3(d.G, W), dim3(BA_T), schur_lds, s, d, dw, iw, states);
-            }
+            hipLaunchKernelGGL(ks, dim3(d.G, W), dim3(BA_T), schur_lds, s, d, dw, iw, states);
             tb_prof_end(ctx);
             tb_prof_begin(ctx, "k_ba_solve");
             if (d.np <= 16) hipLaunchKernelGGL(k_ba_solve<16>, dim3(W), dim3(BA_T), 0, s, d, dw, states);
@@ -1979,15 +2103,78 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
             else if (d.np <= 48) hipLaunchKernelGGL(k_ba_solve<48>, dim3(W), dim3(BA_T), 0, s, d, dw, states);
             else hipLaunchKernelGGL(k_ba_solve<64>, dim3(W), dim3(BA_T), 0, s, d, dw, states);
             tb_prof_end(ctx);
-            }
-            tb_prof_begin(ctx, "k_ba_update");
-            hipLaunchKernelGGL(k_ba_update, dim3(d.nblkP, W), dim3(BA_T), ((size_t)d.nkf * 24 + d.np) * sizeof(double), s, d, d_obs, dw, iw, states);
-            tb_prof_end(ctx);
-            tb_prof_begin(ctx, "k_ba_decide");
-            hipLaunchKernelGGL(k_ba_decide, dim3((W + 63) / 64), dim3(64), 0, s, d, dw, states, running + rounds % ring);
-            tb_prof_end(ctx);
-            TB_HIP(ctx, hipGetLastError());
         }
+        tb_prof_begin(ctx, "k_ba_update");
+        hipLaunchKernelGGL(k_ba_update, dim3(d.nblkP, W), dim3(BA_T), ((size_t)d.nkf * 24 + d.np) * sizeof(double), s, d, d_obs, dw, iw, states);
+        tb_prof_end(ctx);
+        tb_prof_begin(ctx, "k_ba_decide");
+        hipLaunchKernelGGL(k_ba_decide, dim3(W), dim3(64), 0, s, d, dw, states, running + round % ring);
+        tb_prof_end(ctx);
+        TB_HIP(ctx, hipGetLastError());
+        return TB_OK;
+    };
+    int host_running = 1, rounds = 0, rc = TB_OK;
+    const int max_rounds = std::min(iters * 10 + 1, 1000); /* ring size below */
+    int batch = iters + 1;
+    /* Small batches: the set-up and the first iters + 1 trials -- ~100 launches of a few microseconds each, which a host
+     * thread cannot queue as fast as the GPU retires them -- are captured ONCE into a HIP graph per (shape, buffers) and
+     * replayed with one call (the kernels read their state from the workspace, so the graph is the same every time). Large
+     * batches launch directly: their kernels are long enough for the queue to stay ahead, and the
+     * per-kernel timing hooks need ordinary launches. */
+    const bool use_graph = W <= 32 && !ctx->prof && std::min(batch, max_rounds) > 0;
+    if (use_graph) {
+        struct Key { BaDims d; const void *poses, *pts, *obs, *counts, *work; hipStream_t s; } key;
+        memset(&key, 0, sizeof key);
+        key.d = d; key.poses = d_poses; key.pts = d_pts; key.obs = d_obs; key.counts = d_counts; key.work = d_work; key.s = s;
+        const std::string kb((const char*)&key, sizeof key);
+        hipGraphExec_t exec = nullptr;
+        for (auto& g : ctx->ba_graphs)
+            if (g.first == kb) exec = g.second;
+        const int nfirst = std::min(batch, max_rounds);
+        if (!exec) {
+            /* one capture at a time in the process: the pipeline drives its BA partitions from one host thread each, and
+             * three threads capturing on three streams at once produced graphs that did not replay the call (wrong poses,
+             * no error) -- a capture is rare (once per shape and buffer set), so it simply takes a lock */
+            static std::mutex capture_lock;
+            std::lock_guard<std::mutex> guard(capture_lock);
+            hipGraph_t graph = nullptr;
+#ifndef BA_CAPTURE_MODE
+#define BA_CAPTURE_MODE hipStreamCaptureModeThreadLocal
+#endif
+            TB_HIP(ctx, hipStreamBeginCapture(s, BA_CAPTURE_MODE));
+            rc = enqueue_head();
+            for (int r = 0; r < nfirst && rc == TB_OK; r++) rc = enqueue_round(r);
+            const hipError_t e = hipStreamEndCapture(s, &graph); /* always ends the capture, also after a failed launch */
+            if (rc != TB_OK) { if (graph) hipGraphDestroy(graph); return rc; }
+            TB_HIP(ctx, e);
+            const hipError_t e2 = hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0);
+            hipGraphDestroy(graph);
+            TB_HIP(ctx, e2);
+            if (ctx->ba_graphs.size() >= 8) { /* a caller cycling through more buffer sets than this re-captures */
+                hipGraphExecDestroy(ctx->ba_graphs.front().second);
+                ctx->ba_graphs.erase(ctx->ba_graphs.begin());
+            }
+            ctx->ba_graphs.emplace_back(kb, exec);
+        }
+        TB_HIP(ctx, hipGraphLaunch(exec, s));
+        rounds = nfirst;
+#ifdef BA_GRAPH_DEBUG
+        {
+            int ef[4] = {-7, -7, -7, -7}, rn[2] = {-7, -7};
+            hipMemcpyAsync(ef, errflag, sizeof(int) * std::min(W, 4), hipMemcpyDeviceToHost, s);
+            hipMemcpyAsync(rn, running, sizeof rn, hipMemcpyDeviceToHost, s);
+            hipStreamSynchronize(s);
+            fprintf(stderr, "[ba graph] ctx %p exec %p cache %zu W %d errflag %d %d %d %d running %d %d work %p\n", (void*)ctx, (void*)exec,
+                    ctx->ba_graphs.size(), W, ef[0], ef[1], ef[2], ef[3], rn[0], rn[1], d_work);
+        }
+#endif
+    } else if ((rc = enqueue_head()) != TB_OK) return rc;
+    bool replayed = use_graph; /* the first batch of trials is already queued */
+    while (host_running > 0 && (rounds < max_rounds || replayed)) {
+        if (!replayed)
+            for (int r = 0; r < batch && rounds < max_rounds; r++, rounds++)
+                if ((rc = enqueue_round(rounds)) != TB_OK) return rc;
+        replayed = false;
         /* windows still running after the expected number of trials (rejected steps): one sync, then continue */
         TB_HIP(ctx, hipMemcpyAsync(&host_running, running + (rounds - 1) % ring, sizeof(int), hipMemcpyDeviceToHost, s));
         TB_HIP(ctx, hipStreamSynchronize(s));

@@ -176,6 +176,7 @@ void tb_destroy(tb_ctx* ctx) {
     while (!ctx->live.empty()) tb_extractor_destroy(*ctx->live.begin()); /* plans never outlive their context */
     for (int i = 0; i < 12; i++)
         if (ctx->scratch[i]) hipFree(ctx->scratch[i]);
+    for (auto& g : ctx->ba_graphs) hipGraphExecDestroy(g.second);
     prof_drain(ctx);
     for (hipEvent_t e : ctx->prof_pool) hipEventDestroy(e);
     if (ctx->own_stream) hipStreamDestroy(ctx->own_stream);
