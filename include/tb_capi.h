@@ -209,6 +209,37 @@ int tb_search_by_violence_batch_dev(tb_ctx* ctx, int npairs, const tb_keypoint* 
                                     int min_level, int max_level, float radius, int th_low, float nratio, int histo_len,
                                     int check_orientation, tb_match* out, int cap, int32_t* out_counts, int32_t* flags);
 
+/* SURVEY 8(f) row 4, second half -- the DBoW2 transform behind Frame::SetBow (src/types/Frame.cpp:267-270:
+ * voc->transform(descriptors, mBowVec, mFeatVec, 4); third_part/DBoW2/DBoW2/TemplatedVocabulary.h:1124-1260, FORB.cpp:81-101).
+ * The reference tree ships no vocabulary file, so the caller supplies the tree (tb_vocabulary: the arrays of an ORBvoc-style
+ * text file, TemplatedVocabulary::loadFromTextFile :1338-1420); tb_vocab_create uploads it once per context.
+ * tb_bow_transform: per descriptor the word it falls into (word_ids), that word's weight (weights; 0 = a stopped word, which
+ * enters neither vector) and its ancestor at level L - levelsup (node_ids: the key of the frame's FeatureVector; the root when
+ * L - levelsup <= 0; where a branch ends above that level the reference leaves the id unset -- here it is the leaf).
+ * Host pointers. The BowVector / FeatureVector containers are built from these arrays (shim: Frame::SetBow). */
+typedef struct tb_vocab tb_vocab;
+int tb_vocab_create(tb_ctx* ctx, const tb_vocabulary* host, tb_vocab** out);
+void tb_vocab_destroy(tb_vocab* v);
+int tb_bow_transform(tb_ctx* ctx, const tb_vocab* voc, const uint8_t* desc, int n, int levelsup, int32_t* word_ids,
+                     double* weights, int32_t* node_ids);
+/* Batched, device-resident: frame f has counts[f] descriptors at desc + f * desc_pitch * 32. Outputs [nframes][desc_pitch]:
+ * word_ids / node_ids / weights (each nullable), and fv_keys (nullable, uint64): the frame's FeatureVector as a sorted list --
+ * (node id << 32 | feature index) of every feature whose word is not stopped, ascending, i.e. the std::map's node order
+ * with every node's features in insertion order; fv_counts[f] entries. Feeds tb_search_by_bow_batch_dev. Device pointers,
+ * asynchronous on the context's stream; desc_pitch <= 8192. */
+int tb_bow_transform_batch_dev(tb_ctx* ctx, const tb_vocab* voc, int nframes, const uint8_t* desc, const int32_t* counts,
+                               int desc_pitch, int levelsup, int32_t* word_ids, int32_t* node_ids, double* weights,
+                               uint64_t* fv_keys, int32_t* fv_counts);
+/* Batched, device-resident Matcher::searchByBow(F1, F2, MapPointOnly) (matcher.cpp:619-721) on feature vectors in the
+ * sorted-list form above: pair p matches frame p of side 1 against frame p of side 2 (keys / descriptors [npairs][pitchX],
+ * fv keys [npairs][pitchX] with fv_countsX[p] entries; has_mp2 nullable [npairs][pitch2]). Matches [npairs][cap] in the
+ * reference's order, out_counts[p]; flags[p] != 0: a rotation bin outside the histogram (the reference asserts). */
+int tb_search_by_bow_batch_dev(tb_ctx* ctx, int npairs, const tb_keypoint* k1, const uint8_t* d1, int pitch1,
+                               const uint64_t* fv1, const int32_t* fv_counts1, const tb_keypoint* k2, const uint8_t* d2, int pitch2,
+                               const uint64_t* fv2, const int32_t* fv_counts2, const uint8_t* has_mp2, int map_point_only,
+                               int th_low, float nratio, int histo_len, int check_orientation, tb_match* out, int cap,
+                               int32_t* out_counts, int32_t* flags);
+
 /* Stereo tracks -> PoseOptimization's inputs, batched and device-resident (round 3). For frame f and each of its
  * match_counts[f] left <-> right matches (queryIdx = left key, trainIdx = right key; the output of
  * tb_search_by_bf_batch_dev): Depth = bf / |x_right - x_left| (LocalBA::AddMapPointsByStereo, LocalBA.cpp:60-64), the map

@@ -32,4 +32,37 @@ public:
 };
 }
 #endif
+/* DBoW2::BowVector (third_part/DBoW2/DBoW2/BowVector.h:56-110) and the vocabulary Frame::SetBow takes. The reference's
+ * ORBVocabulary is DBoW2::TemplatedVocabulary<FORB::TDescriptor, FORB> (include/types/Frame.h:22), whose tree is a protected
+ * member; what this path needs of it is the tree itself, so the stand-in keeps it as the flat arrays of tb_vocabulary and
+ * reads them from the same ORBvoc-style text file (TemplatedVocabulary::loadFromTextFile, TemplatedVocabulary.h:1338-1420).
+ * A build against the real DBoW2 keeps this class next to it: one loadFromTextFile call per vocabulary. */
+#include <cstdint>
+#include <string>
+namespace DBoW2 {
+typedef unsigned int WordId;
+typedef double WordValue;
+class BowVector : public std::map<WordId, WordValue> {};
+}
+struct tb_vocab;
+namespace TRACKING_BENCH {
+class FlatVocabulary {
+public:
+    FlatVocabulary() = default;
+    ~FlatVocabulary();                                       /* releases the device copy (shim library) */
+    FlatVocabulary(const FlatVocabulary&) = delete;
+    FlatVocabulary& operator=(const FlatVocabulary&) = delete;
+    bool loadFromTextFile(const std::string& filename);     /* TemplatedVocabulary.h:1338-1420 */
+    bool empty() const { return word_id.size() <= 1; }
+    unsigned int size() const { return nwords; }            /* number of words */
+    int getBranchingFactor() const { return k; }
+    int getDepthLevels() const { return L; }
+    int k = 0, L = 0, scoring = 0, weighting = 0;
+    unsigned int nwords = 0;
+    std::vector<int32_t> child_start, child_items, word_id;
+    std::vector<uint8_t> desc;
+    std::vector<double> weight;
+    mutable tb_vocab* device = nullptr;                      /* uploaded on first use by Frame::SetBow */
+};
+}
 #endif

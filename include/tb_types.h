@@ -66,6 +66,22 @@ typedef struct tb_mappoint {
     int32_t bad;
 } tb_mappoint;
 
+/* A DBoW2 vocabulary as flat arrays (reference third_part/DBoW2/DBoW2/TemplatedVocabulary.h:297-329, the tree that
+ * Frame::SetBow walks, src/types/Frame.cpp:267-270). Node 0 is the root; the children of node n are
+ * child_items[child_start[n] .. child_start[n + 1]) in the vocabulary's order (the order decides ties: the first child with
+ * the smallest distance wins, TemplatedVocabulary.h:1231-1244); a node without children is a word and carries word_id / weight.
+ * desc: 32 bytes per node (FORB::TDescriptor). k / L as in the vocabulary file's first line; weighting: 0 TF_IDF, 1 TF, 2 IDF,
+ * 3 BINARY; scoring: 0 L1_NORM, 1 L2_NORM, 2 CHI_SQUARE, 3 KL, 4 BHATTACHARYYA, 5 DOT_PRODUCT (BowVector.h:36-53). */
+typedef struct tb_vocabulary {
+    int32_t nnodes, k, L;
+    int32_t weighting, scoring;
+    const int32_t* child_start;   /* nnodes + 1 */
+    const int32_t* child_items;   /* child_start[nnodes] node ids */
+    const uint8_t* desc;          /* nnodes x 32 */
+    const int32_t* word_id;       /* nnodes, read for leaves */
+    const double* weight;         /* nnodes, read for leaves (WordValue) */
+} tb_vocabulary;
+
 /* One local-BA observation: keyframe index, point index, pixel, information scale. */
 typedef struct tb_ba_obs {
     int32_t kf, pt;

@@ -20,6 +20,7 @@ namespace TRACKING_BENCH
 #define FRAME_GRID_COLS 120
     class Frame;
     class CameraModel;
+    typedef FlatVocabulary ORBVocabulary;   // reference Frame.h:22 names DBoW2's tree type; see tb_compat/deps.h
 
     class Feature
     {
@@ -49,7 +50,9 @@ namespace TRACKING_BENCH
         std::shared_ptr<Feature>& GetKey(size_t id){return mvKeys.at(id);}
         cv::Mat GetDescriptors() const{return mDescriptors;}
         cv::Mat GetDescriptor(int id) const{return mDescriptors.row(id);}   // reference Frame.h:81
-        // reference Frame.h:98 (filled by ComputeBoW, Frame.cpp:266-271; here the caller fills it, the vocabulary is not part of the path)
+        // reference Frame.h:96-98, Frame.cpp:267-270: voc->transform(descriptors, mBowVec, mFeatVec, 4) -- the tree walk runs on the GPU
+        void SetBow(const std::shared_ptr<ORBVocabulary>& voc);
+        DBoW2::BowVector& GetBowVector(){return mBowVec;}
         DBoW2::FeatureVector& GetFeatureVector(){return mFeatVec;}
         bool GetOutlier(size_t id){return mvbOutlier.at(id) != 0;}
         void SetOutlier(size_t id, bool state){mvbOutlier.at(id)=state;}
@@ -76,6 +79,7 @@ namespace TRACKING_BENCH
         Eigen::Vector3f mOw;
         std::vector<std::shared_ptr<Feature>> mvKeys;
         cv::Mat mDescriptors;
+        DBoW2::BowVector mBowVec;
         DBoW2::FeatureVector mFeatVec;
         std::vector<std::shared_ptr<MapPoint>> mvpMapPoints;
         std::shared_ptr<CameraModel> mpCamera = nullptr;

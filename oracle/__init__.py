@@ -325,6 +325,43 @@ def search_by_projection_map(Tcw1, cam1, img1_w, img1_h, k1, d1, taken1, mps, mp
     return out[:n].copy()
 
 
+def bow_transform(voc, desc, levelsup=4):
+    """voc->transform(features, BowVector, FeatureVector, levelsup) per feature (Frame::SetBow, Frame.cpp:267-270;
+    TemplatedVocabulary.h:1124-1260): (word_ids i32, weights f64, node_ids i32). voc: synth.Vocabulary."""
+    d = _desc(desc)
+    n = len(d)
+    wid = np.zeros(max(n, 1), np.int32); wt = np.zeros(max(n, 1), np.float64); nid = np.zeros(max(n, 1), np.int32)
+    _chk(lib().orc_bow_transform(C.byref(voc.c), _p(d), n, int(levelsup), _p(wid), _p(wt), _p(nid)))
+    return wid[:n], wt[:n], nid[:n]
+
+
+def bow_containers(word_ids, weights, node_ids, weighting=0, scoring=0):
+    """The two containers of TemplatedVocabulary::transform(features, v, fv, levelsup) (TemplatedVocabulary.h:1124-1188):
+    BowVector {word: value} (TF / TF-IDF add the weights in feature order, IDF / BINARY keep the first; then the scoring
+    object's normalisation, BowVector.cpp:57-80) and FeatureVector {node: [feature indices]}; stopped words (weight 0) enter neither."""
+    bv, fv = {}, {}
+    for i, (w, wt, n) in enumerate(zip(word_ids.tolist(), weights.tolist(), node_ids.tolist())):
+        if wt > 0:
+            if weighting in (0, 1):
+                bv[w] = bv.get(w, 0.0) + wt
+            else:
+                bv.setdefault(w, wt)
+            fv.setdefault(n, []).append(i)
+    must, l2 = scoring != 5, scoring == 1
+    if bv and not must and weighting in (0, 1):
+        nd = float(len(bv))
+        bv = {k: v / nd for k, v in bv.items()}
+    if must:
+        norm = 0.0
+        for k in sorted(bv):
+            norm += bv[k] * bv[k] if l2 else abs(bv[k])
+        if l2:
+            norm = float(np.sqrt(norm))
+        if norm > 0:
+            bv = {k: v / norm for k, v in bv.items()}
+    return dict(sorted(bv.items())), dict(sorted(fv.items()))
+
+
 def stereo_tracks_to_obs(kl, kr, matches, K, bf, inv_sigma2):
     """The composition of the timed configuration: left <-> right matches -> PoseOptimization rows (stereo depth of the left key,
     LocalBA.cpp:60-64, observed at the right key's pixel, LocalBA.cpp:333-363)."""

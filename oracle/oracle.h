@@ -96,6 +96,8 @@ int orc_search_by_projection_map(const float Tcw1[16], const tb_camera* cam1, in
 /* LocalBA::PoseOptimization, LocalBA.cpp:291-490 (g2o LM restated).
  * K = fx,fy,cx,cy. Tcw_in: row-major 4x4 float (vertex reset value). outlier: in/out flags.
  * Returns nInitialCorrespondences - nBad (>=0) or <0 on error. */
+int orc_bow_transform(const tb_vocabulary* V, const uint8_t* desc, int n, int levelsup, int32_t* word_ids, double* weights,
+                      int32_t* node_ids);
 int orc_stereo_tracks_to_obs(const tb_keypoint* kl, const tb_keypoint* kr, const tb_match* matches, int nmatches, const float K[4],
                              float bf, const float* inv_sigma2, int nlevels, tb_obs* obs, int cap);
 int orc_pose_opt(const double K[4], const float Tcw_in[16], const tb_obs* obs, int n,

@@ -505,4 +505,38 @@ int orc_stereo_tracks_to_obs(const tb_keypoint* kl, const tb_keypoint* kr, const
     return n;
 }
 
+
+/* TemplatedVocabulary::transform(feature, word_id, weight, nid, levelsup) for every descriptor
+ * (third_part/DBoW2/DBoW2/TemplatedVocabulary.h:1218-1260), distances by FORB::distance (FORB.cpp:81-101, a SWAR popcount
+ * of the XOR). The tree comes as flat arrays (tb_vocabulary). Where a branch ends above level L - levelsup the reference
+ * leaves *nid unset (its caller passes an uninitialised NodeId): defined here as the leaf. */
+int orc_bow_transform(const tb_vocabulary* V, const uint8_t* desc, int n, int levelsup, int32_t* word_ids, double* weights,
+                      int32_t* node_ids) {
+    if (!V || V->nnodes < 1) return -1;
+    const int nid_level = V->L - levelsup;
+    for (int f = 0; f < n; f++) {
+        const uint8_t* a = desc + 32 * (size_t)f;
+        int final_id = 0, level = 0, nid = 0;
+        bool nid_set = nid_level <= 0;
+        while (V->child_start[final_id + 1] > V->child_start[final_id]) {
+            level++;
+            const int c0 = V->child_start[final_id], c1 = V->child_start[final_id + 1];
+            int best = V->child_items[c0];
+            int best_d = orc_descriptor_distance(a, V->desc + 32 * (size_t)best);
+            for (int c = c0 + 1; c < c1; c++) {
+                const int id = V->child_items[c];
+                const int d = orc_descriptor_distance(a, V->desc + 32 * (size_t)id);
+                if (d < best_d) { best_d = d; best = id; }
+            }
+            final_id = best;
+            if (level == nid_level) { nid = final_id; nid_set = true; }
+        }
+        if (!nid_set) nid = final_id;
+        word_ids[f] = V->word_id[final_id];
+        weights[f] = V->weight[final_id];
+        node_ids[f] = nid;
+    }
+    return 0;
+}
+
 }  // extern "C"

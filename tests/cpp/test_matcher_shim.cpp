@@ -152,12 +152,20 @@ int main(int argc, char** argv)
     auto rmatches = matcher_ptr->searchByOPFlow(frame2_ptr, frame1_ptr, flow_pts_r, true, true);
     std::vector<float> depths = localBa.AddMapPointsByStereo(frame1_ptr, frame2_ptr, 386.1448f, 718.856f);
 
-    // Matcher::searchByBow (matcher.cpp:619-721): the vocabulary is not part of the path, so the frames' feature vectors
-    // are filled here -- node = a hash of two descriptor bytes, the same rule tests/test_gpu_shim.py applies
-    for (int i = 0; i < descriptors1.rows; i++)
-        frame1_ptr->GetFeatureVector().addFeature((unsigned)(descriptors1.ptr(i)[3] ^ descriptors1.ptr(i)[17]) % 64u, (unsigned)i);
-    for (int i = 0; i < descriptors2.rows; i++)
-        frame2_ptr->GetFeatureVector().addFeature((unsigned)(descriptors2.ptr(i)[3] ^ descriptors2.ptr(i)[17]) % 64u, (unsigned)i);
+    // Frame::SetBow (Frame.cpp:267-270) as test/test_vo.cpp:661,705 calls it, then Matcher::searchByBow (matcher.cpp:619-721).
+    // The reference tree ships no vocabulary file: argv[5] is a seeded synthetic one in the ORBvoc text format
+    auto vocabulary = std::make_shared<ORBVocabulary>();
+    if (!vocabulary->loadFromTextFile(argv[5])) { std::cerr << "vocabulary\n"; return 4; }
+    frame1_ptr->SetBow(vocabulary);
+    frame2_ptr->SetBow(vocabulary);
+    std::vector<uint32_t> fv1_flat;   // node, count, indices ... of frame 1's FeatureVector
+    for (const auto& kv : frame1_ptr->GetFeatureVector())
+    {
+        fv1_flat.push_back(kv.first); fv1_flat.push_back((uint32_t)kv.second.size());
+        fv1_flat.insert(fv1_flat.end(), kv.second.begin(), kv.second.end());
+    }
+    std::vector<uint32_t> bv1_ids; std::vector<double> bv1_vals;
+    for (const auto& kv : frame1_ptr->GetBowVector()) { bv1_ids.push_back(kv.first); bv1_vals.push_back(kv.second); }
     matcher_ptr->setViolenceParam(80, 100, 30, true, 0.95f);
     auto bmatches = matcher_ptr->searchByBow(frame1_ptr, frame2_ptr);
 
@@ -175,6 +183,7 @@ int main(int argc, char** argv)
     put(o, flow_pts.data(), flow_pts.size()); put(o, fmatches.data(), fmatches.size());
     put(o, rmatches.data(), rmatches.size()); put(o, depths.data(), depths.size());
     put(o, bmatches.data(), bmatches.size());
+    put(o, fv1_flat.data(), fv1_flat.size()); put(o, bv1_ids.data(), bv1_ids.size()); put(o, bv1_vals.data(), bv1_vals.size());
     std::cout << "kps " << keypoints1.size() << "/" << keypoints2.size() << " added " << added.size() << " bf " << matches.size()
               << " violence " << vmatches.size() << " fast " << fast_kps.size() << " pose inliers " << inliers
               << " projection " << pmatches.size() << " map projection " << mmatches.size() << " flow " << fmatches.size()

@@ -39,18 +39,23 @@ def test_reference_style_driver_on_shims(golden, kitti_pair):
     isig2 = oracle.scale_factors(5, 0.8)[3]
     octave = np.array([int(np.argmin(np.abs(isig2 - v))) for v in obs["inv_sigma2"]], np.float32)
     rec = np.stack([obs["u"], obs["v"], obs["X"], obs["Y"], obs["Z"], octave], 1).astype(np.float32)
+    voc = synth.vocabulary(41, 4, 6, stop_frac=0.08)          # L = 6: the FeatureVector's nodes are the level-2 ancestors (16 of them)
     with tempfile.TemporaryDirectory() as td:
         ob, out = os.path.join(td, "obs.bin"), os.path.join(td, "out.bin")
+        vocp = os.path.join(td, "voc.txt")
+        voc.to_text(vocp)
         with open(ob, "wb") as f:
             f.write(struct.pack("<i", n))
             f.write(rec.tobytes())
         log = subprocess.check_output([EXE, os.path.join(GOLDEN, "kitti00_left_1241x376.pgm"),
-                                       os.path.join(GOLDEN, "kitti00_right_1241x376.pgm"), ob, out], timeout=300).decode()
+                                       os.path.join(GOLDEN, "kitti00_right_1241x376.pgm"), ob, out, vocp], timeout=300).decode()
         assert "kps" in log
-        (k1, d1, k2, d2, ka, da, bf, vio, fg, T, outl, ninl, k1now, taken1, nomp2, mp, mpd, pm, mm, fpts, fm, rm, depths, bm) = _read_blocks(
+        (k1, d1, k2, d2, ka, da, bf, vio, fg, T, outl, ninl, k1now, taken1, nomp2, mp, mpd, pm, mm, fpts, fm, rm, depths, bm,
+         fv1flat, bv1ids, bv1vals) = _read_blocks(
             out, [capi.KEYPOINT, np.uint8, capi.KEYPOINT, np.uint8, capi.KEYPOINT, np.uint8, capi.MATCH, capi.MATCH,
                   capi.KEYPOINT, np.float32, np.uint8, np.int32, capi.KEYPOINT, np.uint8, np.uint8, capi.MAPPOINT, np.uint8,
-                  capi.MATCH, capi.MATCH, np.dtype([("x", "<f4"), ("y", "<f4")]), capi.MATCH, capi.MATCH, np.float32, capi.MATCH])
+                  capi.MATCH, capi.MATCH, np.dtype([("x", "<f4"), ("y", "<f4")]), capi.MATCH, capi.MATCH, np.float32, capi.MATCH,
+                  np.uint32, np.uint32, np.float64])
     assert np.array_equal(k1, golden["c5_kps_left"]) and np.array_equal(d1.reshape(-1, 32), golden["c5_desc_left"])
     assert np.array_equal(k2, golden["c5_kps_right"]) and np.array_equal(d2.reshape(-1, 32), golden["c5_desc_right"])
     assert np.array_equal(ka, golden["c5_addpoints_kps_left"]) and np.array_equal(da.reshape(-1, 32), golden["c5_addpoints_desc_left"])
@@ -84,13 +89,20 @@ def test_reference_style_driver_on_shims(golden, kitti_pair):
     odepth = oracle.add_map_points_by_stereo(imgR, imgL, cam, keys, 386.1448)
     assert len(depths) == len(k1now) and np.array_equal(depths.view(np.uint32), odepth.view(np.uint32))
     assert (depths[ridx] > 0).all() and (np.delete(depths, ridx) == -1).all()
-    # Matcher::searchByBow through the class API: feature vectors filled by the driver's hash rule (the vocabulary is outside)
+    # Frame::SetBow through the class API (the tree walk on the GPU) == the oracle's transform: both containers of frame 1
     D1, D2 = d1.reshape(-1, 32), d2.reshape(-1, 32)
-    fv1, fv2 = {}, {}
-    for i in range(len(D1)):
-        fv1.setdefault(int(D1[i, 3] ^ D1[i, 17]) % 64, []).append(i)
-    for i in range(len(D2)):
-        fv2.setdefault(int(D2[i, 3] ^ D2[i, 17]) % 64, []).append(i)
+    w1, wt1, n1 = oracle.bow_transform(voc, D1, 4)
+    w2, wt2, n2 = oracle.bow_transform(voc, D2, 4)
+    bv1, fv1 = oracle.bow_containers(w1, wt1, n1, voc.c.weighting, voc.c.scoring)
+    _, fv2 = oracle.bow_containers(w2, wt2, n2, voc.c.weighting, voc.c.scoring)
+    got_fv, i = {}, 0
+    while i < len(fv1flat):
+        node, cnt = int(fv1flat[i]), int(fv1flat[i + 1])
+        got_fv[node] = fv1flat[i + 2:i + 2 + cnt].tolist()
+        i += 2 + cnt
+    assert got_fv == fv1 and len(fv1) > 4
+    assert bv1ids.tolist() == list(bv1) and np.allclose(bv1vals, list(bv1.values()), rtol=1e-14, atol=0)
+    # ... and Matcher::searchByBow on the feature vectors SetBow filled
     bo = oracle.search_by_bow(k1, D1, fv1, k2, D2, fv2, th_low=80, nratio=0.95, histo_len=30, check_orientation=True)
     assert len(bo) > 5 and np.array_equal(bm, bo)
 
@@ -106,5 +118,6 @@ def test_shim_library_exports_reference_classes():
                  "TRACKING_BENCH::LocalBA::AddMapPointsByStereo",
                  "TRACKING_BENCH::Matcher::DescriptorDistance",
                  "TRACKING_BENCH::Matcher::ComputeThreeMaxima", "TRACKING_BENCH::LocalBA::PoseOptimization",
-                 "TRACKING_BENCH::LocalBA::LinearTriangle", "TRACKING_BENCH::Frame::ComputePyramid"):
+                 "TRACKING_BENCH::LocalBA::LinearTriangle", "TRACKING_BENCH::Frame::ComputePyramid", "TRACKING_BENCH::Frame::SetBow",
+                 "TRACKING_BENCH::FlatVocabulary::loadFromTextFile", "TRACKING_BENCH::MapPoint::MapPoint"):
         assert want in syms, want

@@ -38,7 +38,8 @@ EXPORTS = [
     "tb_descriptor_distance", "tb_three_maxima", "tb_match_bf", "tb_search_by_bf", "tb_search_by_bf_batch_dev",
     "tb_search_by_violence", "tb_search_by_bow", "tb_search_by_projection", "tb_search_by_projection_map", "tb_frame_grid_batch_dev",
     "tb_search_by_projection_batch_dev", "tb_search_by_projection_map_batch_dev",
-    "tb_search_by_violence_batch_dev", "tb_stereo_tracks_to_obs_batch_dev", "tb_pose_opt", "tb_pose_opt_batch_dev", "tb_local_ba", "tb_local_ba_batch_dev",
+    "tb_search_by_violence_batch_dev", "tb_stereo_tracks_to_obs_batch_dev", "tb_vocab_create", "tb_vocab_destroy", "tb_bow_transform",
+    "tb_bow_transform_batch_dev", "tb_search_by_bow_batch_dev", "tb_pose_opt", "tb_pose_opt_batch_dev", "tb_local_ba", "tb_local_ba_batch_dev",
     "tb_clahe", "tb_clahe_dev", "tb_optical_flow_pyr_lk", "tb_optical_flow_pyr_lk_dev", "tb_optical_flow_pyr_lk_batch_dev", "tb_search_by_opflow", "tb_search_by_opflow_batch_dev",
     "tb_find_fundamental_ransac", "tb_reject_with_f", "tb_reject_with_f_batch_dev", "tb_add_map_points_by_stereo", "tb_add_map_points_by_stereo_batch_dev",
     "tb_batch_run",
@@ -77,6 +78,8 @@ def lib():
         L.tb_destroy.restype = None
         L.tb_extractor_destroy.restype = None
         L.tb_three_maxima.restype = None
+        L.tb_vocab_destroy.restype = None
+        L.tb_vocab_destroy.argtypes = [C.c_void_p]
         L.tb_last_error.argtypes = [C.c_void_p]
         L.tb_destroy.argtypes = [C.c_void_p]
         L.tb_extractor_destroy.argtypes = [C.c_void_p]
@@ -432,6 +435,23 @@ class Context:
         assert len(cur) == len(last) == len(st)
         self.check(lib().tb_reject_with_f(self._h, _p(cur), _p(last), len(st), _p(st)))
         return st
+
+    def vocab_create(self, voc):
+        """Upload a synth.Vocabulary (tb_vocabulary arrays); returns an opaque handle for bow_transform / vocab_destroy."""
+        h = C.c_void_p()
+        self.check(lib().tb_vocab_create(self._h, C.byref(voc.c), C.byref(h)))
+        return h
+
+    def vocab_destroy(self, h):
+        lib().tb_vocab_destroy(h)
+
+    def bow_transform(self, vocab_handle, desc, levelsup=4):
+        """Frame::SetBow's voc->transform per feature (reference Frame.cpp:267-270): (word_ids, weights, node_ids)."""
+        d = self._desc(desc)
+        n = len(d)
+        wid = np.zeros(max(n, 1), np.int32); wt = np.zeros(max(n, 1), np.float64); nid = np.zeros(max(n, 1), np.int32)
+        self.check(lib().tb_bow_transform(self._h, vocab_handle, _p(d), n, int(levelsup), _p(wid), _p(wt), _p(nid)))
+        return wid[:n], wt[:n], nid[:n]
 
     def reject_with_f_batch(self, cur, last, status, counts=None):
         """tb_reject_with_f_batch_dev on torch tensors of this context's device: cur / last float32 [P, N, 2], status uint8

@@ -907,3 +907,256 @@ int tbk_stereo_obs(tb_ctx* ctx, int nframes, const tb_keypoint* d_kl, const tb_k
     TB_HIP(ctx, hipGetLastError());
     return TB_OK;
 }
+
+/* ---- SURVEY 8(f) row 4, second half: the DBoW2 transform (TemplatedVocabulary::transform, TemplatedVocabulary.h:1218-1260).
+ * One thread per descriptor walks the tree: at every level the Hamming distance (FORB::distance, FORB.cpp:81-101) to each
+ * child of the current node, the first child with the smallest distance wins (strict <, :1238). The children of a node are
+ * consecutive 32-byte rows gathered through the L2 (a 10^6-node ORB vocabulary is 32 MB; the upper levels stay cached, the
+ * leaves are one 320-byte gather per feature); ~k L = 60 distances per feature. Bound: gather latency; no SURVEY 8(d) row. */
+struct BowVocab {
+    int nnodes, L;
+    const int32_t* child_start;
+    const int32_t* child_items;
+    const uint8_t* desc;
+    const int32_t* word_id;
+    const double* weight;
+};
+__global__ void __launch_bounds__(256)
+k_bow_transform(BowVocab V, const uint8_t* __restrict__ desc, const int32_t* __restrict__ counts, int desc_pitch, int levelsup,
+                int32_t* __restrict__ word_ids, int32_t* __restrict__ node_ids, double* __restrict__ weights) {
+    const int f = blockIdx.y, i = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n = counts ? min(counts[f], desc_pitch) : desc_pitch;
+    if (i >= n) return;
+    const size_t at = (size_t)f * desc_pitch + i;
+    Desc256 a;
+    const unsigned long long* pa = reinterpret_cast<const unsigned long long*>(desc + 32 * at);
+    a.w[0] = pa[0]; a.w[1] = pa[1]; a.w[2] = pa[2]; a.w[3] = pa[3];
+    const int nid_level = V.L - levelsup;
+    int final_id = 0, level = 0, nid = 0;
+    bool nid_set = nid_level <= 0;   /* root (TemplatedVocabulary.h:1227) */
+    int c0 = V.child_start[0], c1 = V.child_start[1];
+    while (c1 > c0) {
+        level++;
+        int best = V.child_items[c0];
+        int best_d = bf_dist(a, reinterpret_cast<const unsigned long long*>(V.desc + 32 * (size_t)best));
+        for (int c = c0 + 1; c < c1; c++) {
+            const int id = V.child_items[c];
+            const int dd = bf_dist(a, reinterpret_cast<const unsigned long long*>(V.desc + 32 * (size_t)id));
+            if (dd < best_d) { best_d = dd; best = id; }
+        }
+        final_id = best;
+        if (level == nid_level) { nid = final_id; nid_set = true; }
+        c0 = V.child_start[final_id]; c1 = V.child_start[final_id + 1];
+    }
+    if (!nid_set) nid = final_id; /* the branch ended above level L - levelsup: the reference leaves *nid unset */
+    if (word_ids) word_ids[at] = V.word_id[final_id];
+    if (weights) weights[at] = V.weight[final_id];
+    if (node_ids) node_ids[at] = nid;
+}
+
+/* The frame's FeatureVector as a sorted key list: (node id << 32 | feature index) of the features whose word is not
+ * stopped (w > 0, TemplatedVocabulary.h:1159), ascending -- the std::map's node order, each node's features in insertion
+ * order. One workgroup per frame: keys into LDS (padding = all ones), bitonic sort, count of real keys. */
+#define BOW_MAXN 8192
+__global__ void __launch_bounds__(1024)
+k_bow_fv_sort(const int32_t* __restrict__ node_ids, const double* __restrict__ weights, const int32_t* __restrict__ counts,
+              int desc_pitch, unsigned long long* __restrict__ keys_out, int32_t* __restrict__ fv_counts) {
+    extern __shared__ __attribute__((aligned(16))) unsigned long long sk[];
+    __shared__ int wsum[16];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const int n = counts ? min(counts[f], desc_pitch) : desc_pitch;
+    int m = 1;
+    while (m < n) m <<= 1;
+    int mine = 0;
+    for (int i = tid; i < m; i += 1024) {
+        unsigned long long k = ~0ull;
+        if (i < n && weights[(size_t)f * desc_pitch + i] > 0) { k = ((unsigned long long)(unsigned)node_ids[(size_t)f * desc_pitch + i] << 32) | (unsigned)i; mine++; }
+        sk[i] = k;
+    }
+    mine = tb_wave_sum(mine);
+    if ((tid & 63) == 0) wsum[tid >> 6] = mine;
+    __syncthreads();
+    for (int k2 = 2; k2 <= m; k2 <<= 1)
+        for (int j = k2 >> 1; j > 0; j >>= 1) {
+            for (int i = tid; i < m; i += 1024) {
+                const int l = i ^ j;
+                if (l > i) {
+                    const unsigned long long x = sk[i], y = sk[l];
+                    const bool up = (i & k2) == 0;
+                    if ((x > y) == up) { sk[i] = y; sk[l] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    int total = 0;
+    for (int w = 0; w < 16; w++) total += wsum[w];
+    for (int i = tid; i < total; i += 1024) keys_out[(size_t)f * desc_pitch + i] = sk[i];
+    if (tid == 0) fv_counts[f] = total;
+}
+
+/* Batched searchByBow, search stage: one thread per entry of F1's feature vector (= the reference's emission order once the
+ * entries of nodes F2 does not have are dropped): the node's entries of F2 by binary search, then best / second best Hamming
+ * distance in list order (matcher.cpp:645-669). best[pos] = {bestDist1, bestDist2, bestIdx2, 1 if F2 has the node}. */
+struct BowBatch {
+    const tb_keypoint *k1, *k2;
+    const uint8_t *d1, *d2, *has_mp2;
+    const unsigned long long *fv1, *fv2;
+    const int32_t *n1, *n2;
+    int pitch1, pitch2, map_point_only, th_low, histo_len, check_orientation, cap;
+    float nratio;
+    int32_t* best;
+    tb_match* out;
+    int32_t *out_counts, *flags;
+};
+__global__ void __launch_bounds__(256)
+k_bow_search_batch(BowBatch B) {
+    const int p = blockIdx.y, pos = blockIdx.x * blockDim.x + threadIdx.x;
+    const int n1 = min(B.n1[p], B.pitch1), n2 = min(B.n2[p], B.pitch2);
+    if (pos >= n1) return;
+    const unsigned long long key = B.fv1[(size_t)p * B.pitch1 + pos];
+    const unsigned node = (unsigned)(key >> 32), idx1 = (unsigned)key;
+    const unsigned long long* F2 = B.fv2 + (size_t)p * B.pitch2;
+    int lo = 0, hi = n2;
+    const unsigned long long want = (unsigned long long)node << 32;
+    while (lo < hi) { const int mid = (lo + hi) >> 1; if (F2[mid] < want) lo = mid + 1; else hi = mid; }
+    int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256, found = 0;
+    if (idx1 < (unsigned)B.pitch1) {
+        Desc256 a;
+        const unsigned long long* pa = reinterpret_cast<const unsigned long long*>(B.d1 + 32 * ((size_t)p * B.pitch1 + idx1));
+        a.w[0] = pa[0]; a.w[1] = pa[1]; a.w[2] = pa[2]; a.w[3] = pa[3];
+        for (int q = lo; q < n2 && (unsigned)(F2[q] >> 32) == node; q++) {
+            found = 1;
+            const unsigned idx2 = (unsigned)F2[q];
+            if (idx2 >= (unsigned)B.pitch2) continue;
+            if (B.map_point_only && !(B.has_mp2 && B.has_mp2[(size_t)p * B.pitch2 + idx2])) continue;
+            const int dist = bf_dist(a, reinterpret_cast<const unsigned long long*>(B.d2 + 32 * ((size_t)p * B.pitch2 + idx2)));
+            if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = (int)idx2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+    }
+    reinterpret_cast<int4*>(B.best)[(size_t)p * B.pitch1 + pos] = make_int4(bestDist1, bestDist2, bestIdx2, found);
+}
+/* acceptance (matcher.cpp:671-689), rotation histogram, ComputeThreeMaxima and the reference's output order (kept bins in
+ * ascending order, emission order inside a bin: matcher.cpp:703-717) -- the structure of k_violence_accept_batch */
+__global__ void __launch_bounds__(256)
+k_bow_accept_batch(BowBatch B) {
+    __shared__ int hist[1024];
+    __shared__ int sflag[256];
+    __shared__ int tmp[8];
+    __shared__ int keep[3];
+    __shared__ int srun;
+    const int p = blockIdx.x, tid = threadIdx.x;
+    const int n1 = min(B.n1[p], B.pitch1);
+    const int32_t* best = B.best + (size_t)p * B.pitch1 * 4;
+    const unsigned long long* F1 = B.fv1 + (size_t)p * B.pitch1;
+    const tb_keypoint* k1 = B.k1 + (size_t)p * B.pitch1;
+    const tb_keypoint* k2 = B.k2 + (size_t)p * B.pitch2;
+    tb_match* out = B.out + (size_t)p * B.cap;
+    const float factor = 1.f / (float)B.histo_len;
+    auto accepted = [&](int pos, int& bin) -> bool {
+        if (pos >= n1) return false;
+        const int bd = best[4 * (size_t)pos], bd2 = best[4 * (size_t)pos + 1], bi = best[4 * (size_t)pos + 2];
+        if (best[4 * (size_t)pos + 3] == 0 || bi < 0) return false;
+        if (!(bd < B.th_low && (float)bd < B.nratio * (float)bd2)) return false;
+        bin = 0;
+        if (B.check_orientation) {
+            float rot = k1[(unsigned)F1[pos]].angle - k2[bi].angle;
+            if (rot < 0) rot += 360.f;
+            bin = (int)roundf(rot * factor);
+            if (bin == B.histo_len) bin = 0;
+            if (bin < 0 || bin >= B.histo_len) { B.flags[p] = 2; return false; } /* the reference asserts */
+        }
+        return true;
+    };
+    if (tid == 0) { keep[0] = B.check_orientation ? -1 : 0; keep[1] = keep[2] = -1; srun = 0; B.flags[p] = 0; }
+    for (int b = tid; b < B.histo_len; b += 256) hist[b] = 0;
+    __syncthreads();
+    if (B.check_orientation) {
+        for (int pos = tid; pos < n1; pos += 256) { int bin; if (accepted(pos, bin)) atomicAdd(&hist[bin], 1); }
+        __syncthreads();
+        if (tid == 0) { /* Matcher::ComputeThreeMaxima, matcher.cpp:810-851 */
+            int max1 = 0, max2 = 0, max3 = 0, i1 = -1, i2 = -1, i3 = -1;
+            for (int i = 0; i < B.histo_len; i++) {
+                const int s = hist[i];
+                if (s > max1) { max3 = max2; max2 = max1; max1 = s; i3 = i2; i2 = i1; i1 = i; }
+                else if (s > max2) { max3 = max2; max2 = s; i3 = i2; i2 = i; }
+                else if (s > max3) { max3 = s; i3 = i; }
+            }
+            if ((float)max2 < 0.1f * (float)max1) { i2 = -1; i3 = -1; }
+            else if ((float)max3 < 0.1f * (float)max1) { i3 = -1; }
+            int a = i1 < 0 ? (1 << 30) : i1, b = i2 < 0 ? (1 << 30) : i2, c = i3 < 0 ? (1 << 30) : i3, t;
+            if (a > b) { t = a; a = b; b = t; }
+            if (b > c) { t = b; b = c; c = t; }
+            if (a > b) { t = a; a = b; b = t; }
+            keep[0] = a < (1 << 30) ? a : -1; keep[1] = b < (1 << 30) ? b : -1; keep[2] = c < (1 << 30) ? c : -1;
+        }
+        __syncthreads();
+    }
+    for (int kb = 0; kb < 3; kb++) {
+        const int want = keep[kb];
+        if (want < 0) continue;
+        for (int e0 = 0; e0 < n1; e0 += 256) {
+            const int pos = e0 + tid;
+            int bin = 0;
+            const int f = (accepted(pos, bin) && (!B.check_orientation || bin == want)) ? 1 : 0;
+            sflag[tid] = f;
+            __syncthreads();
+            const int total = tb_block_excl_scan(sflag, 256, tmp);
+            const int slot = srun + sflag[tid];
+            if (f && slot < B.cap) {
+                tb_match m;
+                m.queryIdx = (int)(unsigned)F1[pos]; m.trainIdx = best[4 * (size_t)pos + 2]; m.imgIdx = -1; m.distance = (float)best[4 * (size_t)pos];
+                out[slot] = m;
+            }
+            __syncthreads();
+            if (tid == 0) srun += total;
+            __syncthreads();
+        }
+    }
+    if (tid == 0) B.out_counts[p] = srun;
+}
+
+int tbk_bow_transform(tb_ctx* ctx, int nnodes, int L, const int32_t* d_child_start, const int32_t* d_child_items, const uint8_t* d_vdesc,
+                      const int32_t* d_word_id, const double* d_weight, int nframes, const uint8_t* d_desc, const int32_t* d_counts,
+                      int desc_pitch, int levelsup, int32_t* d_word_ids, int32_t* d_node_ids, double* d_weights,
+                      unsigned long long* d_fv_keys, int32_t* d_fv_counts) {
+    if (nframes <= 0 || desc_pitch <= 0) return TB_OK;
+    BowVocab V = {nnodes, L, d_child_start, d_child_items, d_vdesc, d_word_id, d_weight};
+    tb_prof_begin(ctx, "k_bow_transform");
+    hipLaunchKernelGGL(k_bow_transform, dim3((desc_pitch + 255) / 256, nframes), dim3(256), 0, ctx->stream, V, d_desc, d_counts, desc_pitch,
+                       levelsup, d_word_ids, d_node_ids, d_weights);
+    tb_prof_end(ctx);
+    TB_HIP(ctx, hipGetLastError());
+    if (d_fv_keys) {
+        int m = 1;
+        while (m < desc_pitch) m <<= 1;
+        const size_t lds = (size_t)m * sizeof(unsigned long long);
+        TB_HIP(ctx, hipFuncSetAttribute((const void*)k_bow_fv_sort, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        tb_prof_begin(ctx, "k_bow_fv_sort");
+        hipLaunchKernelGGL(k_bow_fv_sort, dim3(nframes), dim3(1024), lds, ctx->stream, d_node_ids, d_weights, d_counts, desc_pitch, d_fv_keys,
+                           d_fv_counts);
+        tb_prof_end(ctx);
+        TB_HIP(ctx, hipGetLastError());
+    }
+    return TB_OK;
+}
+
+int tbk_bow_search_batch(tb_ctx* ctx, int npairs, const tb_keypoint* d_k1, const uint8_t* d_d1, int pitch1, const unsigned long long* d_fv1,
+                         const int32_t* d_n1, const tb_keypoint* d_k2, const uint8_t* d_d2, int pitch2, const unsigned long long* d_fv2,
+                         const int32_t* d_n2, const uint8_t* d_has_mp2, int map_point_only, int th_low, float nratio, int histo_len,
+                         int check_orientation, tb_match* d_out, int cap, int32_t* d_out_counts, int32_t* d_flags, int32_t* d_best) {
+    if (npairs <= 0) return TB_OK;
+    BowBatch B;
+    B.k1 = d_k1; B.k2 = d_k2; B.d1 = d_d1; B.d2 = d_d2; B.has_mp2 = d_has_mp2; B.fv1 = d_fv1; B.fv2 = d_fv2; B.n1 = d_n1; B.n2 = d_n2;
+    B.pitch1 = pitch1; B.pitch2 = pitch2; B.map_point_only = map_point_only; B.th_low = th_low; B.histo_len = histo_len;
+    B.check_orientation = check_orientation; B.cap = cap; B.nratio = nratio; B.best = d_best; B.out = d_out; B.out_counts = d_out_counts;
+    B.flags = d_flags;
+    tb_prof_begin(ctx, "k_bow_search_batch");
+    hipLaunchKernelGGL(k_bow_search_batch, dim3((pitch1 + 255) / 256, npairs), dim3(256), 0, ctx->stream, B);
+    tb_prof_end(ctx);
+    tb_prof_begin(ctx, "k_bow_accept_batch");
+    hipLaunchKernelGGL(k_bow_accept_batch, dim3(npairs), dim3(256), 0, ctx->stream, B);
+    tb_prof_end(ctx);
+    TB_HIP(ctx, hipGetLastError());
+    return TB_OK;
+}

@@ -906,6 +906,107 @@ int tb_search_by_bf_batch_dev(tb_ctx* ctx, int npairs, const uint8_t* desc1, con
                         (unsigned long long*)tb, (unsigned long long*)qb);
 }
 
+/* ---- DBoW2 transform (see include/tb_capi.h) */
+struct tb_vocab {
+    tb_ctx* ctx = nullptr;
+    int nnodes = 0, k = 0, L = 0, weighting = 0, scoring = 0;
+    int32_t *d_child_start = nullptr, *d_child_items = nullptr, *d_word_id = nullptr;
+    uint8_t* d_desc = nullptr;
+    double* d_weight = nullptr;
+};
+
+void tb_vocab_destroy(tb_vocab* v) {
+    if (!v) return;
+    if (v->ctx) hipSetDevice(v->ctx->device);
+    hipFree(v->d_child_start); hipFree(v->d_child_items); hipFree(v->d_word_id); hipFree(v->d_desc); hipFree(v->d_weight);
+    delete v;
+}
+
+int tb_vocab_create(tb_ctx* ctx, const tb_vocabulary* h, tb_vocab** out) {
+    TB_ENTER(ctx);
+    if (!ctx || !h || !out || h->nnodes < 1 || !h->child_start || !h->desc || !h->word_id || !h->weight) return TB_EINVAL;
+    *out = nullptr;
+    const int nn = h->nnodes, nc = h->child_start[nn];
+    /* the tree must be walkable without a bounds test in the kernel: offsets ascending, children in range, no node its own
+     * ancestor (children have larger ids than their parents in every DBoW2 file: ids are assigned in creation order) */
+    if (h->child_start[0] != 0 || nc < 0 || nc > nn || (nc && !h->child_items)) return tb_fail(ctx, TB_EINVAL, "vocabulary: child offsets");
+    for (int n = 0; n < nn; n++) {
+        if (h->child_start[n + 1] < h->child_start[n]) return tb_fail(ctx, TB_EINVAL, "vocabulary: child offsets of node %d", n);
+        for (int c = h->child_start[n]; c < h->child_start[n + 1]; c++)
+            if (h->child_items[c] <= n || h->child_items[c] >= nn) return tb_fail(ctx, TB_EINVAL, "vocabulary: child %d of node %d", h->child_items[c], n);
+    }
+    tb_vocab* v = new (std::nothrow) tb_vocab();
+    if (!v) return TB_ENOMEM;
+    v->ctx = ctx; v->nnodes = nn; v->k = h->k; v->L = h->L; v->weighting = h->weighting; v->scoring = h->scoring;
+    hipError_t e = hipMalloc(&v->d_child_start, (size_t)(nn + 1) * 4);
+    if (e == hipSuccess) e = hipMalloc(&v->d_child_items, (size_t)std::max(nc, 1) * 4);
+    if (e == hipSuccess) e = hipMalloc(&v->d_word_id, (size_t)nn * 4);
+    if (e == hipSuccess) e = hipMalloc(&v->d_desc, (size_t)nn * 32);
+    if (e == hipSuccess) e = hipMalloc(&v->d_weight, (size_t)nn * 8);
+    if (e == hipSuccess) e = hipMemcpy(v->d_child_start, h->child_start, (size_t)(nn + 1) * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess && nc) e = hipMemcpy(v->d_child_items, h->child_items, (size_t)nc * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(v->d_word_id, h->word_id, (size_t)nn * 4, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(v->d_desc, h->desc, (size_t)nn * 32, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = hipMemcpy(v->d_weight, h->weight, (size_t)nn * 8, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { tb_vocab_destroy(v); return tb_fail(ctx, TB_EDEVICE, "vocabulary upload: %s", hipGetErrorString(e)); }
+    *out = v;
+    return TB_OK;
+}
+
+int tb_bow_transform_batch_dev(tb_ctx* ctx, const tb_vocab* voc, int nframes, const uint8_t* desc, const int32_t* counts,
+                               int desc_pitch, int levelsup, int32_t* word_ids, int32_t* node_ids, double* weights,
+                               uint64_t* fv_keys, int32_t* fv_counts) {
+    TB_ENTER(ctx);
+    if (!ctx || !voc || voc->ctx != ctx || nframes < 0 || desc_pitch < 0 || levelsup < 0) return TB_EINVAL;
+    if (nframes == 0 || desc_pitch == 0) return TB_OK;
+    if (!desc || (fv_keys && (!fv_counts || desc_pitch > 8192))) return TB_EINVAL;
+    void *dn = node_ids, *dwt = weights;
+    int rc;
+    if (fv_keys && !node_ids && (rc = tb_scratch(ctx, 4, (size_t)nframes * desc_pitch * 4, &dn))) return rc;
+    if (fv_keys && !weights && (rc = tb_scratch(ctx, 5, (size_t)nframes * desc_pitch * 8, &dwt))) return rc;
+    return tbk_bow_transform(ctx, voc->nnodes, voc->L, voc->d_child_start, voc->d_child_items, voc->d_desc, voc->d_word_id, voc->d_weight,
+                             nframes, desc, counts, desc_pitch, levelsup, word_ids, (int32_t*)dn, (double*)dwt,
+                             (unsigned long long*)fv_keys, fv_counts);
+}
+
+int tb_bow_transform(tb_ctx* ctx, const tb_vocab* voc, const uint8_t* desc, int n, int levelsup, int32_t* word_ids, double* weights,
+                     int32_t* node_ids) {
+    TB_ENTER(ctx);
+    if (!ctx || !voc || voc->ctx != ctx || n < 0 || levelsup < 0 || (n && (!desc || !word_ids || !weights || !node_ids))) return TB_EINVAL;
+    if (n == 0) return TB_OK;
+    void *dd, *dw, *dn, *dwt;
+    int rc;
+    if ((rc = tb_scratch(ctx, 0, (size_t)n * 32, &dd)) || (rc = tb_scratch(ctx, 1, (size_t)n * 4, &dw)) ||
+        (rc = tb_scratch(ctx, 2, (size_t)n * 4, &dn)) || (rc = tb_scratch(ctx, 3, (size_t)n * 8, &dwt)))
+        return rc;
+    hipStream_t s = ctx->stream;
+    TB_HIP(ctx, hipMemcpyAsync(dd, desc, (size_t)n * 32, hipMemcpyHostToDevice, s));
+    if ((rc = tbk_bow_transform(ctx, voc->nnodes, voc->L, voc->d_child_start, voc->d_child_items, voc->d_desc, voc->d_word_id, voc->d_weight,
+                                1, (const uint8_t*)dd, nullptr, n, levelsup, (int32_t*)dw, (int32_t*)dn, (double*)dwt, nullptr, nullptr)))
+        return rc;
+    TB_HIP(ctx, hipMemcpyAsync(word_ids, dw, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    TB_HIP(ctx, hipMemcpyAsync(node_ids, dn, (size_t)n * 4, hipMemcpyDeviceToHost, s));
+    TB_HIP(ctx, hipMemcpyAsync(weights, dwt, (size_t)n * 8, hipMemcpyDeviceToHost, s));
+    TB_HIP(ctx, hipStreamSynchronize(s));
+    return TB_OK;
+}
+
+int tb_search_by_bow_batch_dev(tb_ctx* ctx, int npairs, const tb_keypoint* k1, const uint8_t* d1, int pitch1, const uint64_t* fv1,
+                               const int32_t* fv_counts1, const tb_keypoint* k2, const uint8_t* d2, int pitch2, const uint64_t* fv2,
+                               const int32_t* fv_counts2, const uint8_t* has_mp2, int map_point_only, int th_low, float nratio,
+                               int histo_len, int check_orientation, tb_match* out, int cap, int32_t* out_counts, int32_t* flags) {
+    TB_ENTER(ctx);
+    if (!ctx || npairs < 0 || pitch1 < 1 || pitch2 < 1 || histo_len < 1 || histo_len > 1024 || cap < 0) return TB_EINVAL;
+    if (npairs == 0) return TB_OK;
+    if (!k1 || !d1 || !fv1 || !fv_counts1 || !k2 || !d2 || !fv2 || !fv_counts2 || !out_counts || !flags || (cap && !out)) return TB_EINVAL;
+    void* best;
+    int rc;
+    if ((rc = tb_scratch(ctx, 6, (size_t)npairs * pitch1 * 16, &best))) return rc;
+    return tbk_bow_search_batch(ctx, npairs, k1, d1, pitch1, (const unsigned long long*)fv1, fv_counts1, k2, d2, pitch2,
+                                (const unsigned long long*)fv2, fv_counts2, has_mp2, map_point_only, th_low, nratio, histo_len,
+                                check_orientation, out, cap, out_counts, flags, (int32_t*)best);
+}
+
 int tb_stereo_tracks_to_obs_batch_dev(tb_ctx* ctx, int nframes, const tb_keypoint* keys_left, const tb_keypoint* keys_right,
                                       int key_pitch, const tb_match* matches, const int32_t* match_counts, int match_pitch,
                                       const float K[4], float bf, const float* inv_sigma2, int nlevels, tb_obs* obs, int obs_pitch,

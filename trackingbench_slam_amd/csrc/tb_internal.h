@@ -194,6 +194,14 @@ int tbk_projection_search(tb_ctx* ctx, int map_overload, const float Tcw[16], co
                           float nratio, const tb_keypoint* d_k1, const uint8_t* d_d1, const uint8_t* d_taken1,
                           const int32_t* d_cellStart, const int32_t* d_cellItems, float widthInv, float heightInv,
                           void* d_queries, int32_t* d_best, int* d_flag);
+int tbk_bow_transform(tb_ctx* ctx, int nnodes, int L, const int32_t* d_child_start, const int32_t* d_child_items, const uint8_t* d_vdesc,
+                      const int32_t* d_word_id, const double* d_weight, int nframes, const uint8_t* d_desc, const int32_t* d_counts,
+                      int desc_pitch, int levelsup, int32_t* d_word_ids, int32_t* d_node_ids, double* d_weights,
+                      unsigned long long* d_fv_keys, int32_t* d_fv_counts);
+int tbk_bow_search_batch(tb_ctx* ctx, int npairs, const tb_keypoint* d_k1, const uint8_t* d_d1, int pitch1, const unsigned long long* d_fv1,
+                         const int32_t* d_n1, const tb_keypoint* d_k2, const uint8_t* d_d2, int pitch2, const unsigned long long* d_fv2,
+                         const int32_t* d_n2, const uint8_t* d_has_mp2, int map_point_only, int th_low, float nratio, int histo_len,
+                         int check_orientation, tb_match* d_out, int cap, int32_t* d_out_counts, int32_t* d_flags, int32_t* d_best);
 int tbk_copy16(tb_ctx* ctx, const void* d_src, void* d_dst, size_t bytes);
 int tbk_stereo_obs(tb_ctx* ctx, int nframes, const tb_keypoint* d_kl, const tb_keypoint* d_kr, int key_pitch, const tb_match* d_matches,
                    const int32_t* d_match_counts, int match_pitch, const float K[4], float bf, const float* d_inv_sigma2, int nlevels,

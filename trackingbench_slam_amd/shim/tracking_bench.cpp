@@ -5,6 +5,9 @@
  */
 #include <cmath>
 #include <cstdlib>
+#include <cstring>
+#include <fstream>
+#include <sstream>
 #include <stdexcept>
 #include <string>
 
@@ -123,6 +126,95 @@ namespace TRACKING_BENCH
         static long unsigned int nNextId = 0;
         if (pMap) { std::unique_lock<std::mutex> lock(pMap->mMutexPointCreation); mnId = nNextId++; }
         else mnId = nNextId++;
+    }
+
+    /* ------------------------------------------------------------------ vocabulary / Frame::SetBow */
+    FlatVocabulary::~FlatVocabulary() { if (device) tb_vocab_destroy(device); }
+
+    bool FlatVocabulary::loadFromTextFile(const std::string& filename)
+    {
+        /* TemplatedVocabulary.h:1338-1420: "k L scoring weighting", then per node (ids in file order from 1): parent, is-leaf,
+         * 32 descriptor bytes, weight; words are numbered in file order */
+        std::ifstream f(filename.c_str());
+        if (!f.good()) return false;
+        std::string line;
+        if (!std::getline(f, line)) return false;
+        {
+            std::stringstream ss(line);
+            ss >> k >> L >> scoring >> weighting;
+            if (ss.fail() || k < 0 || k > 20 || L < 1 || L > 10 || scoring < 0 || scoring > 5 || weighting < 0 || weighting > 3) return false;
+        }
+        std::vector<int> parent(1, 0), leaf(1, 0);
+        desc.assign(32, 0); weight.assign(1, 0.0);
+        while (std::getline(f, line))
+        {
+            if (line.empty()) continue;
+            std::stringstream ss(line);
+            int pid = 0, isleaf = 0;
+            ss >> pid >> isleaf;
+            if (ss.fail() || pid < 0 || pid >= (int)parent.size()) return false;
+            parent.push_back(pid); leaf.push_back(isleaf > 0);
+            for (int i = 0; i < 32; i++) { int v = 0; ss >> v; desc.push_back((uint8_t)v); }
+            double w = 0; ss >> w;
+            if (ss.fail()) return false;
+            weight.push_back(w);
+        }
+        const int nn = (int)parent.size();
+        std::vector<int> cnt(nn + 1, 0);
+        for (int n = 1; n < nn; n++) cnt[parent[n] + 1]++;
+        child_start.assign(nn + 1, 0);
+        for (int n = 0; n < nn; n++) child_start[n + 1] = child_start[n] + cnt[n + 1];
+        child_items.assign(std::max(nn - 1, 0), 0);
+        std::vector<int> at(child_start.begin(), child_start.end() - 1);
+        for (int n = 1; n < nn; n++) child_items[at[parent[n]]++] = n;      /* children in file order, as push_back does */
+        word_id.assign(nn, 0);
+        nwords = 0;
+        for (int n = 1; n < nn; n++) if (leaf[n]) word_id[n] = (int32_t)nwords++;
+        if (device) { tb_vocab_destroy(device); device = nullptr; }
+        return true;
+    }
+
+    void Frame::SetBow(const std::shared_ptr<ORBVocabulary>& voc)
+    {
+        /* Frame.cpp:267-270 / TemplatedVocabulary.h:1124-1188 */
+        mBowVec.clear(); mFeatVec.clear();
+        if (!voc || voc->empty()) return;
+        if (!voc->device)
+        {
+            tb_vocabulary h;
+            h.nnodes = (int32_t)voc->word_id.size(); h.k = voc->k; h.L = voc->L; h.weighting = voc->weighting; h.scoring = voc->scoring;
+            h.child_start = voc->child_start.data(); h.child_items = voc->child_items.data(); h.desc = voc->desc.data();
+            h.word_id = voc->word_id.data(); h.weight = voc->weight.data();
+            check(tb_vocab_create(shim_ctx(), &h, &voc->device), "Frame::SetBow (vocabulary upload)");
+        }
+        const int n = mDescriptors.rows;
+        if (n == 0) return;
+        std::vector<uint8_t> d((size_t)n * 32);
+        for (int i = 0; i < n; i++) std::memcpy(d.data() + (size_t)i * 32, mDescriptors.ptr(i), 32);
+        std::vector<int32_t> wid(n), nid(n);
+        std::vector<double> wt(n);
+        check(tb_bow_transform(shim_ctx(), voc->device, d.data(), n, 4, wid.data(), wt.data(), nid.data()), "Frame::SetBow");
+        const bool tf = voc->weighting == 0 || voc->weighting == 1;         /* TF_IDF, TF: weights add up; IDF, BINARY: first one */
+        for (int i = 0; i < n; i++)
+        {
+            if (!(wt[i] > 0)) continue;                                      /* a stopped word */
+            if (tf) mBowVec[(DBoW2::WordId)wid[i]] += wt[i];
+            else mBowVec.insert(std::make_pair((DBoW2::WordId)wid[i], wt[i]));
+            mFeatVec.addFeature((DBoW2::NodeId)nid[i], (unsigned)i);
+        }
+        const bool must = voc->scoring != 5, l2 = voc->scoring == 1;        /* ScoringObject.h:73-91 */
+        if (!mBowVec.empty() && !must && tf)
+        {
+            const double nd = (double)mBowVec.size();
+            for (auto& kv : mBowVec) kv.second /= nd;
+        }
+        if (must)
+        {
+            double norm = 0.0;                                              /* BowVector::normalize, BowVector.cpp:57-80 */
+            for (auto& kv : mBowVec) norm += l2 ? kv.second * kv.second : std::fabs(kv.second);
+            if (l2) norm = std::sqrt(norm);
+            if (norm > 0.0) for (auto& kv : mBowVec) kv.second /= norm;
+        }
     }
 
     /* ------------------------------------------------------------------ extractors */

@@ -258,3 +258,93 @@ def projection_case(seed, n1=1500, nmp=1200, width=1241, height=376, nlevels=8, 
     k2["size"] = 31.0
     return dict(Tcw=T, cam=cam, width=width, height=height, k1=k1, d1=d1, taken1=taken1, k2=k2, mp=mp, mp_desc=mpd, sf=sf)
 
+
+
+# ------------------------------------------------------------------ DBoW2 vocabulary
+import ctypes as _C
+
+
+class TbVocabulary(_C.Structure):
+    """tb_vocabulary of include/tb_types.h"""
+    _fields_ = [("nnodes", _C.c_int32), ("k", _C.c_int32), ("L", _C.c_int32), ("weighting", _C.c_int32), ("scoring", _C.c_int32),
+                ("child_start", _C.c_void_p), ("child_items", _C.c_void_p), ("desc", _C.c_void_p), ("word_id", _C.c_void_p),
+                ("weight", _C.c_void_p)]
+
+
+class Vocabulary:
+    """A DBoW2 tree as flat numpy arrays + the tb_vocabulary struct that points into them (keep the object alive)."""
+
+    def __init__(self, k, L, child_start, child_items, desc, word_id, weight, weighting=0, scoring=0):
+        self.k, self.L = int(k), int(L)
+        self.child_start = np.ascontiguousarray(child_start, np.int32)
+        self.child_items = np.ascontiguousarray(child_items, np.int32)
+        self.desc = np.ascontiguousarray(desc, np.uint8).reshape(-1, 32)
+        self.word_id = np.ascontiguousarray(word_id, np.int32)
+        self.weight = np.ascontiguousarray(weight, np.float64)
+        self.nnodes = len(self.word_id)
+        assert len(self.child_start) == self.nnodes + 1 and len(self.desc) == self.nnodes and len(self.weight) == self.nnodes
+        self.c = TbVocabulary(self.nnodes, self.k, self.L, int(weighting), int(scoring), self.child_start.ctypes.data,
+                              self.child_items.ctypes.data, self.desc.ctypes.data, self.word_id.ctypes.data, self.weight.ctypes.data)
+
+    def to_text(self, path):
+        """The ORBvoc-style text file TemplatedVocabulary::loadFromTextFile reads (TemplatedVocabulary.h:1338-1420): first line
+        k L scoring weighting, then one line per node in id order: parent, is-leaf, the 32 descriptor bytes, the weight."""
+        parent = np.zeros(self.nnodes, np.int64)
+        for n in range(self.nnodes):
+            parent[self.child_items[self.child_start[n]:self.child_start[n + 1]]] = n
+        with open(path, "w") as f:
+            f.write("%d %d %d %d\n" % (self.k, self.L, self.c.scoring, self.c.weighting))
+            for n in range(1, self.nnodes):
+                leaf = self.child_start[n + 1] == self.child_start[n]
+                f.write("%d %d %s %r\n" % (parent[n], 1 if leaf else 0, " ".join(str(int(b)) for b in self.desc[n]), float(self.weight[n])))
+
+
+def vocabulary(seed, k=10, L=4, stop_frac=0.05, ragged=0.0):
+    """Seeded synthetic vocabulary: a k-ary tree of depth L built breadth-first the way DBoW2 numbers its nodes (children get the
+    next free ids, so every child id exceeds its parent's), random 256-bit node descriptors that inherit most bits from the
+    parent (a walk then has a meaningful nearest child), word weights in (0, 3] with a fraction `stop_frac` of stopped words
+    (weight 0). `ragged` > 0 drops that fraction of the internal nodes' children and turns some nodes into early leaves, like a
+    k-means tree whose clusters ran empty."""
+    st = Stream(0xB0C0 + seed)
+    child_start, child_items, desc, is_leaf, depth = [0], [], [np.zeros(32, np.uint8)], [False], [0]
+    order = [0]
+    head = 0
+    while head < len(order):
+        n = order[head]; head += 1
+        d = depth[n]
+        nchild = 0
+        if d < L and not (n > 0 and ragged > 0 and st.uniform(1)[0] < ragged * 0.3):
+            nchild = k if ragged <= 0 else max(1, int(k - np.floor(st.uniform(1)[0] * ragged * k)))
+        ids = []
+        for _ in range(nchild):
+            cid = len(desc)
+            flip = st.randint(256, 0, 100) < (45 if d == 0 else 12)          # bits that differ from the parent
+            bits = np.unpackbits(desc[n]) ^ flip.astype(np.uint8)
+            desc.append(np.packbits(bits))
+            is_leaf.append(False); depth.append(d + 1)
+            ids.append(cid); order.append(cid)
+        # flat CSR rows must be written in node-id order: remember and assemble below
+        child_items.append((n, ids))
+    nn = len(desc)
+    rows = {n: ids for n, ids in child_items}
+    cs, ci = [0], []
+    for n in range(nn):
+        ci.extend(rows.get(n, []))
+        cs.append(len(ci))
+    word_id = np.zeros(nn, np.int32); weight = np.zeros(nn, np.float64)
+    w = 0
+    for n in range(nn):
+        if cs[n + 1] == cs[n]:
+            word_id[n] = w; w += 1
+            weight[n] = 0.0 if st.uniform(1)[0] < stop_frac else 0.05 + 2.95 * float(st.uniform(1)[0])
+    return Vocabulary(k, L, cs, ci, np.stack(desc), word_id, weight)
+
+
+def descriptors_near_words(seed, voc, n, flips=20):
+    """n descriptors: random words' descriptors with a few flipped bits"""
+    st = Stream(0xD0 + seed)
+    leaves = np.flatnonzero(np.diff(voc.child_start) == 0)
+    pick = leaves[st.randint(n, 0, len(leaves))]
+    bits = np.unpackbits(voc.desc[pick], axis=1)
+    mask = st.randint(n * 256, 0, 256).reshape(n, 256) < flips
+    return np.packbits(bits ^ mask.astype(np.uint8), axis=1)
