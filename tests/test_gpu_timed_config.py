@@ -86,9 +86,34 @@ def _check_pipeline(p, L, R, seed, oracle_cache):
         w0 += ba.W
 
 
+def test_configs3_per_gpu_share_8_frames_one_partition():
+    """BASELINE.json configs[3]: 64 frames over 8 GPUs = 8 stereo frames per GPU and step. bench.py runs that shape with ONE BA
+    partition (8 windows: the local-BA call replays its HIP graph, the Schur workgroups add their wavefronts' systems through
+    LDS, k_ba_solve adds 20 partial systems per window). Several steps back to back without host synchronisation, every output
+    against the oracle; then the same pipeline with per-kernel events on (ordinary launches instead of the graph): same results."""
+    from trackingbench_slam_amd.pipeline import TrackingPipeline
+    F, seed = 8, 11
+    p = TrackingPipeline(1280, 720, 8, 0.8, 2000, 80.0, 30.0, frames=F, with_ba=True, ba_kf=10, ba_pts=5000, ba_iters=10,
+                         seed=seed, ba_split=1, ba_distinct=4, ba_lag=False)
+    assert len(p.bas) == 1 and p.bas[0][0].W == 8
+    L, R = p.set_synthetic(distinct=F, first=500)
+    cache = {}
+    for _ in range(3):
+        p.step()
+    _check_pipeline(p, L, R, seed, cache)
+    P_graph = p.bas[0][0].poses.cpu().numpy().copy()
+    p.profile_enable(True)
+    p.step()
+    p.step()
+    p.profile_enable(False)
+    _check_pipeline(p, L, R, seed, cache)
+    assert np.array_equal(P_graph, p.bas[0][0].poses.cpu().numpy())   # graph replay and ordinary launches: bit for bit
+    p.close()
+
+
 @pytest.mark.parametrize("ba_lag", [False, True])
 def test_timed_configuration_unsynchronised_steps(ba_lag):
-    """ba_lag=True is what bench.py times by default: the BA windows of a batch run beside the next batch's extraction and
+    """ba_lag=True (bench.py --ba-lag; not the default): the BA windows of a batch run beside the next batch's extraction and
     step() returns without joining them (frame_results() drains before anything is read).
     bench.py's default shape at a size the oracle finishes in seconds: 1280x720, 12 stereo frames, 10-KF / 5000-point
     windows, ba_split=3. One step, check; then four more steps back to back with no host synchronisation between them
