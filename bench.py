@@ -80,18 +80,20 @@ def schur_flops_sparse(sum_k2):
     return 216.0 * float(sum_k2)
 
 
-def schur_roofs(ba_pts, nwin, ba_kf, free_edges, nfixed=2):
-    """k_ba_schur, DENSE count of one launch (one LM trial of `nwin` windows): the lower triangle of the np x np
-    reduced system plus the rhs for 3 densified columns per point -- what the 16x16x4 MFMA tiles are sized for, an
-    upper bound of the arithmetic a sparse formulation needs (labelled `dense` in the bench line). bytes = one 16 B
-    record per free-keyframe edge, one 96 B record per point, the per-workgroup partial blocks written."""
+def schur_roofs(ba_pts, nwin, ba_kf, free_edges, nfixed=2, num_cu=256):
+    """k_ba_schur, one launch (one LM trial of `nwin` windows). DENSE flop count: the lower triangle of the np x np reduced
+    system plus the rhs for 3 densified columns per point -- what the 16x16x4 MFMA tiles of rounds 1-2 executed, kept for
+    comparison (the round-3 kernel's executed count comes from the windows' visibility patterns: BatchedLocalBA
+    .mfma_flops_executed). bytes = one 16 B record per free-keyframe edge, one 96 B record per point, the partial systems
+    written (one per Schur wavefront, or per workgroup for small batches: ba_dims() in k_ba.hip)."""
     np_ = 6 * (ba_kf - nfixed)
     flops = 2.0 * (np_ * (np_ + 1) / 2 + np_) * 3 * ba_pts * nwin
-    R = (np_ + 15) // 16
-    nchunks = (ba_pts + 3) // 4
-    G = min(max(1024 // max(nwin, 1), 1), max((nchunks + 3) // 4, 1))     # ba_dims() in k_ba.hip
-    out = G * (R * (R + 1) // 2 * 256 + np_) * 8
-    nbytes = free_edges * 16 + nwin * (ba_pts * 96 + out)
+    slots, cap = 2 * num_cu, min(32, max((ba_pts // 64 + 3) // 4, 1))
+    gbase = min(max(slots // max(nwin, 1), 1), cap)
+    gextra = min(slots - gbase * nwin, nwin) if gbase < cap and slots > gbase * nwin else 0
+    nparts = (gbase * nwin + gextra) * (1 if gbase > 4 else 4)
+    out = nparts * (np_ * (np_ + 1) // 2 + np_) * 8
+    nbytes = free_edges * 16 + nwin * ba_pts * 96 + out
     return flops, nbytes
 
 
@@ -555,8 +557,9 @@ def report(args, pipe, prof, el, world, n_joined, dev):
         fl_dense, nb = schur_roofs(args.ba_pts, nwin, args.ba_kf, free_edges)
         fl = schur_flops_sparse(pipe.bas[0][0].sum_k2_free)
         c_s, ms_s = prof.get("k_ba_schur", (0, 0.0))
-        ls = (ms_s / max(c_s, 1)) / 1e3 or None
         il = iso["k_ba_schur"] / 1e3
+        ls = (ms_s / max(c_s, 1)) / 1e3 or (il if not prof else None)   # region events off: the isolated launch stands in
+        fl_exec = float(pipe.bas[0][0].mfma_flops_executed)
         tr = pmc_traffic("k_ba_schur", nwin, geometry, detail=True)
         schur = {"kernel": "k_ba_schur", "bound": "mfma", "unit": "TFLOP/s", "peak": F64_MFMA_PEAK_TFLOPS, "windows_per_launch": nwin,
                  "algorithmic_flops_per_launch": fl, "flops_rule": "SURVEY 8(d): sum over points of k_free^2 x 216 per window and trial",
@@ -568,10 +571,14 @@ def report(args, pipe, prof, el, world, n_joined, dev):
                  "isolated": {"avg_launch_ms": round(iso["k_ba_schur"], 5),
                               "achieved": round(fl / 1e12 / il, 3), "frac": round(fl / 1e12 / il / F64_MFMA_PEAK_TFLOPS, 5),
                               "hbm_frac": round(nb / 1e9 / il / HBM_PEAK_GBS, 5)},
-                 "dense": {"note": "dense lower triangle + rhs per point (what the MFMA tiles compute, zeros included)",
-                           "flops_per_launch": fl_dense,
-                           "frac": round(fl_dense / 1e12 / ls / F64_MFMA_PEAK_TFLOPS, 5) if ls else None,
-                           "isolated_frac": round(fl_dense / 1e12 / il / F64_MFMA_PEAK_TFLOPS, 5)},
+                 "executed": {"note": "flops the kernel's v_mfma_f64_4x4x4 instructions execute (groups of one visibility pattern: "
+                                      "k-steps x instructions of the pattern x 512; padding rows / columns and mirrored blocks "
+                                      "included) -- rounds 1-2 executed the dense count below, 2.97 x the algorithmic one",
+                              "flops_per_launch": fl_exec, "over_algorithmic": round(fl_exec / fl, 3) if fl else None,
+                              "frac": round(fl_exec / 1e12 / ls / F64_MFMA_PEAK_TFLOPS, 5) if ls else None,
+                              "isolated_frac": round(fl_exec / 1e12 / il / F64_MFMA_PEAK_TFLOPS, 5)},
+                 "dense": {"note": "dense lower triangle + rhs per point (what the 16x16x4 tiles of rounds 1-2 computed, zeros included)",
+                           "flops_per_launch": fl_dense},
                  "traffic": tr["bytes"] if tr else None, "traffic_file": tr["file"] if tr else None,
                  "traffic_scaled": tr["scaled"] if tr else None}
         common["ba_schur"] = schur

@@ -29,8 +29,13 @@ def test_schur_model():
     fl, nb = bench.schur_roofs(5000, 171, 10, free_edges=171 * 20000)
     np_ = 48
     assert fl == 2.0 * (np_ * (np_ + 1) / 2 + np_) * 3 * 5000 * 171
-    G = min(max(1024 // 171, 1), max((1250 + 3) // 4, 1))
-    assert nb == 171 * 20000 * 16 + 171 * (5000 * 96 + G * (6 * 256 + np_) * 8)
+    # ba_dims() in k_ba.hip: 2 x 256 workgroup slots over 171 windows = 2 each and 170 of them one more; one partial system
+    # (lower triangle + rhs) per Schur wavefront
+    nparts = (2 * 171 + 170) * 4
+    assert nb == 171 * 20000 * 16 + 171 * 5000 * 96 + nparts * (np_ * (np_ + 1) // 2 + np_) * 8
+    # a small batch: 20 workgroups per window, added through LDS to one partial system each
+    _, nb8 = bench.schur_roofs(5000, 8, 10, free_edges=8 * 20000)
+    assert nb8 == 8 * 20000 * 16 + 8 * 5000 * 96 + 8 * 20 * (np_ * (np_ + 1) // 2 + np_) * 8
 
 
 def test_schur_sparse_flops_follow_survey_8d():

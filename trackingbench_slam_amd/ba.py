@@ -32,11 +32,31 @@ class BatchedLocalBA:
         # (edge, edge) items of the block-pair lists the large-window Schur kernel walks (more than 10 free keyframes)
         self.pair_items = 0
         self.sum_k2_free = 0   # sum over points of (observations by free keyframes)^2: SURVEY 8(d)'s sparse Schur flop count / 216
+        # what the pattern-compact Schur kernel EXECUTES per LM trial (k_ba.hip: groups of one visibility pattern, at most
+        # 21 points / 64 edges; ceil(3 points / 4) k-steps of NACC(k) v_mfma_f64_4x4x4 instructions, 512 flop each; patterns of
+        # more than five keyframes take the direct vector form, 2 x 36 flop per tile column and block pair)
+        self.mfma_flops_executed = 0
+        nacc = {1: 2, 2: 3, 3: 5, 4: 9, 5: 10}
+        nfree = nkf - nfixed
         for w in range(self.W):
             o = obs[w, :cnt[w]]
-            e = np.bincount(o["pt"][o["kf"] >= nfixed], minlength=npt).astype(np.int64)
+            free = o["kf"] >= nfixed
+            e = np.bincount(o["pt"][free], minlength=npt).astype(np.int64)
             self.pair_items += int((e * (e + 1) // 2).sum())
             self.sum_k2_free += int((e * e).sum())
+            if nfree <= 10:
+                mask = np.zeros(npt, np.int64)
+                np.bitwise_or.at(mask, o["pt"][free], np.int64(1) << (o["kf"][free] - nfixed).astype(np.int64))
+                pats, pc = np.unique(mask[mask > 0], return_counts=True)
+                for m, c in zip(pats.tolist(), pc.tolist()):
+                    k = bin(m).count("1")
+                    cap = min(64 // k, 21)
+                    full, rest = divmod(c, cap)
+                    ksteps = full * ((3 * cap + 3) // 4) + ((3 * rest + 3) // 4 if rest else 0)
+                    if k <= 5:
+                        self.mfma_flops_executed += ksteps * nacc[k] * 512
+                    else:
+                        self.mfma_flops_executed += c * 3 * (k * (k + 1) // 2) * 72
         dev = device
         self.obs = torch.from_numpy(obs.view(np.uint8).reshape(self.W, self.obs_pitch, capi.BA_OBS.itemsize)).to(dev)
         self.counts = torch.from_numpy(cnt).to(dev)
