@@ -37,6 +37,11 @@ int tb_synchronize(tb_ctx* ctx);
  * figure needs the dominant kernel's average launch duration over the timed region). enable(1) resets the
  * accumulators; report() synchronises and writes one line per kernel: "name calls total_ms\n". */
 int tb_profile_enable(tb_ctx* ctx, int on);
+/* A hint for launch shapes: `peers` contexts (this one included) are expected to run their kernels on this GPU at the same time
+ * -- e.g. a batch's local-BA windows split over several contexts, each on its own stream and host thread. Kernels whose grid is
+ * sized to fill the chip in one resident round (the local-BA Schur kernel) then take 1 / peers of it. Default 1. Results do not
+ * depend on it beyond the order of floating-point partial sums (the number of partial systems per window follows the grid). */
+int tb_set_concurrency(tb_ctx* ctx, int peers);
 /* Measurement helper: copies `bytes` (a multiple of 16, 16-byte aligned device pointers) with a 16-byte-per-lane
  * kernel and returns the average seconds per copy over `reps` (HIP events on the context's stream, one untimed copy first). The
  * streaming bandwidth of the device is 2 * bytes / seconds. */

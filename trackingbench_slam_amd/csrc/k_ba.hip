@@ -1948,7 +1948,7 @@ __global__ void k_ba_zero(int* __restrict__ p, int n) {
     if (i < n) p[i] = 0;
 }
 
-static void ba_dims(BaDims& d, int num_cu, int W, const double K[4], int nkf, int nfixed, int npt, int obs_pitch, int iters) {
+static void ba_dims(BaDims& d, int num_cu, int peers, int W, const double K[4], int nkf, int nfixed, int npt, int obs_pitch, int iters) {
     memset(&d, 0, sizeof d);
     d.W = W; d.nkf = nkf; d.nfixed = nfixed; d.nfree = nkf - nfixed; d.np = 6 * d.nfree; d.npt = npt; d.obs_pitch = obs_pitch;
     d.iters = iters;
@@ -1957,10 +1957,12 @@ static void ba_dims(BaDims& d, int num_cu, int W, const double K[4], int nkf, in
     d.nChunks = 0;
     /* Schur workgroups: the kernel holds two per CU (226 registers per lane, ~62 KB of LDS), so the batch gets 2 num_cu of
      * them -- ONE resident round (855 workgroups for 171 windows ran as 1.67 rounds: the second, two-thirds full, cost as much
-     * as the first) -- dealt to the windows as Gbase or Gbase + 1 each. At most 32 per window (k_ba_solve adds the
+     * as the first) -- dealt to the windows as Gbase or Gbase + 1 each. A context that shares the GPU with `peers` - 1 others
+     * running the same chain (tb_set_concurrency: the pipeline's BA partitions) takes 1 / peers of the slots: three
+     * partitions of 171 windows queue 513 workgroups between them instead of 3 x 512 (measured: 18.37 -> 17.91 ms per step). At most 32 per window (k_ba_solve adds the
      * workgroups' partial systems in order) and no more than one per ~256 points. */
     {
-        const int slots = 2 * std::max(num_cu, 1), cap = std::min(32, std::max((npt / 64 + 3) / 4, 1));
+        const int slots = std::max(2 * std::max(num_cu, 1) / std::max(peers, 1), 1), cap = std::min(32, std::max((npt / 64 + 3) / 4, 1));
         d.Gbase = std::min(std::max(slots / std::max(W, 1), 1), cap);
         d.Gextra = (d.Gbase < cap && slots > d.Gbase * W) ? std::min(slots - d.Gbase * W, W) : 0;
         d.G = d.Gbase + (d.Gextra > 0 ? 1 : 0);
@@ -2011,7 +2013,7 @@ static void ba_dims(BaDims& d, int num_cu, int W, const double K[4], int nkf, in
 size_t tbk_local_ba_work_bytes(const tb_ctx* ctx, int W, int nkf, int nfixed, int npt, int obs_pitch) {
     BaDims d;
     const double K[4] = {1, 1, 0, 0};
-    ba_dims(d, ctx->num_cu, W, K, nkf, nfixed, npt, obs_pitch, 1);
+    ba_dims(d, ctx->num_cu, ctx->peers, W, K, nkf, nfixed, npt, obs_pitch, 1);
     return (size_t)W * (d.wstride * sizeof(double) + d.istride * sizeof(int) + sizeof(BaState) + sizeof(int)) + 4096;
 }
 
@@ -2028,7 +2030,7 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
         return tb_fail(ctx, TB_EUNSUPPORTED, "local BA: large window with more than 2^31 / (free keyframes + 1) observations");
     if (iters > 99) return tb_fail(ctx, TB_EUNSUPPORTED, "local BA: more than 99 LM iterations (one still-running counter per trial, 1000 of them)");
     BaDims d;
-    ba_dims(d, ctx->num_cu, W, K, nkf, nfixed, npt, obs_pitch, iters);
+    ba_dims(d, ctx->num_cu, ctx->peers, W, K, nkf, nfixed, npt, obs_pitch, iters);
     if (tbk_local_ba_work_bytes(ctx, W, nkf, nfixed, npt, obs_pitch) > work_bytes) return tb_fail(ctx, TB_ENOMEM, "local BA workspace too small");
     char* base = (char*)d_work;
     double* dw = (double*)base;

@@ -162,6 +162,12 @@ int tb_measure_copy_seconds(tb_ctx* ctx, const void* d_src, void* d_dst, size_t 
     return rc;
 }
 
+int tb_set_concurrency(tb_ctx* ctx, int peers) {
+    if (!ctx || peers < 1) return TB_EINVAL;
+    ctx->peers = peers;
+    return TB_OK;
+}
+
 int tb_debug_force_dense_fast(tb_ctx* ctx, int on) {
     if (!ctx) return TB_EINVAL;
     ctx->dbg_fast_dense = on ? 1 : 0;

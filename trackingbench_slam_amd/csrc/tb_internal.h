@@ -20,6 +20,7 @@ struct tb_ctx {
     int device = 0;
     int num_cu = 256;   /* compute units of the device (tb_create): launch shapes that aim at one resident round */
     std::vector<std::pair<std::string, hipGraphExec_t>> ba_graphs; /* captured local-BA calls of small batches (k_ba.hip) */
+    int peers = 1;      /* tb_set_concurrency: contexts expected to keep this GPU busy at the same time */
     int dbg_fast_dense = 0; /* tb_debug_force_dense_fast: every FAST block takes the any-density path (test hook) */
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;

@@ -91,6 +91,7 @@ class TrackingPipeline:
                 # behind the extractor's half-million (measured, 512 frames: 21.66 -> 21.14 ms per step; TB_BA_PRIO=0 restores)
                 st = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("TB_BA_PRIO", "-1")))
                 cx = capi.Context(device, stream=st.cuda_stream)
+                cx.set_concurrency(nsplit)   # the partitions run side by side: each sizes its grids for its share of the GPU
                 self.bas.append((BatchedLocalBA(cx, bounds[i + 1] - bounds[i], ba_kf, ba_pts, ba_iters, seed * 16 + i, self.dev,
                                                 distinct=max(1, -(-int(ba_distinct) // nsplit)), stream=st), st, cx))
             # each partition's driver blocks on its own stream once per call (LM termination is data dependent):
