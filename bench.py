@@ -300,7 +300,7 @@ class StubPipeline:
         s["trk_kps"].fill_(val + 0.5)
         s["trk_desc"].fill_((self.rank * 16 + self.nstep) % 256)
         s["matches"].fill_(self.rank * 100 + self.nstep)
-        s["match_counts"].fill_(self.nstep)
+        s["match_counts"].fill_(min(self.nstep, self.cap))
         s["n_inliers"].fill_(self.rank)
 
     def close(self):
@@ -338,6 +338,9 @@ def parse_args(argv=None):
                          "work, not by the tail of a partition's chain; the timed region ends with everything complete either way)")
     ap.add_argument("--distinct", type=int, default=64, help="distinct synthetic stereo pairs tiled over the batch")
     ap.add_argument("--ba-distinct", type=int, default=32, help="distinct synthetic BA windows tiled over the batch")
+    ap.add_argument("--exchange", choices=("packed", "padded"), default="packed",
+                    help="the track gather at the end of a batch (N > 1): packed = live rows only, sized by the largest rank of "
+                         "the batch (counts first, then one gather per record); padded = whole capacity-sized record tensors")
     ap.add_argument("--backend", default="nccl", help=argparse.SUPPRESS)   # gloo: CPU test of the launcher / exchange
     ap.add_argument("--stub", action="store_true", help=argparse.SUPPRESS)  # StubPipeline, no GPU: not a measurement
     return ap.parse_args(argv)
@@ -372,7 +375,7 @@ def main(argv=None):
     else:
         pipe = StubPipeline(args.frames, rank)
 
-    state = {"sync_only": False}
+    state = {"sync_only": False, "xbytes": 0, "xsteps": 0, "xrows": (0, 0)}
     pending = []  # exchange steps in flight: the pipeline alternates between two record sets, so at most two
     received = []  # stub mode: (step, parts) rank 0 got
 
@@ -387,7 +390,14 @@ def main(argv=None):
             with pipe.stream_ctx():
                 if not state["sync_only"]:
                     try:
-                        parts, handles = tbd.gather_tracks_async(tbd.pipeline_records(pipe), dst=0, slot=pipe._cur)
+                        if args.exchange == "packed":
+                            parts, handles, nb, rows = tbd.gather_tracks_packed(tbd.pipeline_records(pipe), dst=0, slot=pipe._cur,
+                                                                                packer=getattr(pipe, "pack_rows", None))
+                            state["xbytes"] += nb; state["xsteps"] += 1; state["xrows"] = rows
+                        else:
+                            recs = tbd.pipeline_records(pipe)
+                            parts, handles = tbd.gather_tracks_async(recs, dst=0, slot=pipe._cur)
+                            state["xbytes"] += sum(v.numel() * v.element_size() for v in recs.values()); state["xsteps"] += 1
                         pending.append(handles)
                         if not gpu and rank == 0:
                             received.append((pipe.nstep, parts))
@@ -445,7 +455,8 @@ def main(argv=None):
                             and bool(parts["kps"][r].eq(val + 0.5).all()) and bool(parts["matches"][r].eq(r * 100 + step_no).all())
             print(json.dumps({"stub": True, "n_gpus": n_joined, "steps": args.steps, "warmup": args.warmup,
                               "frames_per_rank": args.frames, "gather_check": "ok" if ok else "MISMATCH",
-                              "exchanges": len(received)}))
+                              "exchanges": len(received), "exchange": args.exchange,
+                              "bytes_per_rank_per_step": state["xbytes"] // max(state["xsteps"], 1)}))
             rc = 0 if ok and n_joined == args.gpus else 3
         if world > 1:
             dist.barrier()
@@ -455,6 +466,11 @@ def main(argv=None):
     out = None
     if rank == 0:
         out = report(args, pipe, prof, el, world, n_joined, dev)
+        if world > 1:
+            per_rank = state["xbytes"] // max(state["xsteps"], 1)
+            out["config"]["exchange"] = {"mode": args.exchange if not state["sync_only"] else "in line (padded)",
+                                         "bytes_per_rank_per_step": per_rank, "bytes_into_rank0_per_step": per_rank * (world - 1),
+                                         "rows_per_rank_last_step": {"keypoints": state["xrows"][0], "matches": state["xrows"][1]}}
         print(json.dumps(out))
         sys.stdout.flush()
     pipe.close()

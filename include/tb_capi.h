@@ -37,6 +37,11 @@ int tb_synchronize(tb_ctx* ctx);
  * figure needs the dominant kernel's average launch duration over the timed region). enable(1) resets the
  * accumulators; report() synchronises and writes one line per kernel: "name calls total_ms\n". */
 int tb_profile_enable(tb_ctx* ctx, int on);
+/* Exchange helper ("counts first, then the live records"): the first counts[f] rows of every frame of a
+ * [nframes][cap][row_bytes] record array, frame after frame, to the front of dst (same total size); *total (nullable, device,
+ * int64) = the number of rows written. row_bytes a multiple of 4. Device pointers, asynchronous on the context's stream. */
+int tb_pack_rows_dev(tb_ctx* ctx, const void* src, int row_bytes, int cap, const int32_t* counts, int nframes, void* dst,
+                     long long* total);
 /* A hint for launch shapes: `peers` contexts (this one included) are expected to run their kernels on this GPU at the same time
  * -- e.g. a batch's local-BA windows split over several contexts, each on its own stream and host thread. Kernels whose grid is
  * sized to fill the chip in one resident round (the local-BA Schur kernel) then take 1 / peers of it. Default 1. Results do not

@@ -25,6 +25,13 @@ def test_bench_gpus2_launches_its_own_ranks_gloo():
     assert len(lines) == 1                      # rank 0 prints ONE line
     out = json.loads(lines[0])
     assert out["stub"] is True and out["n_gpus"] == 2 and out["gather_check"] == "ok" and out["exchanges"] == 7
+    assert out["exchange"] == "packed"
+    packed_bytes = out["bytes_per_rank_per_step"]
+    # the capacity-sized exchange of round 2 moves more: 3 frames x 6 slots x (28 + 32 + 16) bytes + the fixed records
+    r2 = _run(["--gpus", "2", "--steps", "5", "--warmup", "2", "--frames", "3", "--backend", "gloo", "--stub", "--exchange", "padded"])
+    assert r2.returncode == 0, r2.stderr[-2000:]
+    out2 = json.loads([l for l in r2.stdout.splitlines() if l.startswith("{")][0])
+    assert out2["gather_check"] == "ok" and out2["exchange"] == "padded" and 0 < packed_bytes < out2["bytes_per_rank_per_step"]
 
 
 def test_bench_rank_count_mismatch_is_an_error():

@@ -72,3 +72,27 @@ def test_batch_run_shards_and_gathers(nctx, F):
         capi.batch_run(ctxs, L, R, nlevels=6, scale=0.8, target=800, init_th=60.0, min_th=20.0, cap=100)
     for c in ctxs:
         c.close()
+
+
+def test_pack_rows_matches_the_torch_packer():
+    """tb_pack_rows_dev (the exchange step's compaction on the chain's stream) == dist.pack_records' torch fallback."""
+    import torch
+    from trackingbench_slam_amd import dist as tbd
+    from trackingbench_slam_amd.pipeline import TrackingPipeline
+    p = TrackingPipeline(640, 480, 4, 0.8, 500, 40.0, 10.0, frames=5, with_ba=False)
+    p.set_synthetic(distinct=5, first=40)
+    p.step()
+    torch.cuda.synchronize()
+    recs = tbd.pipeline_records(p)
+    a, ta = tbd.pack_records(recs)
+    with p.stream_ctx():
+        b, tb_ = tbd.pack_records(recs, packer=p.pack_rows)
+    torch.cuda.synchronize()
+    assert ta.tolist() == tb_.tolist() and int(ta[0]) > 50, ta.tolist()
+    for name, cname in (("kps", "kp_counts"), ("desc", "kp_counts"), ("matches", "match_counts")):
+        n = int(recs[cname].sum())
+        x, y = a[name][:n].contiguous(), b[name][:n].contiguous()
+        if x.dtype == torch.float32:          # keypoint records viewed as floats: class_id = -1 is a NaN pattern
+            x, y = x.view(torch.int32), y.view(torch.int32)
+        assert torch.equal(x, y), name
+    p.close()

@@ -28,7 +28,7 @@ TB_OK, TB_EINVAL, TB_ENOMEM, TB_ECAPACITY, TB_EUNSUPPORTED, TB_EDEVICE, TB_ESTAT
 # every symbol include/tb_capi.h declares (checked by tests/test_capi_exports.py)
 EXPORTS = [
     "tb_create", "tb_destroy", "tb_last_error", "tb_strerror", "tb_version", "tb_set_stream", "tb_synchronize",
-    "tb_profile_enable", "tb_profile_report", "tb_debug_force_dense_fast", "tb_measure_copy_seconds", "tb_set_concurrency",
+    "tb_profile_enable", "tb_profile_report", "tb_debug_force_dense_fast", "tb_measure_copy_seconds", "tb_set_concurrency", "tb_pack_rows_dev",
     "tb_scale_factors", "tb_pyramid_sizes", "tb_orb_quotas",
     "tb_extractor_create", "tb_extractor_destroy", "tb_extractor_set_images_host", "tb_extractor_set_images_dev",
     "tb_extractor_set_levels_host", "tb_extractor_build_pyramid", "tb_extractor_get_level_host", "tb_extractor_orb",

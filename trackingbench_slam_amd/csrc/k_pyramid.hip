@@ -210,3 +210,44 @@ int tbk_copy16(tb_ctx* ctx, const void* d_src, void* d_dst, size_t bytes) {
     TB_HIP(ctx, hipGetLastError());
     return TB_OK;
 }
+
+/* ---- exchange helper: the live rows of a [F][cap] record array, frame after frame, to the front of a packed
+ * array -- what a rank sends in the track gather instead of capacity-sized tensors. One workgroup per frame: its offset is
+ * the sum of the counts before it (F is a few hundred: every workgroup adds them up itself), then 16 bytes per lane.
+ * row_bytes is a multiple of 4 (28, 32, 16). total_out[0] = all live rows. */
+__global__ void __launch_bounds__(256)
+k_pack_rows(const uint8_t* __restrict__ src, int row_bytes, int cap, const int32_t* __restrict__ counts, int nframes,
+            uint8_t* __restrict__ dst, long long* __restrict__ total_out) {
+    __shared__ long long red[4];
+    const int f = blockIdx.x, tid = threadIdx.x;
+    long long before = 0, all = 0;
+    for (int i = tid; i < nframes; i += 256) {
+        const long long c = min(max(counts[i], 0), cap);
+        all += c;
+        if (i < f) before += c;
+    }
+    for (int pass = 0; pass < 2; pass++) {
+        long long v = pass == 0 ? before : all;
+#pragma unroll
+        for (int d = 32; d > 0; d >>= 1) v += __shfl_xor(v, d, 64);
+        __syncthreads();
+        if ((tid & 63) == 0) red[tid >> 6] = v;
+        __syncthreads();
+        v = red[0] + red[1] + red[2] + red[3];
+        if (pass == 0) before = v; else all = v;
+    }
+    if (f == 0 && tid == 0 && total_out) total_out[0] = all;
+    const int n = min(max(counts[f], 0), cap);
+    const size_t nb = (size_t)n * row_bytes;
+    const uint32_t* s4 = reinterpret_cast<const uint32_t*>(src + (size_t)f * cap * row_bytes);
+    uint32_t* d4 = reinterpret_cast<uint32_t*>(dst + (size_t)before * row_bytes);
+    for (size_t i = tid; i < nb / 4; i += 256) d4[i] = s4[i];
+}
+
+int tbk_pack_rows(tb_ctx* ctx, const void* d_src, int row_bytes, int cap, const int32_t* d_counts, int nframes, void* d_dst, long long* d_total) {
+    if (nframes <= 0) return TB_OK;
+    hipLaunchKernelGGL(k_pack_rows, dim3(nframes), dim3(256), 0, ctx->stream, (const uint8_t*)d_src, row_bytes, cap, d_counts, nframes,
+                       (uint8_t*)d_dst, d_total);
+    TB_HIP(ctx, hipGetLastError());
+    return TB_OK;
+}

@@ -162,6 +162,14 @@ int tb_measure_copy_seconds(tb_ctx* ctx, const void* d_src, void* d_dst, size_t 
     return rc;
 }
 
+int tb_pack_rows_dev(tb_ctx* ctx, const void* src, int row_bytes, int cap, const int32_t* counts, int nframes, void* dst, long long* total) {
+    TB_ENTER(ctx);
+    if (!ctx || nframes < 0 || cap < 1 || row_bytes < 4 || (row_bytes & 3)) return TB_EINVAL;
+    if (nframes == 0) return TB_OK;
+    if (!src || !dst || !counts || src == dst) return TB_EINVAL;
+    return tbk_pack_rows(ctx, src, row_bytes, cap, counts, nframes, dst, total);
+}
+
 int tb_set_concurrency(tb_ctx* ctx, int peers) {
     if (!ctx || peers < 1) return TB_EINVAL;
     ctx->peers = peers;

@@ -203,6 +203,7 @@ int tbk_bow_search_batch(tb_ctx* ctx, int npairs, const tb_keypoint* d_k1, const
                          const int32_t* d_n1, const tb_keypoint* d_k2, const uint8_t* d_d2, int pitch2, const unsigned long long* d_fv2,
                          const int32_t* d_n2, const uint8_t* d_has_mp2, int map_point_only, int th_low, float nratio, int histo_len,
                          int check_orientation, tb_match* d_out, int cap, int32_t* d_out_counts, int32_t* d_flags, int32_t* d_best);
+int tbk_pack_rows(tb_ctx* ctx, const void* d_src, int row_bytes, int cap, const int32_t* d_counts, int nframes, void* d_dst, long long* d_total);
 int tbk_copy16(tb_ctx* ctx, const void* d_src, void* d_dst, size_t bytes);
 int tbk_stereo_obs(tb_ctx* ctx, int nframes, const tb_keypoint* d_kl, const tb_keypoint* d_kr, int key_pitch, const tb_match* d_matches,
                    const int32_t* d_match_counts, int match_pitch, const float K[4], float bf, const float* d_inv_sigma2, int nlevels,

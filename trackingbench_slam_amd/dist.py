@@ -99,6 +99,91 @@ def wait_tracks(handles):
         h.wait()
 
 
+# ---- packed exchange (round 3): rank 0 receives live rows, not capacity
+_PACKED = {"kps": "kp_counts", "desc": "kp_counts", "matches": "match_counts"}   # variable-length record -> its per-frame counts
+
+
+def pack_records(records, packer=None):
+    """Move the live rows of the variable-length records to the front, frame after frame: records[name] is [F, cap, ...] with
+    counts[f] live rows per frame -> a [F * cap, ...] tensor whose first sum(counts) rows are the live ones in frame order
+    (the rows behind them are unspecified). Fixed-shape records pass through. Returns (packed dict, totals int64 [2] on the
+    records' device: live keypoint rows, live match rows). Device-side torch ops only (stable sort of a 0/1 key)."""
+    out = dict(records)
+    totals = []
+    order_cache = {}
+    for name, cname in _PACKED.items():
+        if name not in records:
+            continue
+        t, cnt = records[name], records[cname]
+        F, cap = t.shape[0], t.shape[1]
+        if packer is not None:      # the library's compaction kernel (tb_pack_rows_dev): one launch per record, no sort
+            out[name] = packer(name, t, cnt)
+            continue
+        if cname not in order_cache:
+            dead = (torch.arange(cap, device=t.device)[None, :] >= cnt[:, None].to(torch.int64)).reshape(F * cap)
+            order_cache[cname] = torch.sort(dead.to(torch.uint8), stable=True).indices   # live rows first, original order kept
+        out[name] = t.reshape((F * cap,) + tuple(t.shape[2:])).index_select(0, order_cache[cname])
+    for cname in ("kp_counts", "match_counts"):
+        totals.append(records[cname].to(torch.int64).sum() if cname in records else torch.zeros((), dtype=torch.int64, device=next(iter(records.values())).device))
+    return out, torch.stack(totals)
+
+
+def unpack_records(packed, counts_by_name):
+    """Inverse of pack_records on the receiving side, for checks: list of per-frame row blocks."""
+    res = {}
+    for name, cname in _PACKED.items():
+        if name in packed:
+            cnt = counts_by_name[cname].tolist()
+            off, rows = 0, []
+            for c in cnt:
+                rows.append(packed[name][off:off + c])
+                off += c
+            res[name] = rows
+    return res
+
+
+def gather_tracks_packed(records, dst=0, group=None, slot=0, async_op=True, packer=None):
+    """The exchange step with compacted payloads (SURVEY 8e's first option: counts, then live records). Every rank packs its
+    variable-length records (pack_records); one tiny all-reduce (MAX) tells everybody the largest live row counts of the
+    batch; the SAME gather collective as gather_tracks then moves only that many rows per rank -- equal shapes, as RCCL's
+    gather wants, but sized by the data (ranks hold the same workload, so the largest rank is within a few rows of the
+    others) instead of by the plan's capacity. Reading the two maxima on the host waits for the chain that wrote the
+    records; bench.py calls this right after step(), which has joined the BA partitions by then, so the extractor chain is
+    long done. Returns (parts or None, handles, bytes this rank contributed, rows = (kp_rows, match_rows) per rank sent)."""
+    if not dist.is_available() or not dist.is_initialized() or dist.get_world_size(group) == 1:
+        return dict(records), [], 0, (0, 0)
+    world = dist.get_world_size(group)
+    rank = dist.get_rank(group)
+    packed, totals = pack_records(records, packer)
+    mx = totals.clone()
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+    kp_rows, m_rows = (int(v) for v in mx.cpu().tolist())
+    rows = {"kp_counts": max(kp_rows, 1), "match_counts": max(m_rows, 1)}
+    out = {} if rank == dst else None
+    handles, nbytes = [], 0
+    for name in sorted(packed):
+        t = packed[name]
+        if name in _PACKED:
+            t = t[:rows[_PACKED[name]]]
+        t = t.contiguous()
+        nbytes += t.numel() * t.element_size()
+        if rank == dst:
+            full = packed[name]
+            key = ("packed", name, tuple(full.shape), full.dtype, str(full.device), world, slot)
+            bufs = _GATHER_BUFFERS.get(key)
+            if bufs is None:
+                bufs = [torch.empty_like(full) for _ in range(world)]
+                _GATHER_BUFFERS[key] = bufs
+            parts = [b[:t.shape[0]] for b in bufs] if name in _PACKED else bufs
+            h = dist.gather(t, gather_list=parts, dst=dst, group=group, async_op=async_op)
+            out[name] = parts
+        else:
+            h = dist.gather(t, gather_list=None, dst=dst, group=group, async_op=async_op)
+        if async_op:
+            handles.append(h)
+    return out, handles, nbytes, (kp_rows, m_rows)
+
+
 def pipeline_records(p):
     """The track records of a TrackingPipeline batch as a dict of device tensors."""
     return {

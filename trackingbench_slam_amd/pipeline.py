@@ -40,6 +40,7 @@ class TrackingPipeline:
         self.kps_ptr, self.desc_ptr, self.counts_ptr, self.kp_cap = self.ex.results_dev()
         F, cap = self.F, self.kp_cap
         self.images = None
+        self._pack_bufs = {}
         with torch.cuda.stream(self.main):   # every tensor of the chain is allocated, filled and uploaded ON the chain's stream
             self._alloc_chain(F, cap, seed)
         self._init_ba(with_ba, ba_lag, ba_split, ba_kf, ba_pts, ba_iters, ba_distinct, seed, device)
@@ -106,6 +107,19 @@ class TrackingPipeline:
     trk_kps = property(lambda self: self._sets[self._cur]["trk_kps"])
     trk_desc = property(lambda self: self._sets[self._cur]["trk_desc"])
     trk_counts = property(lambda self: self._sets[self._cur]["trk_counts"])
+
+    def pack_rows(self, name, t, counts):
+        """dist.pack_records' packer: tb_pack_rows_dev on the chain's stream; one reused destination per record and set."""
+        key = (name, self._cur)
+        buf = self._pack_bufs.get(key)
+        if buf is None or buf.shape != (t.shape[0] * t.shape[1],) + tuple(t.shape[2:]):
+            with torch.cuda.stream(self.main):
+                buf = torch.empty((t.shape[0] * t.shape[1],) + tuple(t.shape[2:]), dtype=t.dtype, device=t.device)
+            self._pack_bufs[key] = buf
+        row_bytes = t.element_size() * int(np.prod(t.shape[2:]))
+        self.ctx.check(capi.lib().tb_pack_rows_dev(self.ctx._h, C.c_void_p(t.data_ptr()), row_bytes, t.shape[1], C.c_void_p(counts.data_ptr()),
+                                                   t.shape[0], C.c_void_p(buf.data_ptr()), None))
+        return buf
 
     def stream_ctx(self):
         """Context manager that makes the chain's stream torch's current stream: torch-side work on the records (the RCCL
