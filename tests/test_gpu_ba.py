@@ -42,7 +42,8 @@ def test_local_ba_large_window_kat(ctx):
 
 
 @pytest.mark.parametrize("seed,nkf,npt,nfixed,iters", [(1, 5, 200, 2, 10), (2, 10, 5000, 2, 10), (3, 3, 50, 1, 5),
-                                                        (4, 10, 1000, 0, 10), (5, 12, 700, 2, 3), (6, 4, 33, 2, 10)])
+                                                        (4, 10, 1000, 0, 10), (5, 12, 700, 2, 3), (6, 4, 33, 2, 10),
+                                                        (7, 5, 9000, 2, 4)])   # > 8192 points: no renumbering, pattern sort through global buffers
 def test_local_ba_vs_cpu_solver(ctx, seed, nkf, npt, nfixed, iters):
     Pt, Pi, Xt, Xi, obs = synth.ba_problem(seed, nkf, npt, K)
     rng = np.random.default_rng(seed)

@@ -176,6 +176,35 @@ def test_find_fundamental_ransac_vs_oracle(ctx, n, seed, outliers, noise):
         assert np.array_equal(Fg.view(np.uint64), F.view(np.uint64))
 
 
+def _epipolar_err(F, p1, p2):
+    """max of the two squared point-to-epipolar-line distances (what cv::FMEstimatorCallback::computeError measures), in
+    float64 numpy -- independent of the oracle's code."""
+    x1 = np.concatenate([p1.astype(np.float64), np.ones((len(p1), 1))], 1)
+    x2 = np.concatenate([p2.astype(np.float64), np.ones((len(p2), 1))], 1)
+    l2 = x1 @ F.T                     # lines in image 2
+    l1 = x2 @ F                       # lines in image 1
+    d2 = (x2 * l2).sum(1) ** 2 / (l2[:, 0] ** 2 + l2[:, 1] ** 2)
+    d1 = (x1 * l1).sum(1) ** 2 / (l1[:, 0] ** 2 + l1[:, 1] ** 2)
+    return np.maximum(d1, d2)
+
+
+@pytest.mark.parametrize("n,seed,outliers,noise", [(400, 2, 60, 0.15), (2000, 3, 700, 0.3), (64, 4, 10, 0.1), (12, 23, 3, 0.2)])
+def test_fundamental_matrix_properties(ctx, n, seed, outliers, noise):
+    """Properties of the returned model that do not go through the oracle: F has rank 2, the mask is exactly the
+    set of points within one pixel of their epipolar lines under THAT F, and the planted inliers are (nearly all) kept."""
+    p1, p2 = _stereo_pts(n, seed, outliers, noise)
+    ok, mask, F, _ = ctx.find_fundamental_ransac(p1, p2)
+    assert ok == 1
+    sv = np.linalg.svd(F, compute_uv=False)
+    assert sv[2] <= 1e-9 * sv[0] and sv[1] > 1e-6 * sv[0]
+    err = _epipolar_err(F, p1, p2)
+    if n >= 15:     # RANSAC: inliers = error <= threshold^2 (computed in float by the kernel: leave a band around 1)
+        assert (err[mask == 1] < 1.0 + 1e-3).all() and (err[mask == 0] > 1.0 - 1e-3).all()
+    else:           # LMedS: inliers = error <= sigma^2 with sigma from the best median
+        assert mask.sum() >= 7 and (not (mask == 0).any() or err[mask == 1].max() < err[mask == 0].min())
+    assert mask.sum() >= 0.75 * (n - outliers)
+
+
 def test_find_fundamental_dispatch(ctx):
     p1, p2 = _stereo_pts(40, 8)
     assert ctx.find_fundamental_ransac(p1[:6], p2[:6])[0] == 0

@@ -90,14 +90,16 @@ int main() {
         if (nfound[l] != 4) { okN = okT = 0; continue; }
         for (int t = 0; t < 4; t++) {
             const int al = outA[l][t], bl = outB[l][t];
-            const int blk = l >> 4, hi = (l >> 2) & 3, lo = l & 3;
-            const int ak = (al >> 2) & 3, ai = al & 3, bk = (bl >> 2) & 3, bj = bl & 3;
-            const bool sameblk = (al >> 4) == blk && (bl >> 4) == blk && ak == bk;
-            if (!(sameblk && ai == hi && bj == lo)) okN = 0; /* D[blk][i][j] in lane 16 blk + 4 i + j */
-            if (!(sameblk && ai == lo && bj == hi)) okT = 0; /* D[blk][i][j] in lane 16 blk + 4 j + i */
+            /* measured on gfx950: A[blk][i][k] in lane 16 k + 4 blk + i, B[blk][k][j] in lane 16 k + 4 blk + j,
+               D[blk][i][j] in lane 16 i + 4 blk + j (okN); okT = the transposed output, which the hardware does not use */
+            const int i = l >> 4, blk = (l >> 2) & 3, j = l & 3;
+            const int ak = al >> 4, ablk = (al >> 2) & 3, ai = al & 3, bk = bl >> 4, bblk = (bl >> 2) & 3, bj = bl & 3;
+            const bool sameblk = ablk == blk && bblk == blk && ak == bk;
+            if (!(sameblk && ai == i && bj == j)) okN = 0;
+            if (!(sameblk && ai == j && bj == i)) okT = 0;
         }
     }
-    printf("{\"layout_A_16blk_4k_i__B_16blk_4k_j__D_16blk_4i_j\": %s, \"layout_D_16blk_4j_i\": %s,\n", okN ? "true" : "false", okT ? "true" : "false");
+    printf("{\"layout_A_16k_4blk_i__B_16k_4blk_j__D_16i_4blk_j\": %s, \"layout_D_transposed\": %s,\n", okN ? "true" : "false", okT ? "true" : "false");
     if (!okN && !okT) {
         printf(" \"triples\": [");
         for (int l = 0; l < 64; l++) { printf("[%d", l); for (int t = 0; t < nfound[l]; t++) printf(",%d,%d", outA[l][t], outB[l][t]); printf("]%s", l < 63 ? "," : ""); }

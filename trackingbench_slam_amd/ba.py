@@ -10,10 +10,27 @@ from . import capi, synth
 KITTI_K = (718.856, 718.856, 607.1928, 185.2157)
 
 
+def _pattern_sorted(prob, nfixed):
+    """The same window with its points renumbered by ascending visibility mask (stable), observations regrouped."""
+    Pt, Pi, Xt, Xi, o = prob
+    npt = len(Xi)
+    free = o["kf"] >= nfixed
+    mask = np.zeros(npt, np.int64)
+    np.bitwise_or.at(mask, o["pt"][free], np.int64(1) << (o["kf"][free] - nfixed).astype(np.int64))
+    perm = np.argsort(mask, kind="stable")          # new index r holds old point perm[r]
+    rank = np.empty(npt, np.int64); rank[perm] = np.arange(npt)
+    o2 = o.copy()
+    o2["pt"] = rank[o["pt"]]
+    o2 = o2[np.argsort(o2["pt"], kind="stable")]
+    return Pt, Pi, Xt[perm], Xi[perm], o2
+
+
 class BatchedLocalBA:
-    def __init__(self, ctx, nwindows, nkf=10, npt=5000, iters=10, seed=0, device=None, nfixed=2, distinct=4, stream=None):
+    def __init__(self, ctx, nwindows, nkf=10, npt=5000, iters=10, seed=0, device=None, nfixed=2, distinct=4, stream=None, presort=False):
         self.ctx, self.W, self.nkf, self.npt, self.iters, self.nfixed = ctx, int(nwindows), int(nkf), int(npt), int(iters), nfixed
         probs = [synth.ba_problem(seed * 100 + i, nkf, npt, KITTI_K) for i in range(min(distinct, self.W))]
+        if presort:   # measurement aid: points renumbered in visibility-pattern order (what k_ba_groups' ranks would be)
+            probs = [_pattern_sorted(p, nfixed) for p in probs]
         self.obs_pitch = max(len(p[4]) for p in probs)
         obs = np.zeros((self.W, self.obs_pitch), capi.BA_OBS)
         cnt = np.zeros(self.W, np.int32)

@@ -71,6 +71,9 @@ struct BaDims {
     unsigned long long oPtMask, oPermA, oPermB, oPtRank, oKPs, oGDesc;
     unsigned long long oGCost;   /* ints: cost estimate of the groups before group g (exclusive prefix, total at [ng]) */
     unsigned long long oGCut;    /* ints: first group of Schur wavefront v of the window (4 G + 1 entries) */
+    int renum;                   /* k_ba_rank renumbered the window's points in visibility-pattern order: every later kernel works on
+                                    the renumbered copy of the observations, ranks are the identity */
+    unsigned long long oPerm;    /* ints (renum): old index of the point that is now r */
     int schurWaveLds;            /* doubles of LDS per Schur wavefront (host: ba_c_wave_lds(nfree)) */
     int wgReduce;                /* Schur workgroups add their four wavefronts' partial systems through LDS (small batches: many
                                     workgroups per window, and k_ba_solve -- one workgroup per window -- adds them all) */
@@ -225,12 +228,14 @@ __device__ __forceinline__ int ba_ordered_rank(int n, int* tmp, Pred pred, Pred2
  * block nkf initialises the LM state, checks the input, builds ptStart and converts poses / points;
  * block nkf + 1 numbers the free-keyframe edges compactly (16-byte edge records, ptFree). */
 __global__ void __launch_bounds__(BA_T)
-k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ pts, const tb_ba_obs* __restrict__ obsAll,
-           const int32_t* __restrict__ obsCounts, double* __restrict__ dw, int* __restrict__ iw, BaState* __restrict__ states,
-           int* __restrict__ errflag) {
+k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ pts, const tb_ba_obs* __restrict__ obsOrig,
+           const tb_ba_obs* __restrict__ obsAll, const int32_t* __restrict__ obsCounts, double* __restrict__ dw, int* __restrict__ iw,
+           BaState* __restrict__ states, int* __restrict__ errflag) {
     __shared__ int tmp[8];
     const int w = blockIdx.y, k = blockIdx.x, tid = threadIdx.x;
-    const tb_ba_obs* obs = obsAll + (size_t)w * d.obs_pitch;
+    /* obsOrig: the caller's observations (checked here); obsAll: what the passes read -- the same, or k_ba_rank's renumbered
+     * copy, which is exact whenever the check passes and merely in range when it does not (the window is then skipped) */
+    const tb_ba_obs* obs = obsOrig + (size_t)w * d.obs_pitch;
     const int nobs = min(obsCounts[w], d.obs_pitch);
     double* D = dw + (size_t)w * d.wstride;
     int* I = iw + (size_t)w * d.istride;
@@ -257,6 +262,7 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
         }
         if (bad) errflag[w] = 1; /* benign race: every writer stores 1 */
     }
+    obs = obsAll + (size_t)w * d.obs_pitch;
     if (k < d.nkf) {
         /* keyframe k's edges in ascending edge order, placed behind the edges of the keyframes before it */
         int base = 0;
@@ -309,7 +315,7 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
         for (int p = max(prev + 1, 0); p <= min(cur, d.npt); p++) I[d.oPtStart + p] = e;
     }
     for (int p = max((nobs > 0 ? obs[nobs - 1].pt : -1) + 1, 0) + tid; p <= d.npt; p += BA_T) I[d.oPtStart + p] = nobs;
-    if (d.big) for (int p = tid; p < d.npt; p += BA_T) I[d.oPtRank + p] = p; /* large windows keep the point records in point order */
+    if (d.big || d.renum) for (int p = tid; p < d.npt; p += BA_T) I[d.oPtRank + p] = p; /* point records in point order */
     for (int kk = tid; kk < d.nkf; kk += BA_T) {
         const float* T = poses + ((size_t)w * d.nkf + kk) * 16;
         double R[9], t[3];
@@ -319,7 +325,8 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
         ba_store_se3(D + d.oT + (size_t)(d.nkf + kk) * 7, s);
     }
     for (int i = tid; i < d.npt * 3; i += BA_T) {
-        const double v = (double)pts[(size_t)w * d.npt * 3 + i];
+        const int r = i / 3, c = i - 3 * r;
+        const double v = (double)pts[(size_t)w * d.npt * 3 + (d.renum ? 3 * (size_t)I[d.oPerm + r] + c : (size_t)i)];
         D[d.oP + i] = v;
         D[d.oP + (size_t)d.npt * 3 + i] = v;
     }
@@ -666,6 +673,108 @@ __device__ __forceinline__ void ba_stable_split(int n, int* tmp, const int* src,
     __syncthreads();
 }
 
+/* ---- once per call, before k_ba_setup (windows on the MFMA path with up to BA_SORT_LDS points): renumber the points in
+ * visibility-pattern order. The Schur kernel wants the points of one pattern adjacent; with the records alone stored in that
+ * order (first version of round 3) the point-parallel passes wrote and read 96-byte records at scattered ranks, 10-15 % of
+ * their time. Here the window's observations are copied once with pt := rank -- points of ascending mask, ties in the caller's
+ * order, each point's edges in the caller's order -- and every later kernel runs on that copy: all per-point arrays are in
+ * pattern order, all passes stream. k_ba_finish writes the points back through perm. Sums over a point's edges keep their
+ * order; sums over points (chi2, keyframe blocks) run in the new order.
+ * grid (W) x 256 threads. Input that k_ba_setup's check rejects (indices out of range, not grouped by point) only has to stay
+ * in range here: out-of-range observations are skipped and every write is bounded by the counts. */
+#define BA_RT 1024 /* threads of k_ba_rank: one workgroup per window walks all its observations twice (latency, not bandwidth) */
+__global__ void __launch_bounds__(BA_RT)
+k_ba_rank(BaDims d, const tb_ba_obs* __restrict__ obsAll, const int32_t* __restrict__ obsCounts, int* __restrict__ iw,
+          tb_ba_obs* __restrict__ obs2All) {
+    extern __shared__ __attribute__((aligned(16))) unsigned rank_lds[]; /* 16 bytes per point (host: 16 npt) */
+    unsigned* word = rank_lds;                                 /* edges of the point << 16 | visibility mask */
+    int* first = reinterpret_cast<int*>(rank_lds + d.npt);     /* first edge of every (old) point */
+    int* start2 = first + d.npt;                               /* first edge of every rank in the copy */
+    unsigned short* pbuf = reinterpret_cast<unsigned short*>(start2 + d.npt); /* two permutation buffers */
+    __shared__ int tmp[BA_RT / 64 + 2];
+    constexpr int NW = BA_RT / 64;
+    const int w = blockIdx.x, tid = threadIdx.x;
+    const tb_ba_obs* obs = obsAll + (size_t)w * d.obs_pitch;
+    tb_ba_obs* obs2 = obs2All + (size_t)w * d.obs_pitch;
+    const int nobs = min(max(obsCounts[w], 0), d.obs_pitch);
+    int* I = iw + (size_t)w * d.istride;
+    for (int p = tid; p < d.npt; p += BA_RT) { word[p] = 0; first[p] = 0; }
+    __syncthreads();
+    for (int e0 = tid; e0 < nobs; e0 += 4 * BA_RT) { /* four independent observations (and their predecessors' points) in flight */
+        tb_ba_obs o[4];
+        int prev[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int e = min(e0 + i * BA_RT, nobs - 1);
+            o[i] = obs[e];
+            prev[i] = obs[max(e - 1, 0)].pt;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int e = e0 + i * BA_RT;
+            if (e >= nobs || (unsigned)o[i].pt >= (unsigned)d.npt || (unsigned)o[i].kf >= (unsigned)d.nkf) continue;
+            atomicAdd(&word[o[i].pt], 0x10000u);
+            if (o[i].kf >= d.nfixed) atomicOr(&word[o[i].pt], 1u << (o[i].kf - d.nfixed));
+            if (e == 0 || prev[i] != o[i].pt) first[o[i].pt] = e;
+        }
+    }
+    /* LSD sort by mask, one stable ballot-ranked split per free keyframe (as k_ba_groups does for windows it sorts itself) */
+    unsigned short* pa_ = pbuf;
+    unsigned short* pb_ = pbuf + d.npt;
+    for (int p = tid; p < d.npt; p += BA_RT) pa_[p] = (unsigned short)p;
+    __syncthreads();
+    {
+        const int wave = tid >> 6, lane = tid & 63;
+        const int q = (((d.npt + NW - 1) / NW) + 63) & ~63, lo = min(wave * q, d.npt), hi = min(lo + q, d.npt);
+        const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
+        for (int b = 0; b < d.nfree; b++) {
+            int cnt = 0;
+            for (int e = lo + lane; e < hi; e += 64) cnt += ((word[pa_[e]] >> b) & 1) ? 0 : 1;
+            cnt = tb_wave_sum(cnt);
+            if (lane == 0) tmp[wave] = cnt;
+            __syncthreads();
+            int z = 0, all = 0;
+            for (int v = 0; v < NW; v++) { const int c = tmp[v]; all += c; if (v < wave) z += c; }
+            int o = all + (lo - z);
+            for (int e0 = lo; e0 < hi; e0 += 64) {
+                const int e = e0 + lane;
+                const bool valid = e < hi;
+                const int v = valid ? pa_[e] : 0;
+                const bool f = valid && !((word[v] >> b) & 1);
+                const unsigned long long m0 = __ballot(f), m1 = __ballot(valid && !f);
+                if (valid) pb_[f ? z + __popcll(m0 & lt) : o + __popcll(m1 & lt)] = (unsigned short)v;
+                z += __popcll(m0);
+                o += __popcll(m1);
+            }
+            __syncthreads();
+            unsigned short* t = pa_; pa_ = pb_; pb_ = t;
+        }
+    }
+    /* pa_[r] = the point that becomes r; its edges start behind those of the ranks before it */
+    for (int r = tid; r < d.npt; r += BA_RT) {
+        const int p = pa_[r];
+        I[d.oPerm + r] = p;
+        start2[r] = (int)(word[p] >> 16);
+        pb_[p] = (unsigned short)r; /* rank of the old point */
+    }
+    __syncthreads();
+    tb_block_excl_scan(start2, d.npt, tmp);
+    for (int e0 = tid; e0 < nobs; e0 += 4 * BA_RT) {
+        tb_ba_obs o[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) o[i] = obs[min(e0 + i * BA_RT, nobs - 1)];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int e = e0 + i * BA_RT;
+            if (e >= nobs || (unsigned)o[i].pt >= (unsigned)d.npt || (unsigned)o[i].kf >= (unsigned)d.nkf) continue;
+            const int r = pb_[o[i].pt], j = e - first[o[i].pt];
+            if ((unsigned)j >= (word[o[i].pt] >> 16)) continue; /* not grouped by point: rejected by k_ba_setup */
+            o[i].pt = r;
+            obs2[start2[r] + j] = o[i];
+        }
+    }
+}
+
 /* ---- once per call, windows on the MFMA path: visibility patterns, pattern sort, ranks, pattern-ordered edge records,
  * group descriptors. grid (W) x 256 threads. */
 __global__ void __launch_bounds__(BA_T)
@@ -684,7 +793,7 @@ k_ba_groups(BaDims d, int* __restrict__ iw, const int* __restrict__ errflag) {
         int m = 0;
         for (int e = e0; e < e1; e++) m |= 1 << (KP[e].x & 63);
         I[d.oPtMask + p] = m;
-        if (d.npt > BA_SORT_LDS) I[d.oPermA + p] = p;
+        if (!d.renum && d.npt > BA_SORT_LDS) I[d.oPermA + p] = p;
         atomicAdd(&cntb[m], 1); /* counts only: the order of the adds does not matter */
     }
     __threadfence_block();
@@ -695,7 +804,11 @@ k_ba_groups(BaDims d, int* __restrict__ iw, const int* __restrict__ errflag) {
      * latency: 190 -> ~40 us). Larger windows sort through the global buffers. */
     int* src = I + d.oPermA;
     int* dst = I + d.oPermB;
-    if (d.npt <= BA_SORT_LDS) {
+    if (d.renum) { /* k_ba_rank sorted already: the points ARE in pattern order */
+        for (int r = tid; r < d.npt; r += BA_T) src[r] = r;
+        __threadfence_block();
+        __syncthreads();
+    } else if (d.npt <= BA_SORT_LDS) {
         unsigned short* mk = sortbuf;                  /* mask of point p */
         unsigned short* pa_ = sortbuf + BA_SORT_LDS;   /* permutation, ping */
         unsigned short* pb_ = sortbuf + 2 * BA_SORT_LDS;
@@ -1049,7 +1162,6 @@ k_ba_schur_c(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, BaSt
     for (int i = tid; i < BA_CTAB_ROWS * 64; i += BA_T) ctab[i] = ba_cwhere.v[i];
     __syncthreads();
     const double delta = (double)sqrtf(5.991f);
-    const int ng = I[d.oGDesc + 4 * (size_t)d.npt];
     const int lastE = d.obs_pitch - 1;
     const double* Hq = D + d.oHq;
     const int4* KPs = reinterpret_cast<const int4*>(I + d.oKPs);
@@ -1057,7 +1169,7 @@ k_ba_schur_c(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, BaSt
     const unsigned lastQ = (unsigned)d.npt * BA_REC - 1u;
     /* every wavefront takes a contiguous run of groups: the groups are in pattern order, so consecutive ones mostly share
      * their pattern and keep adding into the same product accumulators */
-    const int nwv = Gw * 4, wv = g0 * 4 + wave;
+    const int wv = g0 * 4 + wave;
     const int gBeg = I[d.oGCut + wv], gEnd = I[d.oGCut + wv + 1], lastG = gEnd - 1;
     auto range = [&](BaPreC& X, int g) {
         X.nxt = GD[min(g, max(lastG, 0))];
@@ -1146,11 +1258,13 @@ k_ba_schur_c(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, BaSt
             }
             double* z = Zt + (6 * slot) * ld + 3 * pl;
 #pragma unroll
+            for (int i = 0; i < 6; i++) JU[i] *= L.ww; /* the weight once, on the 2 x 3 factor */
+#pragma unroll
             for (int a = 0; a < 6; a++) {
-                const double p0w = L.ww * Jp[a], p1w = L.ww * Jp[6 + a];
-                z[a * ld] = fma(p0w, JU[0], p1w * JU[3]);
-                z[a * ld + 1] = fma(p0w, JU[1], p1w * JU[4]);
-                z[a * ld + 2] = fma(p0w, JU[2], p1w * JU[5]);
+                /* rows 3 and 4 of Jp^T have one structural zero each (ba_jac_pose_iz: J[9], J[4]): one product, not two */
+#pragma unroll
+                for (int c = 0; c < 3; c++)
+                    z[a * ld + c] = (a == 3) ? Jp[3] * JU[c] : (a == 4) ? Jp[10] * JU[3 + c] : fma(Jp[a], JU[c], Jp[6 + a] * JU[3 + c]);
             }
             if (slot == 0) { /* the rhs row: U^T bl of the point under its three columns */
                 double* zr = Zt + (6 * k) * ld + 3 * pl;
@@ -1919,11 +2033,12 @@ k_ba_decide(BaDims d, const double* __restrict__ dw, BaState* __restrict__ state
 
 /* ---- write back */
 __global__ void __launch_bounds__(BA_T)
-k_ba_finish(BaDims d, const double* __restrict__ dw, const BaState* __restrict__ states, float* __restrict__ poses,
-            float* __restrict__ pts, double* __restrict__ stats) {
+k_ba_finish(BaDims d, const double* __restrict__ dw, const int* __restrict__ iw, const BaState* __restrict__ states,
+            float* __restrict__ poses, float* __restrict__ pts, double* __restrict__ stats) {
     const int w = blockIdx.x, tid = threadIdx.x;
     const BaState st = states[w];
     const double* D = dw + (size_t)w * d.wstride;
+    const int* I = iw + (size_t)w * d.istride;
     if (!st.err) {
         for (int k = tid; k < d.nkf; k += BA_T) {
             const PoSE3 s = ba_load_se3(D + d.oT + ((size_t)st.cur * d.nkf + k) * 7);
@@ -1934,7 +2049,10 @@ k_ba_finish(BaDims d, const double* __restrict__ dw, const BaState* __restrict__
             T[3] = (float)s.tx; T[7] = (float)s.ty; T[11] = (float)s.tz;
             T[12] = T[13] = T[14] = 0.f; T[15] = 1.f;
         }
-        for (int i = tid; i < d.npt * 3; i += BA_T) pts[(size_t)w * d.npt * 3 + i] = (float)D[d.oP + (size_t)st.cur * d.npt * 3 + i];
+        for (int i = tid; i < d.npt * 3; i += BA_T) { /* renumbered windows: back to the caller's point order */
+            const int r = i / 3, c = i - 3 * r;
+            pts[(size_t)w * d.npt * 3 + (d.renum ? 3 * (size_t)I[d.oPerm + r] + c : (size_t)i)] = (float)D[d.oP + (size_t)st.cur * d.npt * 3 + i];
+        }
     }
     if (stats && tid == 0) {
         double* s = stats + 8 * w;
@@ -1969,6 +2087,7 @@ static void ba_dims(BaDims& d, int num_cu, int peers, int W, const double K[4], 
         d.wgReduce = d.Gbase > 4 ? 1 : 0;
     }
     d.big = d.nfree > BA_SMALL_MAXF;
+    d.renum = (!d.big && npt <= BA_SORT_LDS) ? 1 : 0;
     d.schurWaveLds = d.big ? 0 : ba_c_wave_lds(d.nfree);
     d.npairs = d.nfree * (d.nfree + 1) / 2;
     d.maxItems = (unsigned long long)obs_pitch * (d.nfree + 1) / 2 + 1; /* sum_p E_p (E_p + 1) / 2 with E_p <= nfree */
@@ -1997,6 +2116,7 @@ static void ba_dims(BaDims& d, int num_cu, int peers, int W, const double K[4], 
     d.oFreeKP = itake(4ull * obs_pitch);
     d.oKfRec = itake(4ull * obs_pitch);
     d.oPtRank = itake(npt);
+    d.oPerm = itake(d.renum ? npt : 0);
     d.oPtMask = itake(d.big ? 0 : npt);
     d.oPermA = itake(d.big ? 0 : npt);
     d.oPermB = itake(d.big ? 0 : npt);
@@ -2014,7 +2134,8 @@ size_t tbk_local_ba_work_bytes(const tb_ctx* ctx, int W, int nkf, int nfixed, in
     BaDims d;
     const double K[4] = {1, 1, 0, 0};
     ba_dims(d, ctx->num_cu, ctx->peers, W, K, nkf, nfixed, npt, obs_pitch, 1);
-    return (size_t)W * (d.wstride * sizeof(double) + d.istride * sizeof(int) + sizeof(BaState) + sizeof(int)) + 4096;
+    return (size_t)W * (d.wstride * sizeof(double) + d.istride * sizeof(int) + sizeof(BaState) + sizeof(int)) + 4096 +
+           (d.renum ? (size_t)W * obs_pitch * sizeof(tb_ba_obs) + 64 : 0);
 }
 
 int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixed, float* d_poses, int npt, float* d_pts,
@@ -2044,11 +2165,16 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
      * rejected-input flag per window; zeroed together before the setup kernel */
     const int ring = 1000;
     int* errflag = running + ring;
+    /* behind those (renum): the observations with the points renumbered in pattern order, the layout of the caller's array */
+    tb_ba_obs* obs2 = (tb_ba_obs*)(((uintptr_t)(errflag + W) + 63) & ~(uintptr_t)63);
+    const tb_ba_obs* d_obs_in = d_obs;
+    if (d.renum) d_obs = obs2;
     const size_t big_lds = (size_t)(d.np + 1) * BA_PLD * sizeof(double);
     const int R = (d.np + 15) >> 4;
     typedef void (*schur_t)(BaDims, double*, const int*, BaState*);
     const schur_t ks = R == 1 ? (schur_t)k_ba_schur_c<1> : R == 2 ? (schur_t)k_ba_schur_c<2> : R == 3 ? (schur_t)k_ba_schur_c<3> : (schur_t)k_ba_schur_c<4>;
     if (!d.big) TB_HIP(ctx, hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_lds));
+    if (d.renum) TB_HIP(ctx, hipFuncSetAttribute((const void*)k_ba_rank, hipFuncAttributeMaxDynamicSharedMemorySize, npt * 16));
     else TB_HIP(ctx, hipFuncSetAttribute((const void*)k_ba_solve_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
     /* once per call: LM state, CSR tables, pattern groups (block-pair lists for large windows) */
     auto enqueue_head = [&]() -> int {
@@ -2056,8 +2182,13 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
          * values on one of three contexts replaying from their own host threads (ROCm 7.2), the windows then read a set
          * rejected-input flag and returned their input */
         hipLaunchKernelGGL(k_ba_zero, dim3((ring + W + 255) / 256), dim3(256), 0, s, running, ring + W);
+        if (d.renum) {
+            tb_prof_begin(ctx, "k_ba_rank");
+            hipLaunchKernelGGL(k_ba_rank, dim3(W), dim3(BA_RT), (size_t)npt * 16, s, d, d_obs_in, d_counts, iw, obs2);
+            tb_prof_end(ctx);
+        }
         tb_prof_begin(ctx, "k_ba_setup");
-        hipLaunchKernelGGL(k_ba_setup, dim3(nkf + 2, W), dim3(BA_T), 0, s, d, d_poses, d_pts, d_obs, d_counts, dw, iw, states, errflag);
+        hipLaunchKernelGGL(k_ba_setup, dim3(nkf + 2, W), dim3(BA_T), 0, s, d, d_poses, d_pts, d_obs_in, d_obs, d_counts, dw, iw, states, errflag);
         tb_prof_end(ctx);
         if (!d.big) {
             tb_prof_begin(ctx, "k_ba_groups");
@@ -2127,7 +2258,7 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
     if (use_graph) {
         struct Key { BaDims d; const void *poses, *pts, *obs, *counts, *work; hipStream_t s; } key;
         memset(&key, 0, sizeof key);
-        key.d = d; key.poses = d_poses; key.pts = d_pts; key.obs = d_obs; key.counts = d_counts; key.work = d_work; key.s = s;
+        key.d = d; key.poses = d_poses; key.pts = d_pts; key.obs = d_obs_in; key.counts = d_counts; key.work = d_work; key.s = s;
         const std::string kb((const char*)&key, sizeof key);
         hipGraphExec_t exec = nullptr;
         for (auto& g : ctx->ba_graphs)
@@ -2183,7 +2314,7 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
         batch = 4;
     }
     tb_prof_begin(ctx, "k_ba_finish");
-    hipLaunchKernelGGL(k_ba_finish, dim3(W), dim3(BA_T), 0, s, d, dw, states, d_poses, d_pts, d_stats);
+    hipLaunchKernelGGL(k_ba_finish, dim3(W), dim3(BA_T), 0, s, d, dw, iw, states, d_poses, d_pts, d_stats);
     tb_prof_end(ctx);
     TB_HIP(ctx, hipGetLastError());
     return TB_OK;
