@@ -91,7 +91,12 @@ def schur_roofs(ba_pts, nwin, ba_kf, free_edges, nfixed=2, num_cu=256):
     slots, cap = 2 * num_cu, min(32, max((ba_pts // 64 + 3) // 4, 1))
     gbase = min(max(slots // max(nwin, 1), 1), cap)
     gextra = min(slots - gbase * nwin, nwin) if gbase < cap and slots > gbase * nwin else 0
-    nparts = (gbase * nwin + gextra) * (1 if gbase > 4 else 4)
+    if gbase > 4:      # small batches: one partial system per workgroup
+        nparts = gbase * nwin + gextra
+    else:              # one per wavefront, the round's wavefronts dealt to the windows one by one
+        total = 4 * max(slots, nwin)
+        vbase = min(total // max(nwin, 1), 4 * cap)
+        nparts = vbase * nwin + (total % max(nwin, 1) if vbase < 4 * cap else 0)
     out = nparts * (np_ * (np_ + 1) // 2 + np_) * 8
     nbytes = free_edges * 16 + nwin * ba_pts * 96 + out
     return flops, nbytes
@@ -325,10 +330,12 @@ def parse_args(argv=None):
     ap.add_argument("--ba-iters", type=int, default=10)
     ap.add_argument("--no-ba", action="store_true", help="diagnostic only: drop the local-BA stage")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--region-events", choices=("auto", "on", "off"), default="auto",
-                    help="per-kernel HIP events inside the timed region (auto: on above 64 frames per GPU; below, two event "
-                         "records per ~5 us kernel are a third of the step and keep the local-BA call from replaying its HIP "
-                         "graph: the per-kernel figures then come from the isolated passes right after the region)")
+    ap.add_argument("--region-events", choices=("auto", "dominant", "on", "off"), default="auto",
+                    help="HIP events inside the timed region: 'dominant' times the roofline's kernel only (k_ba_schur, 33 launches "
+                         "per step), 'on' every kernel (~400 launches per step: two event records each cost ~2 %% of the step), "
+                         "'off' none. auto: dominant above 64 frames per GPU; below, off (the event records are a third of a "
+                         "~5 us kernel and keep the local-BA call from replaying its HIP graph). The per-kernel tables "
+                         "come from the isolated passes right after the region either way")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
     ap.add_argument("--ba-split", type=int, default=0,
                     help="partitions of the BA windows, one stream + host thread each (0 = by batch size: 1 up to 64 frames, else 3)")
@@ -422,9 +429,14 @@ def main(argv=None):
     for _ in range(args.warmup):
         one_step()
     fence()
-    region_events = gpu and (args.region_events == "on" or (args.region_events == "auto" and args.frames > 64))
+    mode = args.region_events if args.region_events != "auto" else ("dominant" if args.frames > 64 else "off")
+    if mode == "dominant" and args.no_ba:
+        mode = "on"          # without the BA stage the roofline's kernel is an extractor kernel: time them all
+    region_events = gpu and mode != "off"
     if region_events:
-        pipe.profile_enable(True)
+        # the kernel that needs the most GPU time per step on every configuration measured so far: the Schur complement
+        # (windows of more than 10 free keyframes: its block-pair form); report() falls back to the isolated pass if not
+        pipe.profile_enable(True, only=("k_ba_schur_pairs" if args.ba_kf - 2 > 10 else "k_ba_schur") if mode == "dominant" else None)
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step()
@@ -560,16 +572,20 @@ def report(args, pipe, prof, el, world, n_joined, dev):
     in_region_launch_ms = tot_ms / max(calls, 1)
     events_note = ("HIP events on the kernel's stream over the timed region; other streams share the GPU then, "
                    "so it includes waiting for CU slots -- `isolated` is the same launch with its chain alone")
-    if not prof:   # --region-events off (small batches): the isolated pass right after the region is the only per-kernel timing
+    if name not in prof:   # --region-events off (small batches), or another kernel than the one timed in the region dominates:
+        # the isolated pass right after the region is the only timing of this kernel
         in_region_launch_ms = iso.get(name, 0.0)
         launches_per_step = max(int(round(iso_step.get(name, 0.0) / in_region_launch_ms)), 1) if in_region_launch_ms else 1
-        events_note = ("per-kernel events were OFF in the timed region (small batch: see --region-events); this is the isolated "
+        events_note = ("this kernel was not timed inside the region (see --region-events); this is the isolated "
                        "pass taken right after it, HIP events on the kernel's stream, its chain alone on the GPU")
     common = {"kernel": name, "launches_per_step": launches_per_step,
               "avg_launch_ms": round(in_region_launch_ms, 5),
               "avg_launch_ms_note": events_note,
               "hbm_copy_measured_GBs": round(copy_gbs, 1), "extractor": ext,
               "kernels_ms_per_step_in_region": kern_ms,
+              "kernels_ms_per_step_in_region_note": "HIP-event durations of the kernels timed inside the region (--region-events: "
+                                                    "'dominant' = the roofline's kernel only, 'on' = all); waiting for CU slots "
+                                                    "beside the other streams included",
               "isolated_kernels_ms_per_step": {k: round(v, 4) for k, v in sorted(iso_step.items())}}
 
     schur = None
@@ -580,7 +596,7 @@ def report(args, pipe, prof, el, world, n_joined, dev):
         fl = schur_flops_sparse(pipe.bas[0][0].sum_k2_free)
         c_s, ms_s = prof.get("k_ba_schur", (0, 0.0))
         il = iso["k_ba_schur"] / 1e3
-        ls = (ms_s / max(c_s, 1)) / 1e3 or (il if not prof else None)   # region events off: the isolated launch stands in
+        ls = (ms_s / max(c_s, 1)) / 1e3 or (il if "k_ba_schur" not in prof else None)   # not timed in the region: the isolated launch stands in
         fl_exec = float(pipe.bas[0][0].mfma_flops_executed)
         tr = pmc_traffic("k_ba_schur", nwin, geometry, detail=True)
         schur = {"kernel": "k_ba_schur", "bound": "mfma", "unit": "TFLOP/s", "peak": F64_MFMA_PEAK_TFLOPS, "windows_per_launch": nwin,

@@ -37,6 +37,10 @@ int tb_synchronize(tb_ctx* ctx);
  * figure needs the dominant kernel's average launch duration over the timed region). enable(1) resets the
  * accumulators; report() synchronises and writes one line per kernel: "name calls total_ms\n". */
 int tb_profile_enable(tb_ctx* ctx, int on);
+/* Time only the named kernel while profiling is enabled (NULL or "": all of them). Two event records per launch cost host
+ * time and a queue packet each: with several hundred launches per step, timing every kernel inside a measured region costs
+ * ~2 % of the region; timing the one kernel a roofline figure is about does not. */
+int tb_profile_only(tb_ctx* ctx, const char* kernel);
 /* Exchange helper ("counts first, then the live records"): the first counts[f] rows of every frame of a
  * [nframes][cap][row_bytes] record array, frame after frame, to the front of dst (same total size); *total (nullable, device,
  * int64) = the number of rows written. row_bytes a multiple of 4. Device pointers, asynchronous on the context's stream. */

@@ -29,9 +29,9 @@ def test_schur_model():
     fl, nb = bench.schur_roofs(5000, 171, 10, free_edges=171 * 20000)
     np_ = 48
     assert fl == 2.0 * (np_ * (np_ + 1) / 2 + np_) * 3 * 5000 * 171
-    # ba_dims() in k_ba.hip: 2 x 256 workgroup slots over 171 windows = 2 each and 170 of them one more; one partial system
-    # (lower triangle + rhs) per Schur wavefront
-    nparts = (2 * 171 + 170) * 4
+    # ba_dims() in k_ba.hip: 2 x 256 workgroup slots = 2048 wavefronts over 171 windows = 11 each and 167 of them one more; one
+    # partial system (lower triangle + rhs) per Schur wavefront
+    nparts = 11 * 171 + 167
     assert nb == 171 * 20000 * 16 + 171 * 5000 * 96 + nparts * (np_ * (np_ + 1) // 2 + np_) * 8
     # a small batch: 20 workgroups per window, added through LDS to one partial system each
     _, nb8 = bench.schur_roofs(5000, 8, 10, free_edges=8 * 20000)

@@ -28,7 +28,7 @@ TB_OK, TB_EINVAL, TB_ENOMEM, TB_ECAPACITY, TB_EUNSUPPORTED, TB_EDEVICE, TB_ESTAT
 # every symbol include/tb_capi.h declares (checked by tests/test_capi_exports.py)
 EXPORTS = [
     "tb_create", "tb_destroy", "tb_last_error", "tb_strerror", "tb_version", "tb_set_stream", "tb_synchronize",
-    "tb_profile_enable", "tb_profile_report", "tb_debug_force_dense_fast", "tb_measure_copy_seconds", "tb_set_concurrency", "tb_pack_rows_dev",
+    "tb_profile_enable", "tb_profile_only", "tb_profile_report", "tb_debug_force_dense_fast", "tb_measure_copy_seconds", "tb_set_concurrency", "tb_pack_rows_dev",
     "tb_scale_factors", "tb_pyramid_sizes", "tb_orb_quotas",
     "tb_extractor_create", "tb_extractor_destroy", "tb_extractor_set_images_host", "tb_extractor_set_images_dev",
     "tb_extractor_set_levels_host", "tb_extractor_build_pyramid", "tb_extractor_get_level_host", "tb_extractor_orb",
@@ -206,7 +206,9 @@ class Context:
     def synchronize(self):
         self.check(lib().tb_synchronize(self._h))
 
-    def profile_enable(self, on=True):
+    def profile_enable(self, on=True, only=None):
+        """Per-kernel HIP-event timing on the context's stream; `only`: time just that kernel (None: all)."""
+        self.check(lib().tb_profile_only(self._h, only.encode() if only else None))
         self.check(lib().tb_profile_enable(self._h, int(on)))
 
     def measure_copy_seconds(self, src_ptr, dst_ptr, nbytes, reps=10):

@@ -55,7 +55,9 @@ struct BaState {
 struct BaDims {
     int W, nkf, nfixed, nfree, np, npt, obs_pitch, iters;
     int nblkP, kfChunks, G, nChunks; /* G: most Schur workgroups a window has */
-    int Gbase, Gextra;               /* window w has Gbase + (w < Gextra) of them: Schur workgroups over the batch = one resident round */
+    int Gbase, Gextra;               /* small batches (wgReduce): window w has Gbase + (w < Gextra) Schur workgroups */
+    int Vbase, Vextra;               /* otherwise window w has Vbase + (w < Vextra) Schur WAVEFRONTS, dealt to the windows one by one
+                                        (a workgroup's four may belong to two windows): one resident round over the batch */
     int big, npairs;             /* more than 10 free keyframes: the block-pair Schur / panel solve kernels */
     unsigned long long oBigA;    /* large windows: the reduced system [np + 1][np] (row np = rhs) */
     unsigned long long oPairStart, oPairCnt, oPairItems, maxItems; /* ints: block-pair item lists */
@@ -78,6 +80,17 @@ struct BaDims {
     int wgReduce;                /* Schur workgroups add their four wavefronts' partial systems through LDS (small batches: many
                                     workgroups per window, and k_ba_solve -- one workgroup per window -- adds them all) */
 };
+
+/* Schur wavefronts of window w, and the window / wavefront-in-window of the batch's u-th unit (units: wavefronts, or
+ * workgroups when wgReduce): windows below `extra` have base + 1 units, the others base */
+__host__ __device__ inline int ba_schur_waves(const BaDims& d, int w) {
+    return d.wgReduce ? 4 * (d.Gbase + (w < d.Gextra ? 1 : 0)) : d.Vbase + (w < d.Vextra ? 1 : 0);
+}
+__device__ __forceinline__ void ba_schur_unit(int u, int base, int extra, int& w, int& i) {
+    const int head = extra * (base + 1);
+    if (u < head) { w = u / (base + 1); i = u - w * (base + 1); }
+    else { const int r = u - head; w = extra + r / base; i = r - (w - extra) * base; }
+}
 
 typedef double ba_d4 __attribute__((ext_vector_type(4)));
 typedef double ba_d2 __attribute__((ext_vector_type(2)));
@@ -901,7 +914,7 @@ k_ba_groups(BaDims d, int* __restrict__ iw, const int* __restrict__ errflag) {
     __syncthreads();
     /* where the window's Schur wavefronts start: wavefront v takes the groups whose cost prefix lies in
      * [v, v + 1) / nwv of the total (a binary search per wavefront at kernel start cost 18 dependent loads) */
-    const int nwv = 4 * (d.Gbase + (w < d.Gextra ? 1 : 0));
+    const int nwv = ba_schur_waves(d, w);
     for (int v = tid; v <= nwv; v += BA_T) {
         const long long target = ((long long)total * v + nwv - 1) / nwv;
         int lo = 0, hi = ng;
@@ -1131,24 +1144,39 @@ template <int R> /* 16-row tiles of the dense pose block; NF = free keyframes th
 __global__ void __launch_bounds__(BA_T, 2)
 k_ba_schur_c(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, BaState* __restrict__ states) {
     extern __shared__ __attribute__((aligned(16))) double lds[];
-    __shared__ double sRtf[BA_SMALL_MAXF * 12]; /* free keyframes at the linearisation state: R, t */
+    __shared__ double sRtfAll[4][BA_SMALL_MAXF * 12]; /* per wavefront: its window's free keyframes at the linearisation state: R, t */
     __shared__ unsigned ctab[BA_CTAB_ROWS * 64]; /* where the block products' accumulator entries go (BaCGeom::where) */
     constexpr int NF = (R == 1) ? 2 : (R == 2) ? 5 : (R == 3) ? 8 : BA_SMALL_MAXF;
     constexpr int NPAIR = NF * (NF + 1) / 2;
 #ifdef BA_TIMING
     const unsigned long long tstart_ = __builtin_readcyclecounter();
 #endif
-    const int w = blockIdx.y, g0 = blockIdx.x, tid = threadIdx.x;
-    const BaState st = states[w];
-    const int Gw = d.Gbase + (w < d.Gextra ? 1 : 0); /* this window's workgroups */
-    if (st.status || g0 >= Gw) return;
+    const int tid = threadIdx.x;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    for (int i = tid; i < BA_CTAB_ROWS * 64; i += BA_T) ctab[i] = ba_cwhere.v[i];
+    __syncthreads();
+    /* which window, and which of its wavefronts: a 1-D grid of exactly the units the batch has (a (G, W) grid with idle
+     * workgroups for the windows that have one fewer pushed real ones out of the resident round -- 172 windows ran 1.43 x
+     * as long as 171 -- and, at four per window, parked all idle ones on two of the eight XCDs) */
+    int w, wv, g0 = 0;
+    if (d.wgReduce) {
+        ba_schur_unit(blockIdx.x, d.Gbase, d.Gextra, w, g0);
+        wv = 4 * g0 + wave;
+    } else {
+        const int u = blockIdx.x * 4 + wave;
+        if (u >= d.Vbase * d.W + d.Vextra) return; /* the last workgroup's spare wavefronts (no barrier below on this path) */
+        ba_schur_unit(u, d.Vbase, d.Vextra, w, wv);
+    }
+    w = __builtin_amdgcn_readfirstlane(w); wv = __builtin_amdgcn_readfirstlane(wv);
+    const BaState st = states[w];
+    if (st.status) return;
+    double* sRtf = sRtfAll[wave];
     double* Zt = lds + (size_t)wave * d.schurWaveLds;          /* the group's tile, then its compact result */
     double* Hi = Zt + (d.schurWaveLds - BA_RECS_LDS - BA_ZERO_LDS); /* the group's point records, then a block of zeros */
     const int zeroOfs = d.schurWaveLds - BA_ZERO_LDS;
     double* D = dw + (size_t)w * d.wstride;
     const int* I = iw + (size_t)w * d.istride;
-    for (int k = tid; k < d.nfree; k += BA_T) ba_pose_to_Rt(D + d.oT + ((size_t)st.cur * d.nkf + d.nfixed + k) * 7, sRtf + k * 12);
+    for (int k = lane; k < d.nfree; k += 64) ba_pose_to_Rt(D + d.oT + ((size_t)st.cur * d.nkf + d.nfixed + k) * 7, sRtf + k * 12);
     /* dense accumulators: lane p < NPAIR = block pair (a >= b) of free keyframes, register 6 i + j = entry (i, j) of its
      * 6 x 6 block -- a group's compact blocks are added with one LDS read per register at a per-lane base address */
     double S[36];
@@ -1159,8 +1187,7 @@ k_ba_schur_c(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, BaSt
     while ((pa + 1) * (pa + 2) / 2 <= lane) pa++;
     const int pb = lane - pa * (pa + 1) / 2;
     if (lane < BA_ZERO_LDS) Zt[zeroOfs + lane] = 0;
-    for (int i = tid; i < BA_CTAB_ROWS * 64; i += BA_T) ctab[i] = ba_cwhere.v[i];
-    __syncthreads();
+    ba_wave_lds_fence();
     const double delta = (double)sqrtf(5.991f);
     const int lastE = d.obs_pitch - 1;
     const double* Hq = D + d.oHq;
@@ -1169,7 +1196,6 @@ k_ba_schur_c(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, BaSt
     const unsigned lastQ = (unsigned)d.npt * BA_REC - 1u;
     /* every wavefront takes a contiguous run of groups: the groups are in pattern order, so consecutive ones mostly share
      * their pattern and keep adding into the same product accumulators */
-    const int wv = g0 * 4 + wave;
     const int gBeg = I[d.oGCut + wv], gEnd = I[d.oGCut + wv + 1], lastG = gEnd - 1;
     auto range = [&](BaPreC& X, int g) {
         X.nxt = GD[min(g, max(lastG, 0))];
@@ -1407,8 +1433,7 @@ k_ba_solve(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) {
     BaState* st = states + w;
     if (st->status) return;
     double* D = dw + (size_t)w * d.wstride;
-    const int Gw = d.Gbase + (w < d.Gextra ? 1 : 0);
-    const int np = d.np, nPart = d.wgReduce ? Gw : 4 * Gw; /* one partial system per Schur workgroup or per wavefront */
+    const int np = d.np, nPart = d.wgReduce ? ba_schur_waves(d, w) / 4 : ba_schur_waves(d, w); /* one partial system per Schur workgroup or per wavefront */
     const double lambda = st->lambda;
     /* the lower triangle: every thread owns up to BA_SOLVE_E entries and adds the partial systems in order -- the entries are
      * the INNER loop, so one trip over the partials keeps BA_SOLVE_E x 4 independent loads in flight (one entry per trip
@@ -2085,6 +2110,11 @@ static void ba_dims(BaDims& d, int num_cu, int peers, int W, const double K[4], 
         d.Gextra = (d.Gbase < cap && slots > d.Gbase * W) ? std::min(slots - d.Gbase * W, W) : 0;
         d.G = d.Gbase + (d.Gextra > 0 ? 1 : 0);
         d.wgReduce = d.Gbase > 4 ? 1 : 0;
+        /* large batches: the round's 4 x slots wavefronts dealt to the windows one by one -- with whole workgroups 171 windows
+         * got three each but one of them two, and that window's wavefronts (half as many again to do) ended the launch */
+        const int T = 4 * std::max(slots, W);
+        d.Vbase = std::min(T / std::max(W, 1), 4 * cap);
+        d.Vextra = d.Vbase < 4 * cap ? T % std::max(W, 1) : 0;
     }
     d.big = d.nfree > BA_SMALL_MAXF;
     d.renum = (!d.big && npt <= BA_SORT_LDS) ? 1 : 0;
@@ -2104,7 +2134,8 @@ static void ba_dims(BaDims& d, int num_cu, int peers, int W, const double K[4], 
     d.oXp = take(std::max(64, d.np));
     d.oPartKF = take(27ull * std::max(d.nfree, 1) * d.kfChunks);
     d.oPartP = take(4ull * d.nblkP);
-    d.oPartS = take(d.big ? 0 : 4096ull * 4 * d.G);
+    const int maxWaves = d.wgReduce ? 4 * d.G : d.Vbase + (d.Vextra > 0 ? 1 : 0); /* Schur wavefronts of a window at most */
+    d.oPartS = take(d.big ? 0 : 4096ull * (d.wgReduce ? d.G : maxWaves));
     d.oBigA = take(d.big ? (unsigned long long)(d.np + 1) * d.np + 32 : 0); /* + BA_PB: the last panel's row loads */
     d.wstride = o;
     unsigned long long io = 0;
@@ -2123,7 +2154,7 @@ static void ba_dims(BaDims& d, int num_cu, int peers, int W, const double K[4], 
     d.oKPs = itake(d.big ? 0 : 4ull * obs_pitch);
     d.oGDesc = itake(d.big ? 0 : 4ull * npt + 4);
     d.oGCost = itake(d.big ? 0 : (unsigned long long)npt + 1);
-    d.oGCut = itake(d.big ? 0 : 4ull * d.G + 1);
+    d.oGCut = itake(d.big ? 0 : (unsigned long long)maxWaves + 1);
     d.oPairStart = itake(d.big ? d.npairs + 1 : 0);
     d.oPairCnt = itake(d.big ? d.npairs : 0);
     d.oPairItems = itake(d.big ? 2 * d.maxItems : 0);
@@ -2228,7 +2259,7 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
             tb_prof_end(ctx);
         } else {
             tb_prof_begin(ctx, "k_ba_schur");
-            hipLaunchKernelGGL(ks, dim3(d.G, W), dim3(BA_T), schur_lds, s, d, dw, iw, states);
+            hipLaunchKernelGGL(ks, dim3(d.wgReduce ? d.Gbase * W + d.Gextra : (d.Vbase * W + d.Vextra + 3) / 4), dim3(BA_T), schur_lds, s, d, dw, iw, states);
             tb_prof_end(ctx);
             tb_prof_begin(ctx, "k_ba_solve");
             if (d.np <= 16) hipLaunchKernelGGL(k_ba_solve<16>, dim3(W), dim3(BA_T), 0, s, d, dw, states);

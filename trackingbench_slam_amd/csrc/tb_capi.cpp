@@ -48,7 +48,10 @@ static hipEvent_t prof_event(tb_ctx* ctx) {
     return e;
 }
 void tb_prof_begin(tb_ctx* ctx, const char* name) {
+    ctx->prof_open = false;
     if (!ctx->prof) return;
+    if (!ctx->prof_only.empty() && ctx->prof_only != name) return;
+    ctx->prof_open = true;
     tb_ctx::ProfRec r;
     r.name = name;
     r.a = prof_event(ctx);
@@ -57,8 +60,9 @@ void tb_prof_begin(tb_ctx* ctx, const char* name) {
     ctx->prof_recs.push_back(r);
 }
 void tb_prof_end(tb_ctx* ctx) {
-    if (!ctx->prof || ctx->prof_recs.empty()) return;
+    if (!ctx->prof || !ctx->prof_open || ctx->prof_recs.empty()) return;
     hipEventRecord(ctx->prof_recs.back().b, ctx->stream);
+    ctx->prof_open = false;
 }
 static void prof_drain(tb_ctx* ctx) {
     hipStreamSynchronize(ctx->stream);
@@ -83,6 +87,13 @@ int tb_profile_enable(tb_ctx* ctx, int on) {
     prof_drain(ctx);
     ctx->prof_acc.clear();
     ctx->prof = on != 0;
+    return TB_OK;
+}
+
+int tb_profile_only(tb_ctx* ctx, const char* kernel) {
+    TB_ENTER(ctx);
+    if (!ctx) return TB_EINVAL;
+    ctx->prof_only = kernel ? kernel : "";
     return TB_OK;
 }
 

@@ -29,6 +29,8 @@ struct tb_ctx {
     std::set<tb_extractor*> live;               /* every plan created on this context */
     /* per-kernel HIP-event timing (tb_profile_*) */
     bool prof = false;
+    bool prof_open = false;   /* the last tb_prof_begin recorded its start event */
+    std::string prof_only;    /* non-empty: time only this kernel (tb_profile_only) */
     struct ProfRec { const char* name; hipEvent_t a, b; };
     std::vector<ProfRec> prof_recs;
     std::vector<hipEvent_t> prof_pool;

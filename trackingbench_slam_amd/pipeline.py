@@ -92,7 +92,8 @@ class TrackingPipeline:
                 # behind the extractor's half-million (measured, 512 frames: 21.66 -> 21.14 ms per step; TB_BA_PRIO=0 restores)
                 st = torch.cuda.Stream(device=self.dev, priority=int(os.environ.get("TB_BA_PRIO", "-1")))
                 cx = capi.Context(device, stream=st.cuda_stream)
-                cx.set_concurrency(nsplit)   # the partitions run side by side: each sizes its grids for its share of the GPU
+                # the partitions run side by side: each sizes its grids for its share of the GPU (TB_BA_PEERS: A/B hook)
+                cx.set_concurrency(int(os.environ.get("TB_BA_PEERS", nsplit)))
                 self.bas.append((BatchedLocalBA(cx, bounds[i + 1] - bounds[i], ba_kf, ba_pts, ba_iters, seed * 16 + i, self.dev,
                                                 distinct=max(1, -(-int(ba_distinct) // nsplit)), stream=st), st, cx))
             # each partition's driver blocks on its own stream once per call (LM termination is data dependent):
@@ -136,10 +137,10 @@ class TrackingPipeline:
         for _, _, cx in self.bas:
             cx.close()
 
-    def profile_enable(self, on=True):
-        self.ctx.profile_enable(on)
+    def profile_enable(self, on=True, only=None):
+        self.ctx.profile_enable(on, only)
         for _, _, cx in self.bas:
-            cx.profile_enable(on)
+            cx.profile_enable(on, only)
 
     def profile_report(self):
         rep = dict(self.ctx.profile_report())
