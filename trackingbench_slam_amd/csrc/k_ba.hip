@@ -276,6 +276,7 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
         if (bad) errflag[w] = 1; /* benign race: every writer stores 1 */
     }
     obs = obsAll + (size_t)w * d.obs_pitch;
+    if (d.renum && k != d.nkf) return; /* k_ba_prepare built the lists of this window */
     if (k < d.nkf) {
         /* keyframe k's edges in ascending edge order, placed behind the edges of the keyframes before it */
         int base = 0;
@@ -323,12 +324,14 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
         st->done_iters = 0; st->err = 0; st->sing = 0; st->hq_fresh = 0;
     }
     __syncthreads();
-    for (int e = tid; e < nobs; e += BA_T) { /* ptStart[p] = first edge with pt >= p: the points whose first edge is e */
-        const int prev = (e > 0) ? obs[e - 1].pt : -1, cur = obs[e].pt;
-        for (int p = max(prev + 1, 0); p <= min(cur, d.npt); p++) I[d.oPtStart + p] = e;
+    if (!d.renum) {
+        for (int e = tid; e < nobs; e += BA_T) { /* ptStart[p] = first edge with pt >= p: the points whose first edge is e */
+            const int prev = (e > 0) ? obs[e - 1].pt : -1, cur = obs[e].pt;
+            for (int p = max(prev + 1, 0); p <= min(cur, d.npt); p++) I[d.oPtStart + p] = e;
+        }
+        for (int p = max((nobs > 0 ? obs[nobs - 1].pt : -1) + 1, 0) + tid; p <= d.npt; p += BA_T) I[d.oPtStart + p] = nobs;
+        if (d.big) for (int p = tid; p < d.npt; p += BA_T) I[d.oPtRank + p] = p; /* large windows keep the point records in point order */
     }
-    for (int p = max((nobs > 0 ? obs[nobs - 1].pt : -1) + 1, 0) + tid; p <= d.npt; p += BA_T) I[d.oPtStart + p] = nobs;
-    if (d.big || d.renum) for (int p = tid; p < d.npt; p += BA_T) I[d.oPtRank + p] = p; /* point records in point order */
     for (int kk = tid; kk < d.nkf; kk += BA_T) {
         const float* T = poses + ((size_t)w * d.nkf + kk) * 16;
         double R[9], t[3];
@@ -686,32 +689,45 @@ __device__ __forceinline__ void ba_stable_split(int n, int* tmp, const int* src,
     __syncthreads();
 }
 
-/* ---- once per call, before k_ba_setup (windows on the MFMA path with up to BA_SORT_LDS points): renumber the points in
- * visibility-pattern order. The Schur kernel wants the points of one pattern adjacent; with the records alone stored in that
- * order (first version of round 3) the point-parallel passes wrote and read 96-byte records at scattered ranks, 10-15 % of
- * their time. Here the window's observations are copied once with pt := rank -- points of ascending mask, ties in the caller's
- * order, each point's edges in the caller's order -- and every later kernel runs on that copy: all per-point arrays are in
- * pattern order, all passes stream. k_ba_finish writes the points back through perm. Sums over a point's edges keep their
- * order; sums over points (chi2, keyframe blocks) run in the new order.
- * grid (W) x 256 threads. Input that k_ba_setup's check rejects (indices out of range, not grouped by point) only has to stay
+/* ---- once per call, before k_ba_setup (windows on the MFMA path with up to BA_SORT_LDS points and BA_PREP_MAXKF keyframes):
+ * renumber the points in visibility-pattern order and build every index table of the call, one workgroup per window with its
+ * tables in LDS.
+ * The Schur kernel wants the points of one pattern adjacent; with the records alone stored in that order (first version of
+ * round 3) the point-parallel passes wrote and read 96-byte records at scattered ranks, 10-15 % of their time. Here the
+ * window's observations are copied once with pt := rank -- points of ascending mask, ties in the caller's order, each point's
+ * edges in the caller's order -- and every later kernel runs on that copy: all per-point arrays are in pattern order, all
+ * passes stream. k_ba_finish writes the points back through perm. Sums over a point's edges keep their order; sums over
+ * points (chi2, keyframe blocks) run in the new order.
+ * The tables: ptStart (CSR by point), the keyframe lists (kfStart, 16-byte records in ascending edge order: a stable counting
+ * sort by keyframe, ballots per 64-edge slab), the free-keyframe edge records of the Schur kernel (a point's edges by
+ * ascending keyframe = row block of its group's tile), the group descriptors, their cost prefix and the Schur wavefronts'
+ * cuts. k_ba_setup built the lists with one workgroup per keyframe, each reading all observations twice (24 passes over the
+ * window's observations, the largest HBM reader of the call), and k_ba_groups followed with the patterns; for the windows
+ * that come here setup only checks the input and converts the state.
+ * grid (W) x 1024 threads. Input that k_ba_setup's check rejects (indices out of range, not grouped by point) only has to stay
  * in range here: out-of-range observations are skipped and every write is bounded by the counts. */
-#define BA_RT 1024 /* threads of k_ba_rank: one workgroup per window walks all its observations twice (latency, not bandwidth) */
+#define BA_RT 1024          /* one workgroup per window walks all its observations a few times: latency, not bandwidth */
+#define BA_PREP_MAXKF 64    /* keyframes of a window that takes this path (one lane per keyframe in the counting sort) */
 __global__ void __launch_bounds__(BA_RT)
-k_ba_rank(BaDims d, const tb_ba_obs* __restrict__ obsAll, const int32_t* __restrict__ obsCounts, int* __restrict__ iw,
-          tb_ba_obs* __restrict__ obs2All) {
-    extern __shared__ __attribute__((aligned(16))) unsigned rank_lds[]; /* 16 bytes per point (host: 16 npt) */
-    unsigned* word = rank_lds;                                 /* edges of the point << 16 | visibility mask */
-    int* first = reinterpret_cast<int*>(rank_lds + d.npt);     /* first edge of every (old) point */
-    int* start2 = first + d.npt;                               /* first edge of every rank in the copy */
-    unsigned short* pbuf = reinterpret_cast<unsigned short*>(start2 + d.npt); /* two permutation buffers */
-    __shared__ int tmp[BA_RT / 64 + 2];
+k_ba_prepare(BaDims d, const tb_ba_obs* __restrict__ obsAll, const int32_t* __restrict__ obsCounts, int* __restrict__ iw,
+             tb_ba_obs* __restrict__ obs2All) {
+    extern __shared__ __attribute__((aligned(16))) unsigned prep_lds[]; /* 16 bytes per point + 16 (host: 16 npt + 16) */
+    unsigned* word = prep_lds;                                 /* edges of the (old) point << 16 | visibility mask */
+    int* first = reinterpret_cast<int*>(prep_lds + d.npt);     /* first edge of every (old) point; later the free-edge prefix by rank */
+    int* start2 = first + d.npt;                               /* [npt + 1] first edge of every rank in the copy; later the groups' cost prefix */
+    unsigned short* pbuf = reinterpret_cast<unsigned short*>(start2 + d.npt + 1); /* two permutation buffers */
     constexpr int NW = BA_RT / 64;
-    const int w = blockIdx.x, tid = threadIdx.x;
+    __shared__ int tmp[NW + 2];
+    __shared__ int bins[1 << BA_SMALL_MAXF];   /* points per pattern, then first rank of every pattern */
+    __shared__ int kfc[NW][BA_PREP_MAXKF];     /* edges of keyframe k in wavefront v's range, then their first list position */
+    const int w = blockIdx.x, tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
     const tb_ba_obs* obs = obsAll + (size_t)w * d.obs_pitch;
     tb_ba_obs* obs2 = obs2All + (size_t)w * d.obs_pitch;
     const int nobs = min(max(obsCounts[w], 0), d.obs_pitch);
     int* I = iw + (size_t)w * d.istride;
     for (int p = tid; p < d.npt; p += BA_RT) { word[p] = 0; first[p] = 0; }
+    for (int i = tid; i < (1 << BA_SMALL_MAXF); i += BA_RT) bins[i] = 0;
     __syncthreads();
     for (int e0 = tid; e0 < nobs; e0 += 4 * BA_RT) { /* four independent observations (and their predecessors' points) in flight */
         tb_ba_obs o[4];
@@ -737,9 +753,7 @@ k_ba_rank(BaDims d, const tb_ba_obs* __restrict__ obsAll, const int32_t* __restr
     for (int p = tid; p < d.npt; p += BA_RT) pa_[p] = (unsigned short)p;
     __syncthreads();
     {
-        const int wave = tid >> 6, lane = tid & 63;
         const int q = (((d.npt + NW - 1) / NW) + 63) & ~63, lo = min(wave * q, d.npt), hi = min(lo + q, d.npt);
-        const unsigned long long lt = (lane == 0) ? 0ull : (~0ull >> (64 - lane));
         for (int b = 0; b < d.nfree; b++) {
             int cnt = 0;
             for (int e = lo + lane; e < hi; e += 64) cnt += ((word[pa_[e]] >> b) & 1) ? 0 : 1;
@@ -767,11 +781,15 @@ k_ba_rank(BaDims d, const tb_ba_obs* __restrict__ obsAll, const int32_t* __restr
     for (int r = tid; r < d.npt; r += BA_RT) {
         const int p = pa_[r];
         I[d.oPerm + r] = p;
+        I[d.oPtRank + r] = r;             /* the point records are stored in point order */
         start2[r] = (int)(word[p] >> 16);
-        pb_[p] = (unsigned short)r; /* rank of the old point */
+        pb_[p] = (unsigned short)r;       /* rank of the old point */
     }
     __syncthreads();
-    tb_block_excl_scan(start2, d.npt, tmp);
+    const int total = tb_block_excl_scan(start2, d.npt, tmp);
+    if (tid == 0) start2[d.npt] = total;
+    __syncthreads();
+    for (int r = tid; r <= d.npt; r += BA_RT) I[d.oPtStart + r] = start2[r];
     for (int e0 = tid; e0 < nobs; e0 += 4 * BA_RT) {
         tb_ba_obs o[4];
 #pragma unroll
@@ -785,6 +803,142 @@ k_ba_rank(BaDims d, const tb_ba_obs* __restrict__ obsAll, const int32_t* __restr
             o[i].pt = r;
             obs2[start2[r] + j] = o[i];
         }
+    }
+    __threadfence_block();
+    __syncthreads(); /* the copy is complete and visible to the workgroup; first[] is free */
+    /* masks by rank (the sort is done with the old order), free-edge prefix by rank, points per pattern */
+    for (int r = tid; r < d.npt; r += BA_RT) {
+        const unsigned m = word[pa_[r]] & 0xffffu;
+        first[r] = __popc(m);
+        if (m) atomicAdd(&bins[m], 1);
+    }
+    __syncthreads();
+    for (int r = tid; r < d.npt; r += BA_RT) pb_[r] = (unsigned short)(word[pa_[r]] & 0xffffu); /* pb_: mask of rank r from here on */
+    const int nfreeE = tb_block_excl_scan(first, d.npt, tmp); /* first[r]: the point's first record in the Schur kernel's list */
+    (void)nfreeE;
+    unsigned short* mk = pb_;
+    /* ---- keyframe lists: stable counting sort of the copy's edges by keyframe. Every wavefront owns a contiguous range. */
+    {
+        const int q = (((total + NW - 1) / NW) + 63) & ~63, lo = min(wave * q, total), hi = min(lo + q, total);
+        int cnt = 0; /* lane k: edges of keyframe k in this range */
+        for (int e0 = lo; e0 < hi; e0 += 64) {
+            const int e = e0 + lane;
+            const int kf = (e < hi) ? obs2[e].kf : -1;
+            for (int k = 0; k < d.nkf; k++) {
+                const unsigned long long m = __ballot(kf == k);
+                if (lane == k) cnt += __popcll(m);
+            }
+        }
+        if (lane < d.nkf) kfc[wave][lane] = cnt;
+        __syncthreads();
+        if (tid < d.nkf) { /* thread k: keyframe k's list start, and every wavefront's first position in it */
+            int base = 0;
+            for (int k = 0; k < tid; k++)
+                for (int v = 0; v < NW; v++) base += kfc[v][k];
+            I[d.oKfStart + tid] = base;
+            int run = base;
+            for (int v = 0; v < NW; v++) run += kfc[v][tid];
+            if (tid == d.nkf - 1) I[d.oKfStart + d.nkf] = run;
+        }
+        __syncthreads();
+        if (tid < d.nkf) {
+            int run = I[d.oKfStart + tid];
+            for (int v = 0; v < NW; v++) { const int c = kfc[v][tid]; kfc[v][tid] = run; run += c; }
+        }
+        __syncthreads();
+        int4* KR = reinterpret_cast<int4*>(I + d.oKfRec);
+        for (int e0 = lo; e0 < hi; e0 += 64) {
+            const int e = e0 + lane;
+            tb_ba_obs o;
+            o.kf = -1; o.pt = 0; o.u = o.v = o.inv_sigma2 = 0.f;
+            if (e < hi) o = obs2[e];
+            unsigned long long mine = 0;
+            int add = 0;
+            for (int k = 0; k < d.nkf; k++) {
+                const unsigned long long m = __ballot(o.kf == k);
+                if (o.kf == k) mine = m;
+                if (lane == k) add = __popcll(m);
+            }
+            if (o.kf >= 0 && o.kf < d.nkf) {
+                const int pos = kfc[wave][o.kf] + __popcll(mine & lt);
+                I[d.oKfEdges + pos] = e;
+                KR[pos] = make_int4(o.pt, __float_as_int(o.u), __float_as_int(o.v), __float_as_int(o.inv_sigma2));
+            }
+            ba_wave_lds_fence();
+            if (lane < d.nkf) kfc[wave][lane] += add;
+            ba_wave_lds_fence();
+        }
+    }
+    /* ---- the Schur kernel's edge records: a point's free-keyframe edges by ascending keyframe, points in rank order */
+    int4* KPs = reinterpret_cast<int4*>(I + d.oKPs);
+    for (int r = tid; r < d.npt; r += BA_RT) {
+        const int m = mk[r];
+        if (m == 0) continue;
+        const int base = first[r];
+        for (int e = start2[r]; e < start2[r + 1]; e++) {
+            const tb_ba_obs o = obs2[e];
+            if (o.kf < d.nfixed) continue;
+            const int fk = o.kf - d.nfixed;
+            KPs[base + __popc(m & ((1 << fk) - 1))] = make_int4((int)(((unsigned)r << 6) | (unsigned)fk), __float_as_int(o.u), __float_as_int(o.v),
+                                                                 __float_as_int(o.inv_sigma2));
+        }
+    }
+    /* ---- groups: every ba_c_cap(k)-th point of a pattern's run starts one */
+    tb_block_excl_scan(bins, 1 << BA_SMALL_MAXF, tmp); /* bins[m]: first rank of pattern m (ranks ascend with the mask; mask 0 first) */
+    int zero_pts = 0;
+    {   /* points without a free-keyframe edge come first and are not in the bins */
+        int c = 0;
+        for (int r = tid; r < d.npt; r += BA_RT) c += (mk[r] == 0) ? 1 : 0;
+        c = tb_wave_sum(c);
+        __syncthreads();
+        if (lane == 0) tmp[wave] = c;
+        __syncthreads();
+        for (int v = 0; v < NW; v++) zero_pts += tmp[v];
+        __syncthreads();
+    }
+    auto pat_first = [&](int m) { return zero_pts + bins[m]; };
+    auto pat_count = [&](int m) { return ((m + 1 < (1 << BA_SMALL_MAXF)) ? bins[m + 1] : d.npt - zero_pts) - bins[m]; };
+    int* gflag = start2; /* start2 went to global memory above: from here the group index of every rank, then the cost prefix */
+    __syncthreads();
+    for (int r = tid; r < d.npt; r += BA_RT) {
+        const int m = mk[r];
+        gflag[r] = (m != 0 && (r - pat_first(m)) % ba_ctab.cap[__popc(m)] == 0) ? 1 : 0;
+    }
+    __syncthreads();
+    const int ng = tb_block_excl_scan(gflag, d.npt, tmp);
+    int4* GD = reinterpret_cast<int4*>(I + d.oGDesc);
+    for (int r = tid; r < d.npt; r += BA_RT) {
+        const int m = mk[r];
+        if (m == 0) continue;
+        const int k = __popc(m), at = r - pat_first(m);
+        if (at % ba_ctab.cap[k] != 0) continue;
+        GD[gflag[r]] = make_int4(r, first[r], m, min(ba_ctab.cap[k], pat_count(m) - at));
+    }
+    if (tid == 0) I[d.oGDesc + 4 * (size_t)d.npt] = ng;
+    __threadfence_block();
+    __syncthreads();
+    /* cost estimate per group (shader clocks / 64 of the Schur kernel's phases, measured: a fixed part for the linearisation
+     * and the bookkeeping, the k-steps times the pattern's products, the direct form per tile column), as an exclusive
+     * prefix: the Schur wavefronts cut the group list into runs of equal cost */
+    int* GC = gflag;
+    for (int g = tid; g < ng; g += BA_RT) {
+        const int4 gd = GD[g];
+        const int k = __popc(gd.z), nks = (3 * gd.w + 3) >> 2;
+        GC[g] = 55 + ((k <= BA_KMFMA) ? nks * ba_ctab.nacc[k] : 12 * gd.w);
+    }
+    __syncthreads();
+    const int cost = tb_block_excl_scan(GC, ng, tmp);
+    if (tid == 0) GC[ng] = cost;
+    __syncthreads();
+    const int nwv = ba_schur_waves(d, w);
+    for (int v = tid; v <= nwv; v += BA_RT) {
+        const long long target = ((long long)cost * v + nwv - 1) / nwv;
+        int lo = 0, hi = ng;
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (GC[mid] < target) lo = mid + 1; else hi = mid;
+        }
+        I[d.oGCut + v] = (v == 0) ? 0 : (v == nwv) ? ng : lo;
     }
 }
 
@@ -806,7 +960,7 @@ k_ba_groups(BaDims d, int* __restrict__ iw, const int* __restrict__ errflag) {
         int m = 0;
         for (int e = e0; e < e1; e++) m |= 1 << (KP[e].x & 63);
         I[d.oPtMask + p] = m;
-        if (!d.renum && d.npt > BA_SORT_LDS) I[d.oPermA + p] = p;
+        if (d.npt > BA_SORT_LDS) I[d.oPermA + p] = p;
         atomicAdd(&cntb[m], 1); /* counts only: the order of the adds does not matter */
     }
     __threadfence_block();
@@ -817,11 +971,7 @@ k_ba_groups(BaDims d, int* __restrict__ iw, const int* __restrict__ errflag) {
      * latency: 190 -> ~40 us). Larger windows sort through the global buffers. */
     int* src = I + d.oPermA;
     int* dst = I + d.oPermB;
-    if (d.renum) { /* k_ba_rank sorted already: the points ARE in pattern order */
-        for (int r = tid; r < d.npt; r += BA_T) src[r] = r;
-        __threadfence_block();
-        __syncthreads();
-    } else if (d.npt <= BA_SORT_LDS) {
+    if (d.npt <= BA_SORT_LDS) {
         unsigned short* mk = sortbuf;                  /* mask of point p */
         unsigned short* pa_ = sortbuf + BA_SORT_LDS;   /* permutation, ping */
         unsigned short* pb_ = sortbuf + 2 * BA_SORT_LDS;
@@ -2117,7 +2267,7 @@ static void ba_dims(BaDims& d, int num_cu, int peers, int W, const double K[4], 
         d.Vextra = d.Vbase < 4 * cap ? T % std::max(W, 1) : 0;
     }
     d.big = d.nfree > BA_SMALL_MAXF;
-    d.renum = (!d.big && npt <= BA_SORT_LDS) ? 1 : 0;
+    d.renum = (!d.big && npt <= BA_SORT_LDS && nkf <= BA_PREP_MAXKF) ? 1 : 0;
     d.schurWaveLds = d.big ? 0 : ba_c_wave_lds(d.nfree);
     d.npairs = d.nfree * (d.nfree + 1) / 2;
     d.maxItems = (unsigned long long)obs_pitch * (d.nfree + 1) / 2 + 1; /* sum_p E_p (E_p + 1) / 2 with E_p <= nfree */
@@ -2205,7 +2355,7 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
     typedef void (*schur_t)(BaDims, double*, const int*, BaState*);
     const schur_t ks = R == 1 ? (schur_t)k_ba_schur_c<1> : R == 2 ? (schur_t)k_ba_schur_c<2> : R == 3 ? (schur_t)k_ba_schur_c<3> : (schur_t)k_ba_schur_c<4>;
     if (!d.big) TB_HIP(ctx, hipFuncSetAttribute((const void*)ks, hipFuncAttributeMaxDynamicSharedMemorySize, (int)schur_lds));
-    if (d.renum) TB_HIP(ctx, hipFuncSetAttribute((const void*)k_ba_rank, hipFuncAttributeMaxDynamicSharedMemorySize, npt * 16));
+    if (d.renum) TB_HIP(ctx, hipFuncSetAttribute((const void*)k_ba_prepare, hipFuncAttributeMaxDynamicSharedMemorySize, npt * 16 + 16));
     else TB_HIP(ctx, hipFuncSetAttribute((const void*)k_ba_solve_big, hipFuncAttributeMaxDynamicSharedMemorySize, (int)big_lds));
     /* once per call: LM state, CSR tables, pattern groups (block-pair lists for large windows) */
     auto enqueue_head = [&]() -> int {
@@ -2214,14 +2364,16 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
          * rejected-input flag and returned their input */
         hipLaunchKernelGGL(k_ba_zero, dim3((ring + W + 255) / 256), dim3(256), 0, s, running, ring + W);
         if (d.renum) {
-            tb_prof_begin(ctx, "k_ba_rank");
-            hipLaunchKernelGGL(k_ba_rank, dim3(W), dim3(BA_RT), (size_t)npt * 16, s, d, d_obs_in, d_counts, iw, obs2);
+            tb_prof_begin(ctx, "k_ba_prepare");
+            hipLaunchKernelGGL(k_ba_prepare, dim3(W), dim3(BA_RT), (size_t)npt * 16 + 16, s, d, d_obs_in, d_counts, iw, obs2);
             tb_prof_end(ctx);
         }
         tb_prof_begin(ctx, "k_ba_setup");
         hipLaunchKernelGGL(k_ba_setup, dim3(nkf + 2, W), dim3(BA_T), 0, s, d, d_poses, d_pts, d_obs_in, d_obs, d_counts, dw, iw, states, errflag);
         tb_prof_end(ctx);
-        if (!d.big) {
+        if (d.renum) {
+            /* k_ba_prepare did it */
+        } else if (!d.big) {
             tb_prof_begin(ctx, "k_ba_groups");
             hipLaunchKernelGGL(k_ba_groups, dim3(W), dim3(BA_T), 0, s, d, iw, errflag);
             tb_prof_end(ctx);
