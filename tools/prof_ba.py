@@ -30,7 +30,7 @@ print("done", ba.stats[0].tolist())
 
 import ctypes as C
 if hasattr(capi.lib(), "tb_debug_ba_times"):
-    buf = (C.c_ulonglong * 16)()
+    buf = (C.c_ulonglong * 24)()
     capi.lib().tb_debug_ba_times(buf, 1)
     ba.run(); torch.cuda.synchronize()
     capi.lib().tb_debug_ba_times(buf, 1)
@@ -41,5 +41,8 @@ if hasattr(capi.lib(), "tb_debug_ba_times"):
         print("  %-18s %8.0f clk/group  %5.1f%%" % (nm, buf[i] / ngr, 100.0 * buf[i] / max(tot, 1)))
     print("  groups sampled %d, points per group %.2f" % (ngr, buf[7] / ngr))
     nwg = max(buf[10], 1)
+    ns = max(buf[15], 1)
+    print("  k_ba_solve per launch and window: assembly %.0f clk, factorisation %.0f, substitutions %.0f, state update %.0f" % (
+        buf[11] / ns, buf[12] / ns, buf[13] / ns, buf[14] / ns))
     print("  per sampled wavefront: prologue %.0f clk, first loads + loop tail %.0f, epilogue %.0f, groups %.1f (%.0f clk)" % (
         buf[4] / nwg, buf[8] / nwg, buf[9] / nwg, ngr / nwg, tot / nwg))

@@ -1099,10 +1099,10 @@ __device__ __forceinline__ double ba_rot_any(double v) {
 }
 
 #ifdef BA_TIMING   /* debug build: shader clocks of the Schur kernel's phases (wavefront 0 of every 16th window's workgroups) */
-__device__ unsigned long long ba_times[16];
+__device__ unsigned long long ba_times[24];
 extern "C" int tb_debug_ba_times(unsigned long long* out, int reset) {
-    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ba_times), sizeof(unsigned long long) * 16) != hipSuccess) return -1;
-    if (reset) { unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(ba_times), z, sizeof z); }
+    if (hipMemcpyFromSymbol(out, HIP_SYMBOL(ba_times), sizeof(unsigned long long) * 24) != hipSuccess) return -1;
+    if (reset) { unsigned long long z[24] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(ba_times), z, sizeof z); }
     return 0;
 }
 #define BA_TK(i) do { const unsigned long long t1_ = __builtin_readcyclecounter(); tk_[i] += t1_ - t0_; t0_ = t1_; } while (0)
@@ -1574,59 +1574,85 @@ __device__ __forceinline__ double ba_rsqrt(double x) {
     r = fma(r, fma(-h * r, r, 0.5), r);
     return r;
 }
+#define BA_SOLVE_T 256 /* threads of k_ba_solve: all of them assemble, one wavefront factorises (its rows + L^T need ~200 registers: no more than four wavefronts) */
 template <int NS> /* padded system size: np rounded up to 16 */
-__global__ void __launch_bounds__(BA_T)
+__global__ void __launch_bounds__(BA_SOLVE_T)
 k_ba_solve(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) {
     __shared__ double A[64 * 65];
-    __shared__ double rhs[64], x[64];
+    __shared__ double x[64];
+    __shared__ double Lcol[2][64];
     const int w = blockIdx.x, tid = threadIdx.x;
+#ifdef BA_TIMING
+    unsigned long long ts_[6]; ts_[0] = __builtin_readcyclecounter();
+#endif
     BaState* st = states + w;
-    if (st->status) return;
     double* D = dw + (size_t)w * d.wstride;
     const int np = d.np, nPart = d.wgReduce ? ba_schur_waves(d, w) / 4 : ba_schur_waves(d, w); /* one partial system per Schur workgroup or per wavefront */
-    const double lambda = st->lambda;
-    /* the lower triangle: every thread owns up to BA_SOLVE_E entries and adds the partial systems in order -- the entries are
-     * the INNER loop, so one trip over the partials keeps BA_SOLVE_E x 4 independent loads in flight (one entry per trip
-     * with the partials inside waited out a memory latency per 16 loads; 80 partials at a batch of 8 windows) */
-    constexpr int BA_SOLVE_E = (NS * (NS + 1) / 2 + BA_T - 1) / BA_T;
+    /* Assembly: S = Hpp + lambda I - sum of the partial systems (lower triangle), rhs = bp - sum of the partial rhs (kept as
+     * row np of A). Every thread owns up to BA_SOLVE_E entries of the two together and adds the partials in order. The kernel
+     * is a chain of memory latencies in front of a one-wavefront factorisation (~2 us each: the partials come from other
+     * XCDs' L2s), so the loads are issued as early and as many at a time as registers allow: addresses first (they do not
+     * depend on the window's state), the first BA_SOLVE_G partials of every entry and its Hpp / bp value in one go -- 12
+     * partials, all a large batch has, are ONE round trip -- and only then the state (status, lambda), which arrives
+     * with them. (Rounds 2-3: state, then 4 partials per trip, then Hpp: eight round trips at 20 partials.) */
+    constexpr int BA_SOLVE_E = (NS * (NS + 1) / 2 + NS + BA_SOLVE_T - 1) / BA_SOLVE_T;
+    constexpr int BA_SOLVE_G = (BA_SOLVE_E <= 5) ? 12 : 6; /* partials in flight per entry: what the registers hold */
     {
-        int er[BA_SOLVE_E], ec[BA_SOLVE_E];
+        const int ne = np * (np + 1) / 2, nall = ne + np;
+        int dst[BA_SOLVE_E];          /* where the entry goes in A */
+        bool diag[BA_SOLVE_E];
         const double* ps[BA_SOLVE_E];
-        double acc[BA_SOLVE_E];
-        const int ne = np * (np + 1) / 2;
+        double acc[BA_SOLVE_E], h[BA_SOLVE_E];
+        double t[BA_SOLVE_G][BA_SOLVE_E];
 #pragma unroll
         for (int k = 0; k < BA_SOLVE_E; k++) {
-            const int e = min(tid + k * BA_T, ne - 1);
-            int r = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
-            while ((r + 1) * (r + 2) / 2 <= e) r++;
-            while (r * (r + 1) / 2 > e) r--;
-            er[k] = r; ec[k] = e - r * (r + 1) / 2;
-            ps[k] = D + d.oPartS + er[k] * 64 + ec[k];
+            const int e = min(tid + k * BA_SOLVE_T, nall - 1);
+            int r, c;
+            const double* hp;
+            if (e < ne) {
+                r = (int)((sqrtf(8.0f * (float)e + 1.0f) - 1.0f) * 0.5f);
+                while ((r + 1) * (r + 2) / 2 <= e) r++;
+                while (r * (r + 1) / 2 > e) r--;
+                c = e - r * (r + 1) / 2;
+                hp = (r / 6 == c / 6) ? D + d.oHpp + (size_t)(r / 6) * 36 + (r % 6) * 6 + (c % 6) : nullptr;
+                dst[k] = r * 65 + c;
+            } else {
+                r = e - ne; c = np;
+                hp = D + d.oBp + r;
+                dst[k] = np * 65 + r;
+            }
+            diag[k] = r == c;
+            ps[k] = D + d.oPartS + r * 64 + c;
             acc[k] = 0;
-        }
-#pragma unroll 4
-        for (int g = 0; g < nPart; g++) {
+            h[k] = hp ? *hp : 0.0;
 #pragma unroll
-            for (int k = 0; k < BA_SOLVE_E; k++) acc[k] += ps[k][(size_t)g * 4096];
+            for (int g = 0; g < BA_SOLVE_G; g++) t[g][k] = ps[k][(size_t)min(g, nPart - 1) * 4096];
+        }
+        if (st->status) return;
+        const double lambda = st->lambda;
+        for (int g0 = 0; g0 < nPart; g0 += BA_SOLVE_G) { /* adds in partial order; further trips only for small batches */
+            if (g0 > 0) {
+#pragma unroll
+                for (int g = 0; g < BA_SOLVE_G; g++)
+#pragma unroll
+                    for (int k = 0; k < BA_SOLVE_E; k++) t[g][k] = ps[k][(size_t)min(g0 + g, nPart - 1) * 4096];
+            }
+#pragma unroll
+            for (int g = 0; g < BA_SOLVE_G; g++)
+#pragma unroll
+                for (int k = 0; k < BA_SOLVE_E; k++) acc[k] += (g0 + g < nPart) ? t[g][k] : 0.0;
         }
 #pragma unroll
         for (int k = 0; k < BA_SOLVE_E; k++) {
-            if (tid + k * BA_T >= ne) continue;
-            const int r = er[k], c = ec[k];
-            double h = 0;
-            if (r / 6 == c / 6) h = D[d.oHpp + (size_t)(r / 6) * 36 + (r % 6) * 6 + (c % 6)];
-            if (r == c) h += lambda;
-            A[r * 65 + c] = h - acc[k];
+            if (tid + k * BA_SOLVE_T >= nall) continue;
+            A[dst[k]] = (diag[k] ? h[k] + lambda : h[k]) - acc[k];
         }
     }
-    for (int r = tid; r < np; r += BA_T) {
-        const double* ps = D + d.oPartS + r * 64 + np;
-        double s = 0;
-#pragma unroll 16
-        for (int g = 0; g < nPart; g++) s += ps[(size_t)g * 4096];
-        rhs[r] = D[d.oBp + r] - s;
-    }
+    const double lambda = st->lambda;
     __syncthreads();
+#ifdef BA_TIMING
+    ts_[1] = __builtin_readcyclecounter();
+#endif
     /* One wave factorises and substitutes with the matrix in REGISTERS: lane i holds row i of the 64 x 64
      * system (rows >= np are identity, so the padded part factors to itself); column j of L is broadcast
      * with compile-time lane indices (v_readlane), so the O(n^3) loop is straight-line FMA code with no
@@ -1638,31 +1664,39 @@ k_ba_solve(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) {
         const int i = tid;
         double row[NS];
 #pragma unroll
-        for (int k = 0; k < NS; k++) row[k] = (i < np && k < np) ? ((k <= i) ? A[i * 65 + k] : 0.0) : ((k == i) ? 1.0 : 0.0);
+        for (int k = 0; k < NS; k++) {
+            /* lane np carries the reduced rhs (row np of A) as one more row below the matrix: the column steps turn it into
+             * y = L^-1 rhs -- the forward substitution costs nothing (it was a chain of 48 broadcast / multiply / subtract
+             * steps). Unconditional reads + selects: conditional ones became two branches per entry. */
+            const double a = A[min(i, np) * 65 + k];
+            row[k] = (i <= np && k < np && k <= i) ? a : ((k == i) ? 1.0 : 0.0);
+        }
         bool good = st->sing == 0;
         double dinv = 1.0; /* 1 / L[i][i] of this lane's row */
 #pragma unroll
         for (int j = 0; j < NS; j++) {
-            const double dj = ba_readlane(row[j], j);
+            /* padding columns (j >= np) are identity -- and lane np, the rhs row, must not be read as a pivot */
+            const double djr = ba_readlane(row[j], j); /* read unconditionally: a conditional cross-lane read becomes a branch */
+            const double dj = (j < np) ? djr : 1.0;
             if (!(dj > 0) || !isfinite(dj)) good = false;
             const double isj = ba_rsqrt(good ? dj : 1.0), sj = (good ? dj : 1.0) * isj;
             if (i == j) dinv = isj;
             row[j] = (i == j) ? sj : row[j] * isj; /* lanes i < j hold unused upper-triangle values */
+            /* column j of L through LDS: one store per lane, then L[k][j] is ONE broadcast read (every lane the same address)
+             * per update, issued beside the multiply-adds -- two v_readlane + wait states per update were 3/4 of this
+             * wavefront's instructions, and it is the only one working */
+            double* Lc = Lcol[j & 1];
+            Lc[i] = row[j];
+            ba_wave_lds_fence();
 #pragma unroll
-            for (int k = j + 1; k < NS; k++) {
-                const double lkj = ba_readlane(row[j], k); /* L[k][j] */
-                row[k] = fma(-row[j], lkj, row[k]);        /* only lanes i >= k are ever read back */
-            }
+            for (int k = j + 1; k < NS; k++) row[k] = fma(-row[j], Lc[k], row[k]); /* only lanes i >= k are ever read back */
+            ba_wave_lds_fence();
         }
-        double xi = (i < np) ? rhs[i] : 0.0;
-#pragma unroll
-        for (int j = 0; j < NS; j++) { /* forward: L y = rhs */
-            const double yj = ba_readlane(xi, j) * ba_readlane(dinv, j);
-            if (i == j) xi = yj;
-            else if (i > j) xi = fma(-row[j], yj, xi);
-        }
-        /* L^T into registers: lane i gets column i of L */
-        if (i < NS) {
+#ifdef BA_TIMING
+        ts_[2] = __builtin_readcyclecounter();
+#endif
+        /* L^T into registers: lane i gets column i of L; lane np's row is y */
+        if (i < NS || i == np) {
 #pragma unroll
             for (int k = 0; k < NS; k++) A[i * 65 + k] = (k <= i) ? row[k] : 0.0;
         }
@@ -1670,12 +1704,20 @@ k_ba_solve(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) {
         double col[NS];
 #pragma unroll
         for (int k = 0; k < NS; k++) col[k] = A[k * 65 + min(i, NS - 1)]; /* L[k][i], zero for k < i */
+        double xi = (i < np) ? A[np * 65 + i] : 0.0, xfin = 0.0;
 #pragma unroll
-        for (int j = NS - 1; j >= 0; j--) { /* backward: L^T x = y; lane i < j subtracts L[j][i] x_j as soon as x_j is known */
-            const double xj = ba_readlane(xi, j) * ba_readlane(dinv, j);
-            if (i == j) xi = xj;
-            else if (i < j) xi = fma(-col[j], xj, xi);
+        for (int j = NS - 1; j >= 0; j--) { /* backward: L^T x = y. Straight-line: every lane scales, lane j's product is x_j,
+                                             * every lane subtracts (col[j] is zero for the lanes above j; lane j's own xi is
+                                             * not read again). The branchy form cost 300 clocks per step. */
+            const double xjr = ba_readlane(xi * dinv, j);
+            const double xj = (j < np) ? xjr : 0.0;
+            xfin = (i == j) ? xj : xfin;
+            xi = fma(-col[j], xj, xi);
         }
+        xi = xfin;
+#ifdef BA_TIMING
+        ts_[3] = __builtin_readcyclecounter();
+#endif
         if (!good) xi = 0;
         double term = 0.0;
         if (i < np) {
@@ -1689,7 +1731,7 @@ k_ba_solve(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) {
     __syncthreads();
     const double* T = D + d.oT + (size_t)st->cur * d.nkf * 7;
     double* Tn = D + d.oT + (size_t)(st->cur ^ 1) * d.nkf * 7;
-    for (int k = tid; k < d.nkf; k += BA_T) {
+    for (int k = tid; k < d.nkf; k += BA_SOLVE_T) {
         const PoSE3 Tk = ba_load_se3(T + k * 7);
         if (k < d.nfixed) ba_store_se3(Tn + k * 7, Tk);
         else {
@@ -1698,6 +1740,13 @@ k_ba_solve(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) {
             ba_store_se3(Tn + k * 7, po_exp_mul(u, Tk));
         }
     }
+#ifdef BA_TIMING
+    if (tid == 0) {
+        ts_[4] = __builtin_readcyclecounter();
+        atomicAdd(&ba_times[11], ts_[1] - ts_[0]); atomicAdd(&ba_times[12], ts_[2] - ts_[1]); atomicAdd(&ba_times[13], ts_[3] - ts_[2]);
+        atomicAdd(&ba_times[14], ts_[4] - ts_[3]); atomicAdd(&ba_times[15], 1ull);
+    }
+#endif
 }
 
 /* ---- large windows (11..64 free keyframes, reduced system up to 384 x 384; SURVEY a17's 50-keyframe case).
@@ -2414,10 +2463,10 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
             hipLaunchKernelGGL(ks, dim3(d.wgReduce ? d.Gbase * W + d.Gextra : (d.Vbase * W + d.Vextra + 3) / 4), dim3(BA_T), schur_lds, s, d, dw, iw, states);
             tb_prof_end(ctx);
             tb_prof_begin(ctx, "k_ba_solve");
-            if (d.np <= 16) hipLaunchKernelGGL(k_ba_solve<16>, dim3(W), dim3(BA_T), 0, s, d, dw, states);
-            else if (d.np <= 32) hipLaunchKernelGGL(k_ba_solve<32>, dim3(W), dim3(BA_T), 0, s, d, dw, states);
-            else if (d.np <= 48) hipLaunchKernelGGL(k_ba_solve<48>, dim3(W), dim3(BA_T), 0, s, d, dw, states);
-            else hipLaunchKernelGGL(k_ba_solve<64>, dim3(W), dim3(BA_T), 0, s, d, dw, states);
+            if (d.np <= 16) hipLaunchKernelGGL(k_ba_solve<16>, dim3(W), dim3(BA_SOLVE_T), 0, s, d, dw, states);
+            else if (d.np <= 32) hipLaunchKernelGGL(k_ba_solve<32>, dim3(W), dim3(BA_SOLVE_T), 0, s, d, dw, states);
+            else if (d.np <= 48) hipLaunchKernelGGL(k_ba_solve<48>, dim3(W), dim3(BA_SOLVE_T), 0, s, d, dw, states);
+            else hipLaunchKernelGGL(k_ba_solve<64>, dim3(W), dim3(BA_SOLVE_T), 0, s, d, dw, states);
             tb_prof_end(ctx);
         }
         tb_prof_begin(ctx, "k_ba_update");
