@@ -398,7 +398,7 @@ int orc_local_ba(const double K[4], int nkf, int nfixed, float* poses, int npt, 
     };
 
     double lambda = 0, ni = 2, chi0 = 0, chi_last = 0;
-    int done = 0;
+    int done = 0, trials = 0; /* trials: LM steps tried, rejected ones included (stats[4]) */
     bool ok = true;
     std::vector<double> Hpp((size_t)np * np), bp(np), Hll(9 * (size_t)npt), bl(3 * (size_t)npt),
         Hpl((size_t)nobs * 18);
@@ -539,6 +539,7 @@ int orc_local_ba(const double K[4], int nkf, int nfixed, float* poses, int npt, 
                 errors(T, P);
             }
             qmax++;
+            trials++;
         } while (rho < 0 && qmax < 10);
         done++;
         chi_last = currentChi;
@@ -557,7 +558,8 @@ int orc_local_ba(const double K[4], int nkf, int nfixed, float* poses, int npt, 
     for (int i = 0; i < 3 * npt; i++) pts[i] = (float)P[i];
     if (stats) {
         stats[0] = done; stats[1] = chi0; stats[2] = chi_last; stats[3] = lambda;
-        stats[4] = stats[5] = stats[6] = stats[7] = 0;
+        stats[4] = trials;
+        stats[5] = stats[6] = stats[7] = 0;
     }
     return done;
 }

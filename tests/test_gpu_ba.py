@@ -150,6 +150,22 @@ def test_local_ba_bench_launch_shape(ctx):
     assert np.array_equal(P[0], P[3]) and np.array_equal(X[1], X[4])      # copies of one window agree bit for bit
 
 
+@pytest.mark.parametrize("seed,nkf,npt,per,pose_noise,pt_noise", [(50, 3, 40, 3, 3.0, 12.0), (53, 5, 100, 3, 2.0, 10.0), (58, 3, 40, 3, 3.0, 12.0),
+                                                                    (53, 3, 40, 3, 3.0, 12.0)])
+def test_local_ba_rejected_steps(ctx, seed, nkf, npt, per, pose_noise, pt_noise):
+    """Starts far from the optimum: the CPU solver rejects one to seven LM steps on the way (stats[4] of the oracle counts the
+    trials). A rejected step keeps the linearisation and changes lambda only: the point records are rebuilt by k_ba_points
+    from the stored blocks -- same trajectory, same number of iterations, same result as the CPU solver."""
+    Pt, Pi, Xt, Xi, obs = synth.ba_problem(seed, nkf, npt, K, obs_per_pt=per, pose_noise=pose_noise, pt_noise=pt_noise)
+    io, Po, Xo, so = oracle.local_ba(K, Pi, 1, Xi, obs, 8)
+    assert so[4] > io, "the case is meant to contain rejected steps"
+    ig, Pg, Xg, sg = ctx.local_ba(K, Pi, 1, Xi, obs, 8)
+    assert ig == io
+    _close(Pg, Po)
+    _close(Xg, Xo)
+    assert np.isclose(sg[2], so[2], rtol=1e-6, atol=1e-9) and np.isclose(sg[1], so[1], rtol=1e-9)
+
+
 def test_local_ba_rejects_bad_input(ctx):
     Pt, Pi, Xt, Xi, obs = synth.ba_problem(1, 4, 30, K)
     bad = obs.copy(); bad["kf"][0] = 99

@@ -391,10 +391,25 @@ k_ba_points(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
         return;
     }
     const BaState st = states[w];
-    if (st.status || !st.need_lin) return;
-    const tb_ba_obs* obs = obsAll + (size_t)w * d.obs_pitch;
+    if (st.status) return;
     double* D = dw + (size_t)w * d.wstride;
     const int* I = iw + (size_t)w * d.istride;
+    if (!st.need_lin) {
+        /* the last step was rejected: same linearisation, new lambda -- only the point records change (what k_ba_hinv does
+         * for the first trial, whose lambda comes from the keyframe pass; a launch of its own per trial cost 5 us, 2.5 % of
+         * a large batch's chain, to find nothing to do on ten trials out of eleven) */
+        const int p = blockIdx.x * BA_T + tid;
+        if (p < d.npt) {
+            double ph[6], pb[3], X[3];
+#pragma unroll
+            for (int i = 0; i < 6; i++) ph[i] = D[d.oHll + (size_t)p * 6 + i];
+#pragma unroll
+            for (int i = 0; i < 3; i++) { pb[i] = D[d.oBl + (size_t)p * 3 + i]; X[i] = D[d.oP + ((size_t)st.cur * d.npt + p) * 3 + i]; }
+            ba_write_rec(D + d.oHq + (size_t)I[d.oPtRank + p] * 12, ph, pb, X, st.lambda, states + w);
+        }
+        return;
+    }
+    const tb_ba_obs* obs = obsAll + (size_t)w * d.obs_pitch;
     const double* T = D + d.oT + (size_t)st.cur * d.nkf * 7;
     const double* P = D + d.oP + (size_t)st.cur * d.npt * 3;
     for (int k = tid; k < d.nkf; k += BA_T) ba_pose_to_Rt(T + k * 7, sRt + k * 12);
@@ -2448,9 +2463,11 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
         tb_prof_begin(ctx, "k_ba_reduce");
         hipLaunchKernelGGL(k_ba_reduce, dim3(W), dim3(BA_T), 0, s, d, dw, iw, states);
         tb_prof_end(ctx);
-        tb_prof_begin(ctx, "k_ba_hinv");
-        hipLaunchKernelGGL(k_ba_hinv, dim3(d.nblkP, W), dim3(BA_T), 0, s, d, dw, iw, states);
-        tb_prof_end(ctx);
+        if (round == 0) { /* the first trial's lambda comes out of k_ba_reduce; later ones are known to k_ba_points */
+            tb_prof_begin(ctx, "k_ba_hinv");
+            hipLaunchKernelGGL(k_ba_hinv, dim3(d.nblkP, W), dim3(BA_T), 0, s, d, dw, iw, states);
+            tb_prof_end(ctx);
+        }
         if (d.big) {
             tb_prof_begin(ctx, "k_ba_schur_pairs");
             hipLaunchKernelGGL(k_ba_schur_pairs, dim3((d.npairs + 3) / 4, W), dim3(BA_T), 0, s, d, dw, iw, states);
