@@ -15,7 +15,7 @@
  *   A point pass    (thread per point)   chi2, Hll, bl; the point's record once lambda is final  -- after an accepted step
  *   B keyframe pass (block per KF chunk) Hpp, bp as fixed-shape tree reductions                  -- "
  *   C reduce        chunk partials -> Hpp, bp, chi2, lambda_0
- *   C2 records      (thread per point)   A = Hll + lambda I = C C^T, U = C^-T (A^-1 = U U^T), U^T bl, X -- when A could not
+ *   C2 records      (thread per point)   A = Hll + lambda I = C C^T, U = C^-T (A^-1 = U U^T), bl, X -- when A could not
  *   D Schur         S' = sum_l Z_l Z_l^T, Z_l = Hpl_l U_l, on the FP64 matrix cores (v_mfma_f64_16x16x4): every
  *                   wavefront densifies its own 4-point chunks into a private LDS tile (lane = edge), both MFMA
  *                   operands come from that tile; reduced rhs = sum_l Z_l (U_l^T bl_l) on the vector ALU
@@ -352,7 +352,7 @@ k_ba_setup(BaDims d, const float* __restrict__ poses, const float* __restrict__ 
  * the back-substitution only through A^-1 = U U^T, U = C^-T upper triangular from the Cholesky factor A = C C^T:
  *   S' = sum_l (Hpl U)(Hpl U)^T,   reduced rhs = sum_l (Hpl U)(U^T bl),   xl = U (U^T r)
  * so the Schur kernel densifies ONE matrix Z = Hpl U instead of Hpl and Hpl A^-1. Layout: u00 u01 u02 u11 u12 u22,
- * U^T bl (3), the point X at the linearisation state (3). A block that is not positive definite gives zeros and
+ * bl (3; the Schur kernels form U^T bl from it, the back-substitution reads it), the point X at the linearisation state (3). A block that is not positive definite gives zeros and
  * flags the trial (st->sing), like the failed inverse of the CPU solver. */
 __device__ __forceinline__ void ba_write_rec(double* q, const double* Hll, const double* bl, const double* X, double lambda,
                                              BaState* st) {
@@ -370,10 +370,14 @@ __device__ __forceinline__ void ba_write_rec(double* q, const double* Hll, const
                  u02 = -(c20 * i00 + c21 * u01) * i22;
     q[0] = ok ? u00 : 0.0; q[1] = ok ? u01 : 0.0; q[2] = ok ? u02 : 0.0;
     q[3] = ok ? u11 : 0.0; q[4] = ok ? u12 : 0.0; q[5] = ok ? u22 : 0.0;
-    q[6] = ok ? u00 * bl[0] : 0.0;
-    q[7] = ok ? u01 * bl[0] + u11 * bl[1] : 0.0;
-    q[8] = ok ? u02 * bl[0] + u12 * bl[1] + u22 * bl[2] : 0.0;
+    q[6] = bl[0]; q[7] = bl[1]; q[8] = bl[2]; /* the gradient itself: the back-substitution needs it, the Schur kernels form U^T bl (ba_rec_utb) */
     q[9] = X[0]; q[10] = X[1]; q[11] = X[2];
+}
+/* U^T bl of a point record (zero for a block that was not positive definite: U is zero then) */
+__device__ __forceinline__ void ba_rec_utb(const double* q, double* t) {
+    t[0] = q[0] * q[6];
+    t[1] = q[1] * q[6] + q[3] * q[7];
+    t[2] = q[2] * q[6] + q[4] * q[7] + q[5] * q[8];
 }
 
 /* ---- A: point pass */
@@ -394,21 +398,11 @@ k_ba_points(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
     if (st.status) return;
     double* D = dw + (size_t)w * d.wstride;
     const int* I = iw + (size_t)w * d.istride;
-    if (!st.need_lin) {
-        /* the last step was rejected: same linearisation, new lambda -- only the point records change (what k_ba_hinv does
-         * for the first trial, whose lambda comes from the keyframe pass; a launch of its own per trial cost 5 us, 2.5 % of
-         * a large batch's chain, to find nothing to do on ten trials out of eleven) */
-        const int p = blockIdx.x * BA_T + tid;
-        if (p < d.npt) {
-            double ph[6], pb[3], X[3];
-#pragma unroll
-            for (int i = 0; i < 6; i++) ph[i] = D[d.oHll + (size_t)p * 6 + i];
-#pragma unroll
-            for (int i = 0; i < 3; i++) { pb[i] = D[d.oBl + (size_t)p * 3 + i]; X[i] = D[d.oP + ((size_t)st.cur * d.npt + p) * 3 + i]; }
-            ba_write_rec(D + d.oHq + (size_t)I[d.oPtRank + p] * 12, ph, pb, X, st.lambda, states + w);
-        }
-        return;
-    }
+    /* lambda of this trial is final unless it is the first one (k_ba_reduce derives it from the keyframe pass; k_ba_hinv then
+     * writes the point records from the stored blocks). After a rejected step (need_lin == 0: same state, new lambda) the pass
+     * simply runs again -- the same blocks, records for the new lambda -- so the blocks themselves are only stored in the
+     * first trial: 72 of the pass's 282 bytes per point on every later one (the record carries the gradient). */
+    const bool lam_known = st.iter > 0 || !st.need_lin;
     const tb_ba_obs* obs = obsAll + (size_t)w * d.obs_pitch;
     const double* T = D + d.oT + (size_t)st.cur * d.nkf * 7;
     const double* P = D + d.oP + (size_t)st.cur * d.npt * 3;
@@ -438,9 +432,10 @@ k_ba_points(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
             Hll[4] = fma(ww, fma(Jl[1], Jl[2], Jl[4] * Jl[5]), Hll[4]);
             Hll[5] = fma(ww, fma(Jl[2], Jl[2], Jl[5] * Jl[5]), Hll[5]);
         }
-        for (int a = 0; a < 6; a++) D[d.oHll + (size_t)p * 6 + a] = Hll[a];
-        for (int a = 0; a < 3; a++) D[d.oBl + (size_t)p * 3 + a] = bl[a];
-        if (st.iter > 0) ba_write_rec(D + d.oHq + (size_t)I[d.oPtRank + p] * 12, Hll, bl, X, st.lambda, states + w); /* lambda of this trial is final; records sit in pattern order */
+        if (!lam_known) {
+            for (int a = 0; a < 6; a++) D[d.oHll + (size_t)p * 6 + a] = Hll[a];
+            for (int a = 0; a < 3; a++) D[d.oBl + (size_t)p * 3 + a] = bl[a];
+        } else ba_write_rec(D + d.oHq + (size_t)I[d.oPtRank + p] * 12, Hll, bl, X, st.lambda, states + w); /* lambda of this trial is final; records sit in pattern order */
         maxd = fmax(fabs(Hll[0]), fmax(fabs(Hll[3]), fabs(Hll[5])));
     }
     const double s = ba_block_sum1(chi, red);
@@ -1459,7 +1454,7 @@ k_ba_schur_c(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, BaSt
             }
             if (slot == 0) { /* the rhs row: U^T bl of the point under its three columns */
                 double* zr = Zt + (6 * k) * ld + 3 * pl;
-                zr[0] = q[6]; zr[1] = q[7]; zr[2] = q[8];
+                ba_rec_utb(q, zr);
             }
         }
         const int ncol = 3 * npts, nks = (ncol + 3) >> 2;
@@ -1836,7 +1831,7 @@ k_ba_pair_scan(BaDims d, int* __restrict__ iw, const int* __restrict__ errflag) 
 }
 
 /* Z = Hpl U = (ww Jp)^T (Jl U) (6 x 3, row-major) of one free-keyframe edge from its 16-byte record and its point's
- * record q = [U (6), U^T bl (3), X (3)]; the same arithmetic as the tile fill of k_ba_schur */
+ * record q = [U (6), bl (3), X (3)]; the same arithmetic as the tile fill of k_ba_schur */
 __device__ __forceinline__ void ba_edge_z(const double* __restrict__ sRtf, const int4 r, const double* __restrict__ q,
                                           double fx, double fy, double cx, double cy, double delta, double* __restrict__ z) {
     const double u00 = q[0], u01 = q[1], u02 = q[2], u11 = q[3], u12 = q[4], u22 = q[5];
@@ -1926,8 +1921,10 @@ k_ba_schur_pairs(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, 
             if (a == b) {
 #pragma unroll
                 for (int k = 0; k < 18; k++) zb[k] = za[k];
+                double ub[3];
+                ba_rec_utb(q, ub);
 #pragma unroll
-                for (int k = 0; k < 6; k++) rh[k] += za[3 * k] * q[6] + za[3 * k + 1] * q[7] + za[3 * k + 2] * q[8];
+                for (int k = 0; k < 6; k++) rh[k] += za[3 * k] * ub[0] + za[3 * k + 1] * ub[1] + za[3 * k + 2] * ub[2];
             } else ba_edge_z(sRtf, rb0, q, d.fx, d.fy, d.cx, d.cy, delta, zb);
 #pragma unroll
             for (int i = 0; i < 6; i++)
@@ -2170,13 +2167,13 @@ k_ba_update(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
     const int p = blockIdx.x * BA_T + tid;
     double chi = 0, sc = 0;
     if (p < d.npt) {
-        double r[3] = {D[d.oBl + (size_t)p * 3], D[d.oBl + (size_t)p * 3 + 1], D[d.oBl + (size_t)p * 3 + 2]};
+        /* the point record of this trial: A^-1 = U U^T (all zero for a singular block: xl stays 0), the gradient bl, X */
+        const double* q = D + d.oHq + (size_t)I[d.oPtRank + p] * 12;
+        double r[3] = {q[6], q[7], q[8]};
         const double bl[3] = {r[0], r[1], r[2]};
         double xl[3] = {0, 0, 0};
         const int eBeg = I[d.oPtStart + p], eEnd = I[d.oPtStart + p + 1];
         if (st.ok2) {
-            /* the point record of this trial: A^-1 = U U^T (all zero for a singular block: xl stays 0) */
-            const double* q = D + d.oHq + (size_t)I[d.oPtRank + p] * 12;
             const double u00 = q[0], u01 = q[1], u02 = q[2], u11 = q[3], u12 = q[4], u22 = q[5];
             /* r = bl - sum_k Hpl_k^T x_k with Hpl_k = ww Jp^T Jl rebuilt from the observation (a 144-byte block per edge
              * would cost more to fetch than its ~150 flops): Hpl^T x = ww Jl^T (Jp x) */
