@@ -124,7 +124,8 @@ def pmc_traffic(kernel, units, geometry=None, detail=False):
                 doc = json.load(f)
             rec = doc["kernels"]
             key = kernel
-            for alias in (kernel, {"k_resize": "k_resize_lds", "k_fast_cells": "k_fast_blocks", "k_ba_schur": "k_ba_schur_g"}.get(kernel)):
+            aliases = {"k_resize": ("k_resize_lds",), "k_fast_cells": ("k_fast_blocks",), "k_ba_schur": ("k_ba_schur_g", "k_ba_schur_c")}
+            for alias in (kernel,) + aliases.get(kernel, ()):
                 if alias in rec:     # the profile carries the kernel's function name, tb_profile_* its stage name
                     key = alias
             if key not in rec:
