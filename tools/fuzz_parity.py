@@ -77,7 +77,7 @@ def main():
                 np.array_equal(fg[2].view(np.uint32), fo[2].view(np.uint32))):
             fail("optical_flow_pyr_lk", w=w, h=h, npt=npt, ml=ml, status=(int(fg[1].sum()), int(fo[1].sum())))
         # RANSAC fundamental matrix (rejectWithF), stereo-like point sets with a random share of gross outliers
-        nr_ = int(rng.integers(15, 2500))
+        nr_ = int(rng.integers(7, 22)) if rng.integers(0, 5) == 0 else int(rng.integers(15, 2500))   # 8..14: the LMedS branch
         px = rng.uniform(10, w + 300, nr_); py = rng.uniform(10, h + 100, nr_)
         p1 = np.stack([px, py], 1).astype(np.float32)
         p2 = np.stack([px - 386.0 / rng.uniform(4, 60, nr_), py], 1) + rng.normal(0, float(rng.uniform(0, 0.6)), (nr_, 2))
@@ -116,6 +116,20 @@ def main():
                       has_mp2=(rng.uniform(size=len(k2)) < 0.7).astype(np.uint8))
             if not same_rec(ctx.search_by_bow(k1, d1, fv1, k2, d2, fv2, **bw), oracle.search_by_bow(k1, d1, fv1, k2, d2, fv2, **bw)):
                 fail("search_by_bow", n1=len(k1), n2=len(k2), mod=mod)
+        # Frame::SetBow's transform on seeded vocabularies (regular and ragged trees), the extracted descriptors + near-word ones
+        if it % 3 == 1 and len(d1):
+            kv, Lv = int(rng.integers(2, 11)), int(rng.integers(1, 6))
+            voc = synth.vocabulary(int(rng.integers(0, 10 ** 6)), kv, Lv, ragged=float(rng.choice([0.0, 0.0, 0.2, 0.4])))
+            dd = np.concatenate([d1[: int(rng.integers(1, len(d1) + 1))], synth.descriptors_near_words(int(rng.integers(0, 10 ** 6)), voc, int(rng.integers(1, 300)))])
+            lu = int(rng.integers(0, Lv + 2))
+            hv = ctx.vocab_create(voc)
+            try:
+                gw = ctx.bow_transform(hv, dd, lu)
+            finally:
+                ctx.vocab_destroy(hv)
+            ow = oracle.bow_transform(voc, dd, lu)
+            if not (np.array_equal(gw[0], ow[0]) and np.array_equal(gw[1].view(np.uint64), np.asarray(ow[1], np.float64).view(np.uint64)) and np.array_equal(gw[2], ow[2])):
+                fail("bow_transform", k=kv, L=Lv, levelsup=lu, n=len(dd))
         # FAST cell loop on dense images (the block kernel's list-free path): noise, low thresholds
         if it % 4 == 0:
             nw, nh = int(rng.integers(70, 400)), int(rng.integers(70, 300))
@@ -152,7 +166,9 @@ def main():
         nfx = min(nfx, nkf - 1)
         if nkf - nfx <= 64:
             npt, per = int(rng.integers(20, 1500)), int(rng.integers(2, min(nkf, 14) + 1))
-            Pt, Pi, Xt, Xi, bo = synth.ba_problem(int(rng.integers(0, 10 ** 6)), nkf, npt, K, obs_per_pt=per)
+            far = rng.integers(0, 4) == 0   # a start far from the optimum: the LM loop rejects steps on the way
+            Pt, Pi, Xt, Xi, bo = synth.ba_problem(int(rng.integers(0, 10 ** 6)), nkf, npt, K, obs_per_pt=per,
+                                                  **(dict(pose_noise=float(rng.uniform(0.5, 3.0)), pt_noise=float(rng.uniform(2.0, 12.0))) if far else {}))
             itn = int(rng.integers(1, 8))
             ig, Pg, Xg, sg = ctx.local_ba(K, Pi, nfx, Xi, bo, itn)
             io, Po, Xo, so = oracle.local_ba(K, Pi, nfx, Xi, bo, itn)
