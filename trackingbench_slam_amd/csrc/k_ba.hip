@@ -33,8 +33,12 @@
 #include "tb_se3.h"
 
 #define BA_T 256
-#define BA_KFCH 1024          /* edges per keyframe-pass chunk */
+#ifndef BA_KFCH
+#define BA_KFCH 512           /* edges per keyframe-pass chunk: two per thread (four: 134 VGPRs, three wavefronts per SIMD, 0.48 against 0.44 ms per 171-window call; one: 0.67) */
+#endif
+#ifndef BA_KFBLK
 #define BA_KFBLK 4            /* workgroups per keyframe in the keyframe pass */
+#endif
 #define BA_BIG_MAXF 64        /* free keyframes of a large window (6 bits of the free-edge key) */
 #define BA_SMALL_MAXF 10      /* free keyframes of a window on the MFMA path (visibility patterns are 10-bit masks) */
 #define BA_SORT_LDS 8192      /* points of a window whose pattern sort runs in LDS (k_ba_groups) */
@@ -1694,7 +1698,9 @@ k_ba_solve(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) {
             row[j] = (i == j) ? sj : row[j] * isj; /* lanes i < j hold unused upper-triangle values */
             /* column j of L through LDS: one store per lane, then L[k][j] is ONE broadcast read (every lane the same address)
              * per update, issued beside the multiply-adds -- two v_readlane + wait states per update were 3/4 of this
-             * wavefront's instructions, and it is the only one working */
+             * wavefront's instructions, and it is the only one working. (Forming the next pivot's reciprocal square root one
+             * column ahead in the source changes nothing: the compiler already interleaves the columns, and a lone wavefront
+             * issues one instruction per 4-5 clocks whatever its kind.) */
             double* Lc = Lcol[j & 1];
             Lc[i] = row[j];
             ba_wave_lds_fence();
