@@ -2523,10 +2523,7 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
             static std::mutex capture_lock;
             std::lock_guard<std::mutex> guard(capture_lock);
             hipGraph_t graph = nullptr;
-#ifndef BA_CAPTURE_MODE
-#define BA_CAPTURE_MODE hipStreamCaptureModeThreadLocal
-#endif
-            TB_HIP(ctx, hipStreamBeginCapture(s, BA_CAPTURE_MODE));
+            TB_HIP(ctx, hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
             rc = enqueue_head();
             for (int r = 0; r < nfirst && rc == TB_OK; r++) rc = enqueue_round(r);
             const hipError_t e = hipStreamEndCapture(s, &graph); /* always ends the capture, also after a failed launch */
@@ -2543,16 +2540,6 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
         }
         TB_HIP(ctx, hipGraphLaunch(exec, s));
         rounds = nfirst;
-#ifdef BA_GRAPH_DEBUG
-        {
-            int ef[4] = {-7, -7, -7, -7}, rn[2] = {-7, -7};
-            hipMemcpyAsync(ef, errflag, sizeof(int) * std::min(W, 4), hipMemcpyDeviceToHost, s);
-            hipMemcpyAsync(rn, running, sizeof rn, hipMemcpyDeviceToHost, s);
-            hipStreamSynchronize(s);
-            fprintf(stderr, "[ba graph] ctx %p exec %p cache %zu W %d errflag %d %d %d %d running %d %d work %p\n", (void*)ctx, (void*)exec,
-                    ctx->ba_graphs.size(), W, ef[0], ef[1], ef[2], ef[3], rn[0], rn[1], d_work);
-        }
-#endif
     } else if ((rc = enqueue_head()) != TB_OK) return rc;
     bool replayed = use_graph; /* the first batch of trials is already queued */
     while (host_running > 0 && (rounds < max_rounds || replayed)) {
