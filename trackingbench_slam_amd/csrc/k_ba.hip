@@ -835,13 +835,16 @@ k_ba_prepare(BaDims d, const tb_ba_obs* __restrict__ obsAll, const int32_t* __re
     {
         const int q = (((total + NW - 1) / NW) + 63) & ~63, lo = min(wave * q, total), hi = min(lo + q, total);
         int cnt = 0; /* lane k: edges of keyframe k in this range */
-        for (int e0 = lo; e0 < hi; e0 += 64) {
-            const int e = e0 + lane;
-            const int kf = (e < hi) ? obs2[e].kf : -1;
-            for (int k = 0; k < d.nkf; k++) {
-                const unsigned long long m = __ballot(kf == k);
-                if (lane == k) cnt += __popcll(m);
-            }
+        for (int e0 = lo; e0 < hi; e0 += 256) { /* four slabs' loads in flight (one at a time: a cache round trip per slab) */
+            int kf4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) { const int e = e0 + 64 * u + lane; kf4[u] = (e < hi) ? obs2[e].kf : -1; }
+#pragma unroll
+            for (int u = 0; u < 4; u++)
+                for (int k = 0; k < d.nkf; k++) {
+                    const unsigned long long m = __ballot(kf4[u] == k);
+                    if (lane == k) cnt += __popcll(m);
+                }
         }
         if (lane < d.nkf) kfc[wave][lane] = cnt;
         __syncthreads();
@@ -861,26 +864,34 @@ k_ba_prepare(BaDims d, const tb_ba_obs* __restrict__ obsAll, const int32_t* __re
         }
         __syncthreads();
         int4* KR = reinterpret_cast<int4*>(I + d.oKfRec);
-        for (int e0 = lo; e0 < hi; e0 += 64) {
-            const int e = e0 + lane;
-            tb_ba_obs o;
-            o.kf = -1; o.pt = 0; o.u = o.v = o.inv_sigma2 = 0.f;
-            if (e < hi) o = obs2[e];
-            unsigned long long mine = 0;
-            int add = 0;
-            for (int k = 0; k < d.nkf; k++) {
-                const unsigned long long m = __ballot(o.kf == k);
-                if (o.kf == k) mine = m;
-                if (lane == k) add = __popcll(m);
+        for (int e00 = lo; e00 < hi; e00 += 256) {
+            tb_ba_obs o4[4];
+#pragma unroll
+            for (int u = 0; u < 4; u++) {
+                const int e = e00 + 64 * u + lane;
+                o4[u].kf = -1; o4[u].pt = 0; o4[u].u = o4[u].v = o4[u].inv_sigma2 = 0.f;
+                if (e < hi) o4[u] = obs2[e];
             }
-            if (o.kf >= 0 && o.kf < d.nkf) {
-                const int pos = kfc[wave][o.kf] + __popcll(mine & lt);
-                I[d.oKfEdges + pos] = e;
-                KR[pos] = make_int4(o.pt, __float_as_int(o.u), __float_as_int(o.v), __float_as_int(o.inv_sigma2));
+#pragma unroll
+            for (int u = 0; u < 4; u++) { /* slab by slab: the list positions follow the edge order */
+                const int e = e00 + 64 * u + lane;
+                const tb_ba_obs o = o4[u];
+                unsigned long long mine = 0;
+                int add = 0;
+                for (int k = 0; k < d.nkf; k++) {
+                    const unsigned long long m = __ballot(o.kf == k);
+                    if (o.kf == k) mine = m;
+                    if (lane == k) add = __popcll(m);
+                }
+                if (o.kf >= 0 && o.kf < d.nkf) {
+                    const int pos = kfc[wave][o.kf] + __popcll(mine & lt);
+                    I[d.oKfEdges + pos] = e;
+                    KR[pos] = make_int4(o.pt, __float_as_int(o.u), __float_as_int(o.v), __float_as_int(o.inv_sigma2));
+                }
+                ba_wave_lds_fence();
+                if (lane < d.nkf) kfc[wave][lane] += add;
+                ba_wave_lds_fence();
             }
-            ba_wave_lds_fence();
-            if (lane < d.nkf) kfc[wave][lane] += add;
-            ba_wave_lds_fence();
         }
     }
     /* ---- the Schur kernel's edge records: a point's free-keyframe edges by ascending keyframe, points in rank order */
