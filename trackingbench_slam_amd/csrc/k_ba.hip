@@ -494,7 +494,14 @@ __global__ void __launch_bounds__(BA_T)
 k_ba_kf(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw, const int* __restrict__ iw,
         const BaState* __restrict__ states) {
     __shared__ double red[BA_KFR_LDS];
-    const int w = blockIdx.z, kf = d.nfixed + blockIdx.y, tid = threadIdx.x;
+    /* 1-D grid, a window per XCD at a time: workgroup ids go round-robin over the eight XCDs, so ids r, r + 8, r + 16, ... of a
+     * run of 8 x (workgroups per window) ids serve ONE window -- all keyframes of a window gather from the same point array
+     * (each touches most of its cache lines), which then comes from HBM once, into one L2, instead of once per keyframe */
+    const int tid = threadIdx.x, nx = min(BA_KFBLK, d.kfChunks), per = nx * d.nfree;
+    const int run = blockIdx.x / (8 * per), rr_ = blockIdx.x - run * (8 * per);
+    const int w = run * 8 + (rr_ & 7), slot = rr_ >> 3;
+    if (w >= d.W) return;
+    const int chunk0 = slot % nx, kfree = slot / nx, kf = d.nfixed + kfree;
     const BaState st = states[w];
     if (st.status || !st.need_lin) return;
     double* D = dw + (size_t)w * d.wstride;
@@ -505,7 +512,7 @@ k_ba_kf(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw,
     const double* P = D + d.oP + (size_t)st.cur * d.npt * 3;
     const double delta = (double)sqrtf(5.991f);
     /* BA_KFBLK blocks per keyframe walk its chunks; k_ba_reduce sums the occupied chunks in order */
-    for (int chunk = blockIdx.x; chunk * BA_KFCH < end - beg; chunk += BA_KFBLK) {
+    for (int chunk = chunk0; chunk * BA_KFCH < end - beg; chunk += BA_KFBLK) {
         double acc[27];
 #pragma unroll
         for (int i = 0; i < 27; i++) acc[i] = 0;
@@ -550,7 +557,7 @@ k_ba_kf(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw,
             }
         }
         const double tot = ba_block_sum27(acc, red);
-        if (tid < 27) D[d.oPartKF + ((size_t)blockIdx.y * d.kfChunks + chunk) * 27 + tid] = tot;
+        if (tid < 27) D[d.oPartKF + ((size_t)kfree * d.kfChunks + chunk) * 27 + tid] = tot;
     }
 }
 
@@ -2472,7 +2479,7 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
         hipLaunchKernelGGL(k_ba_points, dim3(d.nblkP, W), dim3(BA_T), (size_t)d.nkf * 12 * sizeof(double), s, d, d_obs, dw, iw, states, errflag);
         tb_prof_end(ctx);
         tb_prof_begin(ctx, "k_ba_kf");
-        hipLaunchKernelGGL(k_ba_kf, dim3(std::min(BA_KFBLK, d.kfChunks), d.nfree, W), dim3(BA_T), 0, s, d, d_obs, dw, iw, states);
+        hipLaunchKernelGGL(k_ba_kf, dim3(((W + 7) / 8) * 8 * std::min(BA_KFBLK, d.kfChunks) * d.nfree), dim3(BA_T), 0, s, d, d_obs, dw, iw, states);
         tb_prof_end(ctx);
         tb_prof_begin(ctx, "k_ba_reduce");
         hipLaunchKernelGGL(k_ba_reduce, dim3(W), dim3(BA_T), 0, s, d, dw, iw, states);
