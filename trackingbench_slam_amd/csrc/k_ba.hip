@@ -562,12 +562,14 @@ k_ba_kf(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw,
 }
 
 /* ---- C: ordered reduction of the partials, lambda_0 */
-__global__ void __launch_bounds__(BA_T)
-k_ba_reduce(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, BaState* __restrict__ states) {
-    __shared__ double red[4];
-    const int w = blockIdx.x, tid = threadIdx.x;
+/* per-keyframe Hpp / bp from the chunk partials in order, chi2 of the linearisation state and the first lambda: a launch of its
+ * own in the first trial (k_ba_hinv needs that lambda before the Schur kernel runs) and for large windows, the prologue of
+ * k_ba_solve -- one workgroup per window as well -- in every later trial (a launch less per trial: 5 us, the critical path of a
+ * small batch) */
+__device__ __forceinline__ void ba_reduce_body(const BaDims& d, double* __restrict__ dw, const int* __restrict__ iw, BaState* __restrict__ states,
+                                               int w, double* red) {
+    const int tid = threadIdx.x;
     BaState* st = states + w;
-    if (st->status || !st->need_lin) return;
     double* D = dw + (size_t)w * d.wstride;
     const int* I = iw + (size_t)w * d.istride;
     double maxd = 0;
@@ -597,6 +599,14 @@ k_ba_reduce(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, BaSta
         st->hq_fresh = st->iter > 0 ? 1 : 0; /* the point pass ran with this trial's final lambda */
         st->need_lin = 0;
     }
+}
+
+__global__ void __launch_bounds__(BA_T)
+k_ba_reduce(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, BaState* __restrict__ states) {
+    __shared__ double red[4];
+    const int w = blockIdx.x;
+    if (states[w].status || !states[w].need_lin) return;
+    ba_reduce_body(d, dw, iw, states, w, red);
 }
 
 /* ---- C2: damped point-block inverses for this trial's lambda, one thread per point: the 6 unique entries of
@@ -1609,7 +1619,7 @@ __device__ __forceinline__ double ba_rsqrt(double x) {
 #define BA_SOLVE_T 256 /* threads of k_ba_solve: all of them assemble, one wavefront factorises (its rows + L^T need ~200 registers: no more than four wavefronts) */
 template <int NS> /* padded system size: np rounded up to 16 */
 __global__ void __launch_bounds__(BA_SOLVE_T)
-k_ba_solve(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) {
+k_ba_solve(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, BaState* __restrict__ states, int with_reduce) {
     __shared__ double A[64 * 65];
     __shared__ double x[64];
     __shared__ double Lcol[2][64];
@@ -1618,6 +1628,13 @@ k_ba_solve(BaDims d, double* __restrict__ dw, BaState* __restrict__ states) {
     unsigned long long ts_[6]; ts_[0] = __builtin_readcyclecounter();
 #endif
     BaState* st = states + w;
+    if (with_reduce) { /* the keyframe pass's partials -> Hpp, bp, chi2 (trials after the first: see ba_reduce_body) */
+        __shared__ double redf[4];
+        if (st->status) return;
+        if (st->need_lin) ba_reduce_body(d, dw, iw, states, w, redf);
+        __threadfence_block();
+        __syncthreads();
+    }
     double* D = dw + (size_t)w * d.wstride;
     const int np = d.np, nPart = d.wgReduce ? ba_schur_waves(d, w) / 4 : ba_schur_waves(d, w); /* one partial system per Schur workgroup or per wavefront */
     /* Assembly: S = Hpp + lambda I - sum of the partial systems (lower triangle), rhs = bp - sum of the partial rhs (kept as
@@ -2481,9 +2498,12 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
         tb_prof_begin(ctx, "k_ba_kf");
         hipLaunchKernelGGL(k_ba_kf, dim3(((W + 7) / 8) * 8 * std::min(BA_KFBLK, d.kfChunks) * d.nfree), dim3(BA_T), 0, s, d, d_obs, dw, iw, states);
         tb_prof_end(ctx);
-        tb_prof_begin(ctx, "k_ba_reduce");
-        hipLaunchKernelGGL(k_ba_reduce, dim3(W), dim3(BA_T), 0, s, d, dw, iw, states);
-        tb_prof_end(ctx);
+        const bool reduce_in_solve = !d.big && round > 0;
+        if (!reduce_in_solve) {
+            tb_prof_begin(ctx, "k_ba_reduce");
+            hipLaunchKernelGGL(k_ba_reduce, dim3(W), dim3(BA_T), 0, s, d, dw, iw, states);
+            tb_prof_end(ctx);
+        }
         if (round == 0) { /* the first trial's lambda comes out of k_ba_reduce; later ones are known to k_ba_points */
             tb_prof_begin(ctx, "k_ba_hinv");
             hipLaunchKernelGGL(k_ba_hinv, dim3(d.nblkP, W), dim3(BA_T), 0, s, d, dw, iw, states);
@@ -2501,10 +2521,10 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
             hipLaunchKernelGGL(ks, dim3(d.wgReduce ? d.Gbase * W + d.Gextra : (d.Vbase * W + d.Vextra + 3) / 4), dim3(BA_T), schur_lds, s, d, dw, iw, states);
             tb_prof_end(ctx);
             tb_prof_begin(ctx, "k_ba_solve");
-            if (d.np <= 16) hipLaunchKernelGGL(k_ba_solve<16>, dim3(W), dim3(BA_SOLVE_T), 0, s, d, dw, states);
-            else if (d.np <= 32) hipLaunchKernelGGL(k_ba_solve<32>, dim3(W), dim3(BA_SOLVE_T), 0, s, d, dw, states);
-            else if (d.np <= 48) hipLaunchKernelGGL(k_ba_solve<48>, dim3(W), dim3(BA_SOLVE_T), 0, s, d, dw, states);
-            else hipLaunchKernelGGL(k_ba_solve<64>, dim3(W), dim3(BA_SOLVE_T), 0, s, d, dw, states);
+            if (d.np <= 16) hipLaunchKernelGGL(k_ba_solve<16>, dim3(W), dim3(BA_SOLVE_T), 0, s, d, dw, iw, states, reduce_in_solve ? 1 : 0);
+            else if (d.np <= 32) hipLaunchKernelGGL(k_ba_solve<32>, dim3(W), dim3(BA_SOLVE_T), 0, s, d, dw, iw, states, reduce_in_solve ? 1 : 0);
+            else if (d.np <= 48) hipLaunchKernelGGL(k_ba_solve<48>, dim3(W), dim3(BA_SOLVE_T), 0, s, d, dw, iw, states, reduce_in_solve ? 1 : 0);
+            else hipLaunchKernelGGL(k_ba_solve<64>, dim3(W), dim3(BA_SOLVE_T), 0, s, d, dw, iw, states, reduce_in_solve ? 1 : 0);
             tb_prof_end(ctx);
         }
         tb_prof_begin(ctx, "k_ba_update");
