@@ -385,17 +385,16 @@ __device__ __forceinline__ void ba_rec_utb(const double* q, double* t) {
 }
 
 /* ---- A: point pass */
-__global__ void __launch_bounds__(BA_T)
-k_ba_points(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw, const int* __restrict__ iw,
-            BaState* __restrict__ states, const int* __restrict__ errflag) {
+__device__ __forceinline__ void ba_points_pass(const BaDims& d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw, const int* __restrict__ iw,
+                                               BaState* __restrict__ states, const int* __restrict__ errflag, int bx, int w) {
     __shared__ double red[4];
     /* keyframe poses as R | t, 12 doubles each: DYNAMIC shared memory sized by the window (960 bytes at 10 keyframes, where a static
      * array for the largest window took 6 KB): the pass is bound by HBM latency and bandwidth, its wavefronts are meant to sit on
      * CUs beside the extractor's workgroups, which leave ~10 KB of LDS free */
     extern __shared__ __attribute__((aligned(16))) double sRt[];
-    const int w = blockIdx.y, tid = threadIdx.x;
+    const int tid = threadIdx.x;
     if (errflag[w]) { /* k_ba_setup rejected the window's observations: nothing may index with them */
-        if (blockIdx.x == 0 && tid == 0) { states[w].status = 1; states[w].err = 1; }
+        if (bx == 0 && tid == 0) { states[w].status = 1; states[w].err = 1; }
         return;
     }
     const BaState st = states[w];
@@ -413,7 +412,7 @@ k_ba_points(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
     for (int k = tid; k < d.nkf; k += BA_T) ba_pose_to_Rt(T + k * 7, sRt + k * 12);
     __syncthreads();
     const double delta = (double)sqrtf(5.991f);
-    const int p = blockIdx.x * BA_T + tid;
+    const int p = bx * BA_T + tid;
     double chi = 0, maxd = 0;
     if (p < d.npt) {
         double Hll[6] = {0, 0, 0, 0, 0, 0}, bl[3] = {0, 0, 0};
@@ -445,8 +444,8 @@ k_ba_points(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__
     const double s = ba_block_sum1(chi, red);
     const double m = ba_block_max1(maxd, red);
     if (tid == 0) {
-        D[d.oPartP + (size_t)blockIdx.x * 4] = s;
-        D[d.oPartP + (size_t)blockIdx.x * 4 + 1] = m;
+        D[d.oPartP + (size_t)bx * 4] = s;
+        D[d.oPartP + (size_t)bx * 4 + 1] = m;
     }
 }
 
@@ -490,17 +489,17 @@ __device__ __forceinline__ double ba_block_sum27(const double (&v)[27], double* 
     return r;
 }
 
-__global__ void __launch_bounds__(BA_T)
-k_ba_kf(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw, const int* __restrict__ iw,
-        const BaState* __restrict__ states) {
+__device__ __forceinline__ void ba_kf_pass(const BaDims& d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw, const int* __restrict__ iw,
+                                           const BaState* __restrict__ states, const int* __restrict__ errflag, int bid) {
     __shared__ double red[BA_KFR_LDS];
     /* 1-D grid, a window per XCD at a time: workgroup ids go round-robin over the eight XCDs, so ids r, r + 8, r + 16, ... of a
      * run of 8 x (workgroups per window) ids serve ONE window -- all keyframes of a window gather from the same point array
      * (each touches most of its cache lines), which then comes from HBM once, into one L2, instead of once per keyframe */
     const int tid = threadIdx.x, nx = min(BA_KFBLK, d.kfChunks), per = nx * d.nfree;
-    const int run = blockIdx.x / (8 * per), rr_ = blockIdx.x - run * (8 * per);
+    const int run = bid / (8 * per), rr_ = bid - run * (8 * per);
     const int w = run * 8 + (rr_ & 7), slot = rr_ >> 3;
     if (w >= d.W) return;
+    if (errflag[w]) return; /* rejected input: the point pass flags the window, but runs BESIDE this pass now */
     const int chunk0 = slot % nx, kfree = slot / nx, kf = d.nfixed + kfree;
     const BaState st = states[w];
     if (st.status || !st.need_lin) return;
@@ -562,6 +561,32 @@ k_ba_kf(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw,
 }
 
 /* ---- C: ordered reduction of the partials, lambda_0 */
+__global__ void __launch_bounds__(BA_T)
+k_ba_points(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw, const int* __restrict__ iw, BaState* __restrict__ states,
+            const int* __restrict__ errflag) {
+    ba_points_pass(d, obsAll, dw, iw, states, errflag, (int)blockIdx.x, (int)blockIdx.y);
+}
+__global__ void __launch_bounds__(BA_T)
+k_ba_kf(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw, const int* __restrict__ iw, const BaState* __restrict__ states,
+        const int* __restrict__ errflag) {
+    ba_kf_pass(d, obsAll, dw, iw, states, errflag, (int)blockIdx.x);
+}
+/* ---- A + B in one launch, for small batches (the replayed graph): the point pass and the keyframe pass are independent of each
+ * other (both read the state, each writes its own partials), so a batch that fills a fraction of the GPU runs them side by
+ * side and saves a launch per trial (the 8-frame BA call 1.02 -> 0.97 ms). The keyframe pass's workgroups come first (ids
+ * 0 ..: their window-per-XCD order needs id mod 8), then the point pass's. Large batches keep two launches: the fused kernel
+ * carries the keyframe pass's 32 KB of LDS in every workgroup, and the point pass's workgroups are meant to sit on CUs beside
+ * the extractor's, which leave ~10 KB free (measured inside the pipeline: 17.6 against 16.6-17.0 ms per 512-frame step). */
+__global__ void __launch_bounds__(BA_T)
+k_ba_lin(BaDims d, const tb_ba_obs* __restrict__ obsAll, double* __restrict__ dw, const int* __restrict__ iw, BaState* __restrict__ states,
+         const int* __restrict__ errflag, int nKfBlocks) {
+    if ((int)blockIdx.x < nKfBlocks) ba_kf_pass(d, obsAll, dw, iw, states, errflag, (int)blockIdx.x);
+    else {
+        const int b = (int)blockIdx.x - nKfBlocks;
+        ba_points_pass(d, obsAll, dw, iw, states, errflag, b % d.nblkP, b / d.nblkP);
+    }
+}
+
 /* per-keyframe Hpp / bp from the chunk partials in order, chi2 of the linearisation state and the first lambda: a launch of its
  * own in the first trial (k_ba_hinv needs that lambda before the Schur kernel runs) and for large windows, the prologue of
  * k_ba_solve -- one workgroup per window as well -- in every later trial (a launch less per trial: 5 us, the critical path of a
@@ -2492,12 +2517,22 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
     };
     /* one LM trial of every window: eight launches */
     auto enqueue_round = [&](int round) -> int {
-        tb_prof_begin(ctx, "k_ba_points");
-        hipLaunchKernelGGL(k_ba_points, dim3(d.nblkP, W), dim3(BA_T), (size_t)d.nkf * 12 * sizeof(double), s, d, d_obs, dw, iw, states, errflag);
-        tb_prof_end(ctx);
-        tb_prof_begin(ctx, "k_ba_kf");
-        hipLaunchKernelGGL(k_ba_kf, dim3(((W + 7) / 8) * 8 * std::min(BA_KFBLK, d.kfChunks) * d.nfree), dim3(BA_T), 0, s, d, d_obs, dw, iw, states);
-        tb_prof_end(ctx);
+        {
+            const int nKfBlocks = ((W + 7) / 8) * 8 * std::min(BA_KFBLK, d.kfChunks) * d.nfree;
+            if (W <= 32) {
+                tb_prof_begin(ctx, "k_ba_lin");
+                hipLaunchKernelGGL(k_ba_lin, dim3(nKfBlocks + d.nblkP * W), dim3(BA_T), (size_t)d.nkf * 12 * sizeof(double), s, d, d_obs, dw, iw, states,
+                                   errflag, nKfBlocks);
+                tb_prof_end(ctx);
+            } else {
+                tb_prof_begin(ctx, "k_ba_points");
+                hipLaunchKernelGGL(k_ba_points, dim3(d.nblkP, W), dim3(BA_T), (size_t)d.nkf * 12 * sizeof(double), s, d, d_obs, dw, iw, states, errflag);
+                tb_prof_end(ctx);
+                tb_prof_begin(ctx, "k_ba_kf");
+                hipLaunchKernelGGL(k_ba_kf, dim3(nKfBlocks), dim3(BA_T), 0, s, d, d_obs, dw, iw, states, errflag);
+                tb_prof_end(ctx);
+            }
+        }
         const bool reduce_in_solve = !d.big && round > 0;
         if (!reduce_in_solve) {
             tb_prof_begin(ctx, "k_ba_reduce");
