@@ -637,6 +637,12 @@ def report(args, pipe, prof, el, world, n_joined, dev):
             per_trial = {"k_ba_schur_pairs": sum(b.pair_items for b, _, _ in pipe.bas) * (8 + 2 * 16 + 96) + nwin_all * (np_ + 1) * np_ * 4,
                          "k_ba_solve_big": nwin_all * (np_ + 1) * np_ * 8}[name]
             abytes = per_trial * launches_per_step // max(len(pipe.bas), 1)
+        if name == "k_ba_solve" and pipe.bas:
+            # small batches: the one-wavefront-per-window solve is the longest kernel (a latency chain, not a bandwidth one).
+            # Its algorithmic bytes: the partial reduced systems the Schur wavefronts / workgroups wrote, read once.
+            nwin = pipe.bas[0][0].W
+            _, nb_all = schur_roofs(args.ba_pts, nwin, args.ba_kf, pipe.bas[0][0].free_edges)
+            abytes = (nb_all - pipe.bas[0][0].free_edges * 16 - nwin * args.ba_pts * 96) * launches_per_step
         per_launch = abytes / launches_per_step
         achieved = per_launch / 1e9 / (in_region_launch_ms / 1e3) if in_region_launch_ms > 0 else 0.0
         units = pipe.bas[0][0].W if name.startswith("k_ba_") and pipe.bas else nimg if name in EXTRACTOR_KERNELS else npairs
@@ -645,6 +651,10 @@ def report(args, pipe, prof, el, world, n_joined, dev):
                     "frac": round(achieved / HBM_PEAK_GBS, 5), "traffic": tr["bytes"] if tr else None,
                     "traffic_file": tr["file"] if tr else None, "traffic_scaled": tr["scaled"] if tr else None,
                     "algorithmic_bytes_per_launch": int(per_launch), **common}
+        if name == "k_ba_solve":
+            roofline["note"] = ("small batch: the longest kernel is a latency chain (assembly of the partial systems, then a 48-column "
+                                "factorisation on ONE wavefront per window), not a bandwidth-bound one; the HBM fraction says how far from "
+                                "any roof this shape is. `ba_schur` carries the Schur kernel's figures")
         if iso.get(name):
             roofline["isolated"] = {"avg_launch_ms": round(iso[name], 5),
                                     "achieved": round(per_launch / 1e9 / (iso[name] / 1e3), 2),
