@@ -150,6 +150,35 @@ def test_local_ba_bench_launch_shape(ctx):
     assert np.array_equal(P[0], P[3]) and np.array_equal(X[1], X[4])      # copies of one window agree bit for bit
 
 
+@pytest.mark.parametrize("W,peers", [(33, 1), (100, 1), (128, 1), (130, 1), (515, 1), (171, 3), (64, 2)])
+def test_local_ba_batch_shapes(W, peers):
+    """How the Schur launch deals its wavefronts depends on the batch: whole workgroups per window summed through LDS (small
+    batches: 33, 64 and 100 windows), a resident round of wavefronts dealt one by one (128: sixteen each; 130: fifteen or
+    sixteen), four per window when there are more windows than workgroup slots (515, or a context that shares the GPU:
+    tb_set_concurrency). Every window of every shape against the CPU solver; copies of one window agree bit for bit."""
+    import torch
+    from trackingbench_slam_amd.ba import BatchedLocalBA
+    c = capi.Context(0)
+    try:
+        c.set_concurrency(peers)
+        ba = BatchedLocalBA(c, W, nkf=7, npt=700, iters=4, seed=17, device=torch.device("cuda", 0), distinct=3)
+        ba.run()
+        torch.cuda.synchronize()
+        P = ba.poses.cpu().numpy(); X = ba.pts.cpu().numpy(); st = ba.stats.cpu().numpy()
+        ref = []
+        for w in range(3):
+            n = int(ba.host["counts"][w])
+            ref.append(oracle.local_ba(K, ba.host["poses"][w], 2, ba.host["pts"][w], ba.host["obs"][w, :n], 4))
+        for w in range(W):
+            io, Po, Xo, so = ref[w % 3]
+            _close(P[w].reshape(-1, 4, 4), Po)
+            _close(X[w], Xo)
+            assert np.isclose(st[w, 2], so[2], rtol=1e-6) and int(st[w, 0]) == io
+        assert np.array_equal(P[0], P[3 * ((W - 1) // 3)]) and np.array_equal(X[1], X[1 + 3 * ((W - 2) // 3)])
+    finally:
+        c.close()
+
+
 @pytest.mark.parametrize("seed,nkf,npt,per,pose_noise,pt_noise", [(50, 3, 40, 3, 3.0, 12.0), (53, 5, 100, 3, 2.0, 10.0), (58, 3, 40, 3, 3.0, 12.0),
                                                                     (53, 3, 40, 3, 3.0, 12.0)])
 def test_local_ba_rejected_steps(ctx, seed, nkf, npt, per, pose_noise, pt_noise):
