@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Driver for rocprofv3 passes and quick timing of the local-BA kernels: W windows of the bench size (10 keyframes, 5000
-points, 10 LM iterations), a few runs, per-kernel HIP-event times. Usage: python tools/prof_ba.py [windows] [reps] [distinct] [presort]"""
+points, 10 LM iterations), a few runs, per-kernel HIP-event times. Usage: python tools/prof_ba.py [windows] [reps] [distinct] [presort|-] [iters]"""
 import os
 import sys
 
@@ -13,9 +13,10 @@ W = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 2
 distinct = int(sys.argv[3]) if len(sys.argv) > 3 else 8
 presort = len(sys.argv) > 4 and sys.argv[4] == "presort"
+iters = int(sys.argv[5]) if len(sys.argv) > 5 else 10
 torch.cuda.set_device(0)
 ctx = capi.Context(0)  # own stream; BatchedLocalBA waits for its reset copies on the host
-ba = BatchedLocalBA(ctx, W, 10, 5000, 10, 0, torch.device("cuda", 0), distinct=distinct, presort=presort)
+ba = BatchedLocalBA(ctx, W, 10, 5000, iters, 0, torch.device("cuda", 0), distinct=distinct, presort=presort)
 ba.run()
 torch.cuda.synchronize()
 ctx.profile_enable(True)
