@@ -1734,49 +1734,68 @@ k_ba_solve(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, BaStat
      * column instead of an IEEE square root and a division, fused multiply-adds in the update, and the back-substitution
      * on a register copy of L^T (lane i = column i, transposed once through LDS) -- a wave-wide sum per column cost 48 x 12
      * LDS permutes; the kernel went from 54 to ~25 us per launch, the latency a small batch's LM trial waits for. */
-    if (tid < 64) {
-        const int i = tid;
-        double row[NS];
+    /* Factorisation on all four wavefronts (round 3, last change): lane i of EVERY wavefront is row i, wavefront v keeps the
+     * columns k with k % 4 == v. Column j's owner forms the pivot's reciprocal square root, scales its column and publishes
+     * it (LDS, double-buffered by column parity); after one barrier every wavefront subtracts it from ITS columns. The lone
+     * wavefront of rounds 1-3 was bound by its instruction count (~5000 in this loop; a version blocked by keyframe, with an
+     * eighth of the cross-lane exchanges, took the same time): here each wavefront issues a quarter of the multiply-adds and
+     * broadcast reads. */
+    __shared__ double dinvS[64];
+    __shared__ int goodS;
+    const int i = tid & 63, wv = tid >> 6;
+    constexpr int NC = NS / 4; /* columns per wavefront */
+    double myc[NC];
 #pragma unroll
-        for (int k = 0; k < NS; k++) {
-            /* lane np carries the reduced rhs (row np of A) as one more row below the matrix: the column steps turn it into
-             * y = L^-1 rhs -- the forward substitution costs nothing (it was a chain of 48 broadcast / multiply / subtract
-             * steps). Unconditional reads + selects: conditional ones became two branches per entry. */
-            const double a = A[min(i, np) * 65 + k];
-            row[k] = (i <= np && k < np && k <= i) ? a : ((k == i) ? 1.0 : 0.0);
-        }
-        bool good = st->sing == 0;
-        double dinv = 1.0; /* 1 / L[i][i] of this lane's row */
+    for (int kl = 0; kl < NC; kl++) {
+        /* lane np carries the reduced rhs (row np of A) as one more row below the matrix: the column steps turn it into
+         * y = L^-1 rhs -- no forward substitution. Unconditional reads + selects: conditional ones became branches. */
+        const int k = 4 * kl + wv;
+        const double a = A[min(i, np) * 65 + k];
+        myc[kl] = (i <= np && k < np && k <= i) ? a : ((k == i) ? 1.0 : 0.0);
+    }
+    if (tid == 0) goodS = st->sing == 0 ? 1 : 0;
+    if (tid < 64) dinvS[tid] = 1.0;
+    __syncthreads(); /* every wavefront has its columns out of A: A is free until the transpose */
 #pragma unroll
-        for (int j = 0; j < NS; j++) {
+    for (int j = 0; j < NS; j++) {
+        double* Lc = Lcol[j & 1];
+        if (wv == (j & 3)) { /* the owner of column j (wave-uniform) */
+            constexpr int dummy = 0; (void)dummy;
+            double& cj = myc[j >> 2];
             /* padding columns (j >= np) are identity -- and lane np, the rhs row, must not be read as a pivot */
-            const double djr = ba_readlane(row[j], j); /* read unconditionally: a conditional cross-lane read becomes a branch */
+            const double djr = ba_readlane(cj, j);
             const double dj = (j < np) ? djr : 1.0;
-            if (!(dj > 0) || !isfinite(dj)) good = false;
-            const double isj = ba_rsqrt(good ? dj : 1.0), sj = (good ? dj : 1.0) * isj;
-            if (i == j) dinv = isj;
-            row[j] = (i == j) ? sj : row[j] * isj; /* lanes i < j hold unused upper-triangle values */
-            /* column j of L through LDS: one store per lane, then L[k][j] is ONE broadcast read (every lane the same address)
-             * per update, issued beside the multiply-adds -- two v_readlane + wait states per update were 3/4 of this
-             * wavefront's instructions, and it is the only one working. (Forming the next pivot's reciprocal square root one
-             * column ahead in the source changes nothing: the compiler already interleaves the columns, and a lone wavefront
-             * issues one instruction per 4-5 clocks whatever its kind.) */
-            double* Lc = Lcol[j & 1];
-            Lc[i] = row[j];
-            ba_wave_lds_fence();
-#pragma unroll
-            for (int k = j + 1; k < NS; k++) row[k] = fma(-row[j], Lc[k], row[k]); /* only lanes i >= k are ever read back */
-            ba_wave_lds_fence();
+            const bool ok = (dj > 0) && isfinite(dj);
+            const double sg = ok ? dj : 1.0;
+            const double isj = ba_rsqrt(sg), sj = sg * isj;
+            cj = (i == j) ? sj : cj * isj; /* lanes i < j hold unused upper-triangle values */
+            Lc[i] = cj;
+            if (i == j) { dinvS[j] = isj; if (!ok) goodS = 0; }
         }
+        __syncthreads();
+        const double lij = Lc[i];
+#pragma unroll
+        for (int kl = 0; kl < NC; kl++) {
+            const int k = 4 * kl + wv; /* only lanes i >= k are ever read back */
+            if (4 * kl + 3 > j) myc[kl] = (k > j) ? fma(-lij, Lc[k], myc[kl]) : myc[kl];
+        }
+    }
+    /* L (lower triangle, the rhs row = y in row np) back into A for the back-substitution's transposed read */
+    if (i < NS || i == np) {
+#pragma unroll
+        for (int kl = 0; kl < NC; kl++) {
+            const int k = 4 * kl + wv;
+            A[i * 65 + k] = (k <= i) ? myc[kl] : 0.0;
+        }
+    }
+    __syncthreads();
 #ifdef BA_TIMING
-        ts_[2] = __builtin_readcyclecounter();
+    if (tid == 0) ts_[2] = __builtin_readcyclecounter();
 #endif
+    if (tid < 64) {
+        const bool good = goodS != 0;
+        const double dinv = dinvS[i]; /* 1 / L[i][i] */
         /* L^T into registers: lane i gets column i of L; lane np's row is y */
-        if (i < NS || i == np) {
-#pragma unroll
-            for (int k = 0; k < NS; k++) A[i * 65 + k] = (k <= i) ? row[k] : 0.0;
-        }
-        ba_wave_lds_fence();
         double col[NS];
 #pragma unroll
         for (int k = 0; k < NS; k++) col[k] = A[k * 65 + min(i, NS - 1)]; /* L[k][i], zero for k < i */
