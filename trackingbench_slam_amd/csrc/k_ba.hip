@@ -1727,13 +1727,11 @@ k_ba_solve(BaDims d, double* __restrict__ dw, const int* __restrict__ iw, BaStat
 #ifdef BA_TIMING
     ts_[1] = __builtin_readcyclecounter();
 #endif
-    /* One wave factorises and substitutes with the matrix in REGISTERS: lane i holds row i of the 64 x 64
-     * system (rows >= np are identity, so the padded part factors to itself); column j of L is broadcast
-     * with compile-time lane indices (v_readlane), so the O(n^3) loop is straight-line FMA code with no
-     * LDS round trips and no barriers. Right-looking Cholesky on the lower triangle. Round 3: one refined v_rsq_f64 per
-     * column instead of an IEEE square root and a division, fused multiply-adds in the update, and the back-substitution
-     * on a register copy of L^T (lane i = column i, transposed once through LDS) -- a wave-wide sum per column cost 48 x 12
-     * LDS permutes; the kernel went from 54 to ~25 us per launch, the latency a small batch's LM trial waits for. */
+    /* The matrix lives in REGISTERS: lane i holds row i of the 64 x 64 system (rows >= np are identity, so the padded part
+     * factors to itself), right-looking Cholesky on the lower triangle, no forward substitution (the rhs is one more row),
+     * back-substitution by ONE wavefront on a register copy of L^T (lane i = column i, transposed once through LDS). Rounds
+     * 1-2: one wavefront, columns broadcast with v_readlane, IEEE square root and division per column, branchy triangular
+     * solves: 54 us per launch; round 3: 28 us (171 windows). */
     /* Factorisation on all four wavefronts (round 3, last change): lane i of EVERY wavefront is row i, wavefront v keeps the
      * columns k with k % 4 == v. Column j's owner forms the pivot's reciprocal square root, scales its column and publishes
      * it (LDS, double-buffered by column parity); after one barrier every wavefront subtracts it from ITS columns. The lone
