@@ -332,7 +332,7 @@ def parse_args(argv=None):
     ap.add_argument("--no-ba", action="store_true", help="diagnostic only: drop the local-BA stage")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--region-events", choices=("auto", "dominant", "on", "off"), default="auto",
-                    help="HIP events inside the timed region: 'dominant' times the roofline's kernel only (k_ba_schur, 33 launches "
+                    help="HIP events inside the timed region: 'dominant' times the roofline's kernel only (k_ba_schur, 30 launches "
                          "per step), 'on' every kernel (~400 launches per step: two event records each cost ~2 %% of the step), "
                          "'off' none. auto: dominant above 64 frames per GPU; below, off (the event records are a third of a "
                          "~5 us kernel and keep the local-BA call from replaying its HIP graph). The per-kernel tables "

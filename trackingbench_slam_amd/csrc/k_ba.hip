@@ -2590,8 +2590,9 @@ int tbk_local_ba_batch(tb_ctx* ctx, int W, const double K[4], int nkf, int nfixe
     };
     int host_running = 1, rounds = 0, rc = TB_OK;
     const int max_rounds = std::min(iters * 10 + 1, 1000); /* ring size below */
-    int batch = iters + 1;
-    /* Small batches: the set-up and the first iters + 1 trials -- ~100 launches of a few microseconds each, which a host
+    int batch = iters; /* what every window needs at least; a speculative extra round (rounds 1-3) was seven empty launches on
+                          every call to save one host round trip on the calls with a rejected step */
+    /* Small batches: the set-up and the first `iters` trials -- ~100 launches of a few microseconds each, which a host
      * thread cannot queue as fast as the GPU retires them -- are captured ONCE into a HIP graph per (shape, buffers) and
      * replayed with one call (the kernels read their state from the workspace, so the graph is the same every time). Large
      * batches launch directly: their kernels are long enough for the queue to stay ahead, and the
